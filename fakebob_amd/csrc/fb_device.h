@@ -1,0 +1,126 @@
+// fb_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// RNG contract (identical, op for op, to the CPU oracle so that noise -- and
+// therefore every int16 sample and every attack decision -- is bit-identical):
+//   Philox4x32-10, key = seed, counter = (n/4, pair j, iteration, stream);
+//   the 4 output words give 4 consecutive samples via two float32 Box-Muller
+//   transforms built only from exactly-rounded primitives.
+// The library is compiled with -ffp-contract=off; every fused op is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FB_WAVE 64
+
+__device__ __forceinline__ void fb_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float fb_ln_u(float u) {  // u in (0,1]
+  uint32_t bits = __float_as_uint(u);
+  int e = (int)(bits >> 23) - 127;
+  float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+  if (m > 1.41421354f) { m = __fmul_rn(m, 0.5f); e += 1; }
+  float t = __fsub_rn(m, 1.0f);
+  float p = -1.0f / 20.0f;
+  p = __fmaf_rn(p, t, 1.0f / 19.0f);
+  p = __fmaf_rn(p, t, -1.0f / 18.0f);
+  p = __fmaf_rn(p, t, 1.0f / 17.0f);
+  p = __fmaf_rn(p, t, -1.0f / 16.0f);
+  p = __fmaf_rn(p, t, 1.0f / 15.0f);
+  p = __fmaf_rn(p, t, -1.0f / 14.0f);
+  p = __fmaf_rn(p, t, 1.0f / 13.0f);
+  p = __fmaf_rn(p, t, -1.0f / 12.0f);
+  p = __fmaf_rn(p, t, 1.0f / 11.0f);
+  p = __fmaf_rn(p, t, -1.0f / 10.0f);
+  p = __fmaf_rn(p, t, 1.0f / 9.0f);
+  p = __fmaf_rn(p, t, -1.0f / 8.0f);
+  p = __fmaf_rn(p, t, 1.0f / 7.0f);
+  p = __fmaf_rn(p, t, -1.0f / 6.0f);
+  p = __fmaf_rn(p, t, 1.0f / 5.0f);
+  p = __fmaf_rn(p, t, -1.0f / 4.0f);
+  p = __fmaf_rn(p, t, 1.0f / 3.0f);
+  p = __fmaf_rn(p, t, -1.0f / 2.0f);
+  p = __fmaf_rn(p, t, 1.0f);
+  p = __fmul_rn(p, t);
+  return __fmaf_rn((float)e, 0.693147182f, p);
+}
+
+__device__ __forceinline__ void fb_sincos_q(float a, float &s, float &c) {  // a in [0, pi/2)
+  float a2 = __fmul_rn(a, a);
+  float ps = -1.0f / 1307674368000.0f;
+  ps = __fmaf_rn(ps, a2, 1.0f / 6227020800.0f);
+  ps = __fmaf_rn(ps, a2, -1.0f / 39916800.0f);
+  ps = __fmaf_rn(ps, a2, 1.0f / 362880.0f);
+  ps = __fmaf_rn(ps, a2, -1.0f / 5040.0f);
+  ps = __fmaf_rn(ps, a2, 1.0f / 120.0f);
+  ps = __fmaf_rn(ps, a2, -1.0f / 6.0f);
+  ps = __fmaf_rn(ps, a2, 1.0f);
+  s = __fmul_rn(ps, a);
+  float pc = 1.0f / 20922789888000.0f;
+  pc = __fmaf_rn(pc, a2, -1.0f / 87178291200.0f);
+  pc = __fmaf_rn(pc, a2, 1.0f / 479001600.0f);
+  pc = __fmaf_rn(pc, a2, -1.0f / 3628800.0f);
+  pc = __fmaf_rn(pc, a2, 1.0f / 40320.0f);
+  pc = __fmaf_rn(pc, a2, -1.0f / 720.0f);
+  pc = __fmaf_rn(pc, a2, 1.0f / 24.0f);
+  pc = __fmaf_rn(pc, a2, -0.5f);
+  pc = __fmaf_rn(pc, a2, 1.0f);
+  c = pc;
+}
+
+__device__ __forceinline__ void fb_box_muller(uint32_t r0, uint32_t r1, float &z0, float &z1) {
+  float u1 = __fmul_rn((float)((r0 >> 8) + 1u), 5.9604644775390625e-08f);
+  uint32_t q = r1 >> 30;
+  uint32_t fr = (r1 & 0x3FFFFFFFu) >> 6;
+  float a = __fmul_rn((float)fr, 9.36227702e-08f);
+  float s, c;
+  fb_sincos_q(a, s, c);
+  float rr = __fsqrt_rn(__fmul_rn(-2.0f, fb_ln_u(u1)));
+  float cs, sn;
+  if (q == 0) { cs = c; sn = s; }
+  else if (q == 1) { cs = -s; sn = c; }
+  else if (q == 2) { cs = -c; sn = -s; }
+  else { cs = s; sn = -c; }
+  z0 = __fmul_rn(rr, cs);
+  z1 = __fmul_rn(rr, sn);
+}
+
+// 4 consecutive normals z[4*n4 .. 4*n4+3] of antithetic pair j
+__device__ __forceinline__ void fb_noise4(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t n4,
+                                          uint32_t j, float z[4]) {
+  uint32_t r[4];
+  fb_philox4x32_10(n4, j, iter, stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  fb_box_muller(r[0], r[1], z[0], z[1]);
+  fb_box_muller(r[2], r[3], z[2], z[3]);
+}
+
+// (x * 2^(bits-1)).astype(int16): trunc toward zero, keep the low 16 bits
+// (gmm_ubm_OSI.py:83-85; golden G5: 1.0 -> -32768)
+__device__ __forceinline__ int16_t fb_quantize(double x, double scale) {
+  double v = __dmul_rn(x, scale);
+  long long t;
+  if (!(v > -9.2e18 && v < 9.2e18)) t = 0;
+  else t = (long long)v;
+  return (int16_t)(uint16_t)((unsigned long long)t & 0xFFFFull);
+}
+
+__device__ __forceinline__ double fb_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double fb_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}

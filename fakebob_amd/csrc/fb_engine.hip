@@ -1,0 +1,912 @@
+// fb_engine.hip -- host side of libfakebob_hip.so: engine state, device buffers,
+// model/front-end table preparation and the C ABI (include/fakebob_hip.h).
+//
+// One engine = one GPU + one HIP stream.  A NES iteration is a fixed chain of
+// launches on that stream with a single 8-byte-aligned result block copied back
+// through pinned memory; nothing else crosses PCIe inside the attack loop.
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "fb_kernels.h"
+
+static thread_local std::string g_err;
+static int fb_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t _e = (x);                                                                           \
+    if (_e != hipSuccess)                                                                          \
+      return fb_fail(FB_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define FBCHK(x)            \
+  do {                      \
+    int _r = (x);           \
+    if (_r != FB_OK) return _r; \
+  } while (0)
+
+extern "C" const char *fb_last_error(void) { return g_err.c_str(); }
+extern "C" int fb_version(void) { return 100; }
+extern "C" int fb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return FB_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return fb_fail(FB_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    cap = want;
+    return FB_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct fb_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // front-end
+  bool have_fe = false;
+  fb_frontend_cfg cfg;
+  FbFrontendDev fe;
+  DevBuf fe_tables;
+  // gmm
+  bool have_gmm = false;
+  FbGmmDev gmm;
+  DevBuf gmm_images, gmm_items;
+  int n_groups = 0;
+  // system
+  int task = FB_TASK_OSI;
+  DevBuf zmean, zstd;
+  std::vector<double> h_zmean, h_zstd;
+  // batch scratch
+  DevBuf wav, wav_off, frame_off, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
+  std::vector<int64_t> h_wav_off;
+  std::vector<int> h_frame_off;
+  int cached_B = -1;
+  int64_t cached_N = -1;
+  int last_total_frames = 0, last_B = 0, last_chunks = 1;
+  // NES state
+  DevBuf audio, adver, grad_m, grad, noise, scores, loss, dist_part, nes_out, stage_f64;
+  FbNesDev *h_out = nullptr;  // pinned
+  int *h_tv = nullptr;        // pinned, grows
+  size_t h_tv_cap = 0;
+  // stats
+  int64_t scored_utts = 0, scored_frames = 0, voiced_frames = 0, nes_iters = 0;
+};
+
+// ------------------------------------------------------------------ create
+extern "C" int fb_engine_create(int device, fb_engine **out) {
+  if (!out) return fb_fail(FB_E_ARG, "out is NULL");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fb_fail(FB_E_ARG, "device %d out of range (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  fb_engine *e = new fb_engine();
+  e->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&e->ev0));
+  HIPCHK(hipEventCreate(&e->ev1));
+  HIPCHK(hipHostMalloc((void **)&e->h_out, sizeof(FbNesDev), hipHostMallocDefault));
+  fb_frontend_cfg cfg;
+  fb_default_frontend(&cfg);
+  *out = e;
+  int rc = fb_set_frontend(e, &cfg);
+  if (rc != FB_OK) { fb_engine_destroy(e); *out = nullptr; return rc; }
+  return FB_OK;
+}
+
+extern "C" int fb_engine_destroy(fb_engine *e) {
+  if (!e) return FB_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+                    &e->frame_off, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise,
+                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64};
+  for (DevBuf *b : bufs) b->release();
+  if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->h_tv) (void)hipHostFree(e->h_tv);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return FB_OK;
+}
+
+// ---------------------------------------------------------------- frontend
+extern "C" void fb_default_frontend(fb_frontend_cfg *c) {
+  // [EXT] voxceleb/v1 conf/mfcc.conf, conf/vad.conf, delta_opts
+  c->sample_freq = 16000.0; c->frame_length = 400; c->frame_shift = 160; c->padded_length = 512;
+  c->num_mel_bins = 30; c->num_ceps = 24; c->low_freq = 20.0; c->high_freq = 7600.0;
+  c->preemph = 0.97; c->cepstral_lifter = 22.0; c->snip_edges = 0; c->remove_dc = 1;
+  c->use_energy = 1; c->raw_energy = 1; c->energy_floor = 0.0;
+  c->vad_energy_threshold = 5.5; c->vad_energy_mean_scale = 0.5; c->vad_proportion_threshold = 0.12;
+  c->vad_frames_context = 2; c->delta_window = 3; c->delta_order = 2; c->cmn_window = 300;
+}
+
+static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+
+extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
+  if (!e || !c) return fb_fail(FB_E_ARG, "null argument");
+  const int L = c->frame_length, P = c->padded_length, nb = c->num_mel_bins, nc = c->num_ceps;
+  if (L <= 1 || L > 512 || P < L || (P & (P - 1)) || P < 8 || P > 4096)
+    return fb_fail(FB_E_ARG, "frame_length %d / padded_length %d unsupported (need L<=512, P power of 2)", L, P);
+  if (nb <= 0 || nb > 128 || nc <= 0 || nc > nb || c->frame_shift <= 0)
+    return fb_fail(FB_E_ARG, "bad mel/ceps/shift configuration");
+  if (c->delta_order < 0 || c->delta_order > 4 || c->delta_window <= 0 || c->delta_window > 8)
+    return fb_fail(FB_E_ARG, "bad delta options");
+  const int dim = nc * (c->delta_order + 1);
+  if (dim > 256) return fb_fail(FB_E_ARG, "feature dim %d > 256 unsupported", dim);
+  HIPCHK(hipSetDevice(e->device));
+  const int Nc = P / 2;
+  // ---- host tables; float32-stored Kaldi constants are rounded to float first
+  std::vector<double> window(L), tw_half(2 * (size_t)(Nc > 1 ? Nc : 1)), tw_full(2 * (size_t)(Nc + 1));
+  const double a = 2.0 * M_PI / (L - 1);
+  for (int i = 0; i < L; ++i) window[i] = (double)(float)pow(0.5 - 0.5 * cos(a * i), 0.85);
+  for (int m = 0; m < Nc; ++m) { tw_half[2 * m] = cos(-2.0 * M_PI * m / Nc); tw_half[2 * m + 1] = sin(-2.0 * M_PI * m / Nc); }
+  for (int k = 0; k <= Nc; ++k) { tw_full[2 * k] = cos(-2.0 * M_PI * k / P); tw_full[2 * k + 1] = sin(-2.0 * M_PI * k / P); }
+  std::vector<int> mel_first(nb), mel_len(nb), mel_off(nb);
+  std::vector<double> mel_w;
+  {
+    const double nyq = 0.5 * c->sample_freq;
+    const double hi = c->high_freq > 0.0 ? c->high_freq : nyq + c->high_freq;
+    if (c->low_freq < 0.0 || hi <= c->low_freq || hi > nyq) return fb_fail(FB_E_ARG, "bad mel frequency range");
+    const double bw = c->sample_freq / P;
+    const double mlo = mel_scale(c->low_freq), mhi = mel_scale(hi), md = (mhi - mlo) / (nb + 1);
+    for (int b = 0; b < nb; ++b) {
+      const double left = mlo + b * md, center = mlo + (b + 1) * md, right = mlo + (b + 2) * md;
+      int first = -1, last = -1;
+      std::vector<double> wts;
+      for (int i = 0; i < Nc; ++i) {
+        const double mel = mel_scale(bw * i);
+        if (mel > left && mel < right) {
+          const double wv = mel <= center ? (mel - left) / (center - left) : (right - mel) / (right - center);
+          if (first < 0) first = i;
+          last = i;
+          wts.push_back((double)(float)wv);
+        }
+      }
+      mel_first[b] = first < 0 ? 0 : first;
+      mel_len[b] = first < 0 ? 0 : last - first + 1;
+      mel_off[b] = (int)mel_w.size();
+      mel_w.insert(mel_w.end(), wts.begin(), wts.end());
+    }
+  }
+  std::vector<double> dct((size_t)nc * nb), lifter(nc);
+  for (int k = 0; k < nc; ++k)
+    for (int n = 0; n < nb; ++n)
+      dct[(size_t)k * nb + n] = (k == 0) ? (double)(float)sqrt(1.0 / nb)
+                                         : (double)(float)(sqrt(2.0 / nb) * cos(M_PI / nb * (n + 0.5) * k));
+  for (int i = 0; i < nc; ++i)
+    lifter[i] = c->cepstral_lifter != 0.0
+                    ? (double)(float)(1.0 + 0.5 * c->cepstral_lifter * sin(M_PI * i / c->cepstral_lifter))
+                    : 1.0;
+  const int order = c->delta_order, W = c->delta_window, maxlen = 2 * order * W + 1;
+  std::vector<double> dscale((size_t)(order + 1) * maxlen, 0.0);
+  dscale[0] = 1.0;
+  for (int i = 1; i <= order; ++i) {
+    const double *prev = &dscale[(size_t)(i - 1) * maxlen];
+    double *cur = &dscale[(size_t)i * maxlen];
+    const int poff = (i - 1) * W, coff = i * W;
+    double normalizer = 0.0;
+    for (int j = -W; j <= W; ++j) {
+      normalizer += (double)j * j;
+      for (int k = -poff; k <= poff; ++k) cur[j + k + coff] += (double)j * prev[k + poff];
+    }
+    for (int k = 0; k < 2 * coff + 1; ++k) cur[k] = (double)(float)(cur[k] / normalizer);
+  }
+  // ---- pack into one device allocation
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  size_t off = 0;
+  const size_t o_window = off; off = al(off + sizeof(double) * window.size());
+  const size_t o_twh = off; off = al(off + sizeof(double) * tw_half.size());
+  const size_t o_twf = off; off = al(off + sizeof(double) * tw_full.size());
+  const size_t o_mf = off; off = al(off + sizeof(int) * nb);
+  const size_t o_ml = off; off = al(off + sizeof(int) * nb);
+  const size_t o_mo = off; off = al(off + sizeof(int) * nb);
+  const size_t o_mw = off; off = al(off + sizeof(double) * (mel_w.size() + 1));
+  const size_t o_dct = off; off = al(off + sizeof(double) * dct.size());
+  const size_t o_lift = off; off = al(off + sizeof(double) * lifter.size());
+  const size_t o_ds = off; off = al(off + sizeof(double) * dscale.size());
+  std::vector<char> host(off, 0);
+  memcpy(&host[o_window], window.data(), sizeof(double) * window.size());
+  memcpy(&host[o_twh], tw_half.data(), sizeof(double) * tw_half.size());
+  memcpy(&host[o_twf], tw_full.data(), sizeof(double) * tw_full.size());
+  memcpy(&host[o_mf], mel_first.data(), sizeof(int) * nb);
+  memcpy(&host[o_ml], mel_len.data(), sizeof(int) * nb);
+  memcpy(&host[o_mo], mel_off.data(), sizeof(int) * nb);
+  if (!mel_w.empty()) memcpy(&host[o_mw], mel_w.data(), sizeof(double) * mel_w.size());
+  memcpy(&host[o_dct], dct.data(), sizeof(double) * dct.size());
+  memcpy(&host[o_lift], lifter.data(), sizeof(double) * lifter.size());
+  memcpy(&host[o_ds], dscale.data(), sizeof(double) * dscale.size());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(e->fe_tables.ensure(off));
+  HIPCHK(hipMemcpy(e->fe_tables.p, host.data(), off, hipMemcpyHostToDevice));
+  char *base = e->fe_tables.as<char>();
+  FbFrontendDev &fe = e->fe;
+  fe.L = L; fe.P = P; fe.shift = c->frame_shift; fe.nb = nb; fe.nc = nc; fe.dim = dim; fe.order = order;
+  fe.dwin = W; fe.cmn_window = c->cmn_window; fe.snip_edges = c->snip_edges; fe.remove_dc = c->remove_dc;
+  fe.use_energy = c->use_energy; fe.raw_energy = c->raw_energy; fe.vad_ctx = c->vad_frames_context;
+  fe.preemph = c->preemph;
+  fe.log_energy_floor = c->energy_floor > 0.0 ? log(c->energy_floor) : -INFINITY;
+  fe.vad_thr = c->vad_energy_threshold; fe.vad_mean_scale = c->vad_energy_mean_scale;
+  fe.vad_prop = (float)c->vad_proportion_threshold;
+  fe.window = (const double *)(base + o_window); fe.tw_half = (const double *)(base + o_twh);
+  fe.tw_full = (const double *)(base + o_twf); fe.mel_first = (const int *)(base + o_mf);
+  fe.mel_len = (const int *)(base + o_ml); fe.mel_off = (const int *)(base + o_mo);
+  fe.mel_w = (const double *)(base + o_mw); fe.dct = (const double *)(base + o_dct);
+  fe.lifter = (const double *)(base + o_lift); fe.dscale = (const double *)(base + o_ds);
+  e->cfg = *c;
+  e->have_fe = true;
+  e->cached_B = -1;
+  if (e->have_gmm && e->gmm.D != dim) e->have_gmm = false;
+  return FB_OK;
+}
+
+static int num_frames(const fb_frontend_cfg &c, int64_t n) {
+  if (c.snip_edges) return n < c.frame_length ? 0 : (int)(1 + (n - c.frame_length) / c.frame_shift);
+  return (int)((n + c.frame_shift / 2) / c.frame_shift);
+}
+
+// --------------------------------------------------------------------- gmm
+extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gconsts, const float *miv,
+                           const float *iv) {
+  if (!e || !gconsts || !miv || !iv) return fb_fail(FB_E_ARG, "null argument");
+  if (M <= 0 || C <= 0 || D <= 0) return fb_fail(FB_E_ARG, "bad GMM shape M=%d C=%d D=%d", M, C, D);
+  if (M > 60) return fb_fail(FB_E_ARG, "at most 60 models per engine (got %d)", M);
+  if (!e->have_fe || e->fe.dim != D)
+    return fb_fail(FB_E_ARG, "GMM dim %d != front-end feature dim %d", D, e->have_fe ? e->fe.dim : -1);
+  static const int khs[] = {20, 32, 36, 40};
+  int KH = -1;
+  for (int k : khs) if (2 * k >= D) { KH = k; break; }
+  if (KH < 0) return fb_fail(FB_E_ARG, "feature dim %d > 80 unsupported by the MFMA kernel", D);
+  HIPCHK(hipSetDevice(e->device));
+  // groups of models with bitwise-identical inv_vars
+  std::vector<int> group_of(M, -1);
+  std::vector<int> group_rep;
+  for (int m = 0; m < M; ++m) {
+    for (size_t g = 0; g < group_rep.size(); ++g)
+      if (memcmp(iv + (size_t)m * C * D, iv + (size_t)group_rep[g] * C * D, sizeof(float) * (size_t)C * D) == 0) {
+        group_of[m] = (int)g;
+        break;
+      }
+    if (group_of[m] < 0) { group_of[m] = (int)group_rep.size(); group_rep.push_back(m); }
+  }
+  const int G = (int)group_rep.size();
+  std::vector<int> item_model;
+  for (int g = 0; g < G; ++g) {
+    item_model.push_back(-1 - g);  // Q item of group g (any negative = Q)
+    for (int m = 0; m < M; ++m) if (group_of[m] == g) item_model.push_back(m);
+  }
+  const int n_items = (int)item_model.size();
+  const int n_tiles = (C + 31) / 32;
+  const int ROWF = 2 * KH + 4, IMGF = 32 * ROWF + 32;
+  std::vector<float> img((size_t)n_tiles * n_items * IMGF, 0.0f);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int it = 0; it < n_items; ++it) {
+      float *im = &img[((size_t)t * n_items + it) * IMGF];
+      const int im_model = item_model[it];
+      for (int cc = 0; cc < 32; ++cc) {
+        const int c = t * 32 + cc;
+        float *row = im + (size_t)cc * ROWF;
+        if (c < C) {
+          if (im_model < 0) {
+            const float *src = iv + ((size_t)group_rep[-1 - im_model] * C + c) * D;
+            for (int d = 0; d < D; ++d) row[d] = -0.5f * src[d];
+          } else {
+            const float *src = miv + ((size_t)im_model * C + c) * D;
+            for (int d = 0; d < D; ++d) row[d] = src[d];
+          }
+        }
+        if (im_model >= 0) im[32 * ROWF + cc] = c < C ? gconsts[(size_t)im_model * C + c] : -1.0e30f;
+      }
+    }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
+  HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
+  std::vector<int> im_dev(item_model);
+  FBCHK(e->gmm_items.ensure(sizeof(int) * im_dev.size()));
+  HIPCHK(hipMemcpy(e->gmm_items.p, im_dev.data(), sizeof(int) * im_dev.size(), hipMemcpyHostToDevice));
+  FbGmmDev &g = e->gmm;
+  g.M = M; g.C = C; g.D = D; g.KH = KH; g.n_tiles = n_tiles; g.n_items = n_items; g.img_floats = IMGF;
+  g.images = e->gmm_images.as<float>();
+  g.item_model = e->gmm_items.as<int>();
+  e->n_groups = G;
+  e->have_gmm = true;
+  // default system: OSI (UBM first) without z-norm
+  e->h_zmean.assign(M, 0.0);
+  e->h_zstd.assign(M, 1.0);
+  FBCHK(e->zmean.ensure(sizeof(double) * M));
+  FBCHK(e->zstd.ensure(sizeof(double) * M));
+  HIPCHK(hipMemcpy(e->zmean.p, e->h_zmean.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->zstd.p, e->h_zstd.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  return FB_OK;
+}
+
+extern "C" int fb_set_system(fb_engine *e, int task, const double *z_mean, const double *z_std) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "load a model first");
+  if (task != FB_TASK_OSI && task != FB_TASK_CSI && task != FB_TASK_SV) return fb_fail(FB_E_ARG, "bad task");
+  const int M = e->gmm.M;
+  if (task != FB_TASK_CSI && M < 2) return fb_fail(FB_E_ARG, "OSI/SV need the UBM + >=1 speaker model");
+  if (task == FB_TASK_SV && M != 2) return fb_fail(FB_E_ARG, "SV takes exactly [ubm, speaker]");
+  HIPCHK(hipSetDevice(e->device));
+  e->task = task;
+  for (int m = 0; m < M; ++m) {
+    e->h_zmean[m] = (task == FB_TASK_CSI && z_mean) ? z_mean[m] : 0.0;
+    e->h_zstd[m] = (task == FB_TASK_CSI && z_std) ? z_std[m] : 1.0;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->zmean.p, e->h_zmean.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->zstd.p, e->h_zstd.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  return FB_OK;
+}
+
+extern "C" int fb_num_speakers(fb_engine *e) {
+  if (!e || !e->have_gmm) return 0;
+  return e->task == FB_TASK_CSI ? e->gmm.M : e->gmm.M - 1;
+}
+
+// ------------------------------------------------------- scoring pipeline
+// Prepares offsets for a batch whose int16 samples are already in e->wav.
+static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
+  e->h_wav_off.assign(off, off + B + 1);
+  e->h_frame_off.resize(B + 1);
+  e->h_frame_off[0] = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = off[b + 1] - off[b];
+    if (n <= 0) return fb_fail(FB_E_ARG, "utterance %d is empty", b);
+    const int T = num_frames(e->cfg, n);
+    if (T <= 0) return fb_fail(FB_E_ARG, "utterance %d (%lld samples) is shorter than one frame", b, (long long)n);
+    e->h_frame_off[b + 1] = e->h_frame_off[b] + T;
+  }
+  FBCHK(e->wav_off.ensure(sizeof(int64_t) * (B + 1)));
+  FBCHK(e->frame_off.ensure(sizeof(int) * (B + 1)));
+  HIPCHK(hipMemcpyAsync(e->wav_off.p, e->h_wav_off.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->frame_off.p, e->h_frame_off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, e->stream));
+  // the host vectors must outlive the async copies: they are members, and the next overwrite
+  // happens only after a stream sync in the callers.
+  return FB_OK;
+}
+
+static int choose_chunks(const FbGmmDev &g, int rows_cap) {
+  const int strips = (rows_cap + 127) / 128;
+  int want = (1536 + strips - 1) / strips;
+  if (want < 1) want = 1;
+  if (want > g.n_tiles) want = g.n_tiles;
+  const int tpc = (g.n_tiles + want - 1) / want;
+  return (g.n_tiles + tpc - 1) / tpc;
+}
+
+// wav (device) + offsets (device) -> raw[B][M] (device).  Purely asynchronous.
+static int run_scoring(fb_engine *e, int B, int total_frames) {
+  const FbFrontendDev &fe = e->fe;
+  const FbGmmDev &g = e->gmm;
+  FBCHK(e->mfcc.ensure(sizeof(float) * (size_t)total_frames * fe.nc));
+  FBCHK(e->vrank.ensure(sizeof(int) * (size_t)total_frames));
+  FBCHK(e->tv.ensure(sizeof(int) * (size_t)B));
+  FBCHK(e->row_off.ensure(sizeof(int) * (size_t)(B + 1)));
+  FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
+  FBCHK(e->feats.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
+  const int n_chunks = choose_chunks(g, total_frames);
+  FBCHK(e->part_m.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
+  FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
+  FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * g.M));
+  hipStream_t s = e->stream;
+  fb_launch_mfcc(s, fe, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), B, total_frames,
+                 e->mfcc.as<float>());
+  fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>());
+  fb_launch_rowscan(s, e->tv.as<int>(), B, e->row_off.as<int>());
+  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, total_frames, e->dfeat.as<float>());
+  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(), e->row_off.as<int>(), B,
+                 e->feats.as<float>());
+  fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
+                e->part_m.as<float>(), e->part_s.as<float>());
+  fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
+                         e->row_off.as<int>(), B, e->raw.as<double>());
+  HIPCHK(hipGetLastError());
+  e->last_total_frames = total_frames;
+  e->last_B = B;
+  e->last_chunks = n_chunks;
+  e->scored_utts += B;
+  e->scored_frames += total_frames;
+  return FB_OK;
+}
+
+static int ensure_host_tv(fb_engine *e, int B) {
+  if ((size_t)B <= e->h_tv_cap) return FB_OK;
+  if (e->h_tv) (void)hipHostFree(e->h_tv);
+  e->h_tv = nullptr;
+  e->h_tv_cap = 0;
+  HIPCHK(hipHostMalloc((void **)&e->h_tv, sizeof(int) * (size_t)(B + 64), hipHostMallocDefault));
+  e->h_tv_cap = (size_t)B + 64;
+  return FB_OK;
+}
+
+static int finish_score(fb_engine *e, int B, double *raw, int *tv) {
+  FBCHK(ensure_host_tv(e, B));
+  HIPCHK(hipMemcpyAsync(raw, e->raw.p, sizeof(double) * (size_t)B * e->gmm.M, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_tv, e->tv.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int bad = -1;
+  for (int b = 0; b < B; ++b) {
+    if (tv) tv[b] = e->h_tv[b];
+    e->voiced_frames += e->h_tv[b];
+    if (e->h_tv[b] <= 0 && bad < 0) bad = b;
+  }
+  if (bad >= 0) return fb_fail(FB_E_NO_VOICED, "utterance %d has no voiced frames", bad);
+  return FB_OK;
+}
+
+extern "C" int fb_score_i16(fb_engine *e, const int16_t *wav, const int64_t *off, int B, double *raw, int *tv) {
+  if (!e || !wav || !off || !raw || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int64_t total = off[B] - off[0];
+  if (off[0] != 0) return fb_fail(FB_E_ARG, "off[0] must be 0");
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)total));
+  HIPCHK(hipMemcpyAsync(e->wav.p, wav, sizeof(int16_t) * (size_t)total, hipMemcpyHostToDevice, e->stream));
+  FBCHK(prepare_batch(e, off, B));
+  e->cached_B = -1;
+  FBCHK(run_scoring(e, B, e->h_frame_off[B]));
+  return finish_score(e, B, raw, tv);
+}
+
+extern "C" int fb_score_f64(fb_engine *e, const double *audio, const int64_t *off, int B, int bits, double *raw,
+                            int *tv) {
+  if (!e || !audio || !off || !raw || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (bits < 2 || bits > 16) return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported", bits);
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (off[0] != 0) return fb_fail(FB_E_ARG, "off[0] must be 0");
+  const int64_t total = off[B];
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)total));
+  FBCHK(e->stage_f64.ensure(sizeof(double) * (size_t)total));
+  HIPCHK(hipMemcpyAsync(e->stage_f64.p, audio, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, e->stream));
+  fb_launch_quantize(e->stream, e->stage_f64.as<double>(), total, bits, e->wav.as<int16_t>());
+  FBCHK(prepare_batch(e, off, B));
+  e->cached_B = -1;
+  FBCHK(run_scoring(e, B, e->h_frame_off[B]));
+  return finish_score(e, B, raw, tv);
+}
+
+extern "C" int fb_system_scores(fb_engine *e, const double *raw, int B, double *scores) {
+  if (!e || !raw || !scores || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no model loaded");
+  const int M = e->gmm.M;
+  if (e->task == FB_TASK_CSI) {
+    for (int b = 0; b < B; ++b)
+      for (int m = 0; m < M; ++m)
+        scores[(size_t)b * M + m] = (raw[(size_t)b * M + m] - e->h_zmean[m]) / e->h_zstd[m];
+  } else {
+    const int S = M - 1;
+    for (int b = 0; b < B; ++b)
+      for (int s = 0; s < S; ++s) scores[(size_t)b * S + s] = raw[(size_t)b * M + 1 + s] - raw[(size_t)b * M];
+  }
+  return FB_OK;
+}
+
+// --------------------------------------------------------------------- NES
+static int check_params(fb_engine *e, const fb_nes_params *p, int64_t N) {
+  if (!e || !p) return fb_fail(FB_E_ARG, "null argument");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no model loaded");
+  if (N <= 0) return fb_fail(FB_E_ARG, "empty audio");
+  if (p->task != e->task) return fb_fail(FB_E_ARG, "params.task %d != engine system task %d", p->task, e->task);
+  const int S = fb_num_speakers(e);
+  if (S > 62) return fb_fail(FB_E_ARG, "more than 62 speakers unsupported in the NES result block");
+  if (p->samples_per_draw < 0 || p->samples_per_draw > 4094) return fb_fail(FB_E_ARG, "bad samples_per_draw");
+  if (p->task != FB_TASK_SV && p->attack_type == FB_TARGETED && (p->target < 0 || p->target >= S))
+    return fb_fail(FB_E_ARG, "target %d out of range", p->target);
+  if (p->task == FB_TASK_CSI && p->attack_type == FB_UNTARGETED && (p->true_label < 0 || p->true_label >= S))
+    return fb_fail(FB_E_ARG, "true label %d out of range", p->true_label);
+  if (!(p->sigma > 0.0) && p->samples_per_draw >= 2) return fb_fail(FB_E_ARG, "sigma must be > 0");
+  if (num_frames(e->cfg, N) <= 0) return fb_fail(FB_E_ARG, "audio shorter than one frame");
+  return FB_OK;
+}
+
+// (re)builds the equal-length batch layout of B utterances of N samples
+static int prepare_nes_batch(fb_engine *e, int64_t N, int B) {
+  if (e->cached_B == B && e->cached_N == N) return FB_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<int64_t> off(B + 1);
+  for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N * B));
+  FBCHK(prepare_batch(e, off.data(), B));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->cached_B = B;
+  e->cached_N = N;
+  return FB_OK;
+}
+
+static int ensure_nes_buffers(fb_engine *e, int64_t N, int B) {
+  const int S = fb_num_speakers(e);
+  FBCHK(e->audio.ensure(sizeof(double) * (size_t)N));
+  FBCHK(e->adver.ensure(sizeof(double) * (size_t)N));
+  FBCHK(e->grad_m.ensure(sizeof(double) * (size_t)N));
+  FBCHK(e->grad.ensure(sizeof(double) * (size_t)N));
+  FBCHK(e->scores.ensure(sizeof(double) * (size_t)B * (S > 0 ? S : 1)));
+  FBCHK(e->loss.ensure(sizeof(double) * (size_t)B));
+  FBCHK(e->dist_part.ensure(sizeof(double) * (size_t)((N + 1023) / 1024 + 1)));
+  FBCHK(e->nes_out.ensure(sizeof(FbNesDev)));
+  return FB_OK;
+}
+
+// One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
+static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
+                            const double *noise_dev, bool with_dist) {
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1;
+  int ndp = 0;
+  fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
+                    p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
+                    e->dist_part.as<double>(), &ndp);
+  FBCHK(run_scoring(e, B, e->h_frame_off[B]));
+  fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->gmm.M, p->task, p->attack_type,
+                 e->zmean.as<double>(), e->zstd.as<double>(), p->threshold, p->adver_thresh, p->target,
+                 p->true_label, e->dist_part.as<double>(), with_dist ? ndp : 0, e->scores.as<double>(),
+                 e->loss.as<double>(), e->nes_out.as<FbNesDev>());
+  return FB_OK;
+}
+
+static int fetch_out(fb_engine *e) {
+  HIPCHK(hipMemcpyAsync(e->h_out, e->nes_out.p, sizeof(FbNesDev), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->h_out->err != 0)
+    return fb_fail(FB_E_NO_VOICED, "NES sample %d has no voiced frames", e->h_out->err - 1);
+  return FB_OK;
+}
+
+extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *audio, int64_t N, uint32_t iter,
+                           const double *noise_pos, double *final_loss, double *grad, double *adver_loss,
+                           double *score0) {
+  if (!audio) return fb_fail(FB_E_ARG, "audio is NULL");
+  FBCHK(check_params(e, p, N));
+  HIPCHK(hipSetDevice(e->device));
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
+  FBCHK(prepare_nes_batch(e, N, B));
+  FBCHK(ensure_nes_buffers(e, N, B));
+  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  const double *noise_dev = nullptr;
+  if (noise_pos && half > 0) {
+    FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
+    HIPCHK(hipMemcpyAsync(e->noise.p, noise_pos, sizeof(double) * (size_t)N * half, hipMemcpyHostToDevice, e->stream));
+    noise_dev = e->noise.as<double>();
+  }
+  FBCHK(enqueue_get_grad(e, p, N, iter, noise_dev, false));
+  fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, iter, p->stream, noise_dev,
+                        e->grad.as<double>(), 0, 0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr);
+  if (grad) HIPCHK(hipMemcpyAsync(grad, e->grad.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  FBCHK(fetch_out(e));
+  e->nes_iters += 1;
+  if (final_loss) *final_loss = e->h_out->final_loss;
+  if (adver_loss) *adver_loss = e->h_out->adver_loss;
+  if (score0) for (int s = 0; s < S; ++s) score0[s] = e->h_out->score0[s];
+  return FB_OK;
+}
+
+struct Plateau {  // FAKEBOB.py:195-200
+  std::vector<double> ls;
+  double lr;
+  void step(double loss, const fb_nes_params *p) {
+    ls.push_back(loss);
+    if ((int)ls.size() > p->plateau_length) ls.erase(ls.begin(), ls.end() - p->plateau_length);
+    if (!ls.empty() && ls.back() > ls.front() && (int)ls.size() == p->plateau_length) {
+      if (lr > p->min_lr) { double l2 = lr / p->plateau_drop; lr = l2 > p->min_lr ? l2 : p->min_lr; }
+      ls.clear();
+    }
+  }
+};
+
+extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *audio, int64_t N,
+                         const double *noise_all, int16_t *adv_i16, double *adver_f64, double *trace,
+                         int *n_trace, int *success_flag) {
+  if (!audio || !adv_i16 || !success_flag) return fb_fail(FB_E_ARG, "null argument");
+  FBCHK(check_params(e, p, N));
+  if (p->max_iter <= 0) return fb_fail(FB_E_ARG, "max_iter must be > 0");
+  HIPCHK(hipSetDevice(e->device));
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
+  FBCHK(prepare_nes_batch(e, N, B));
+  FBCHK(ensure_nes_buffers(e, N, B));
+  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));  // grad = 0 (:157)
+  if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
+  Plateau pl;
+  pl.lr = p->max_lr;
+  const double one_minus_m = 1.0 - p->momentum;
+  int rows = 0, it = 0;
+  bool broke = false;
+  for (it = 0; it < p->max_iter; ++it) {
+    const double *noise_dev = nullptr;
+    if (noise_all && half > 0) {
+      HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half,
+                            hipMemcpyHostToDevice, e->stream));
+      noise_dev = e->noise.as<double>();
+    }
+    FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true));
+    FBCHK(fetch_out(e));
+    e->nes_iters += 1;
+    double *row = trace ? trace + (size_t)rows * (3 + S) : nullptr;
+    const double adver_loss = e->h_out->adver_loss;
+    if (adver_loss < 0.0) {  // :181
+      if (row) { row[0] = e->h_out->distance; row[1] = adver_loss; row[2] = pl.lr; for (int s = 0; s < S; ++s) row[3 + s] = e->h_out->score0[s]; }
+      ++rows;
+      broke = true;
+      break;
+    }
+    pl.step(e->h_out->final_loss, p);
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, (uint32_t)it, p->stream,
+                          noise_dev, nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon,
+                          e->audio.as<double>(), e->grad_m.as<double>(), e->adver.as<double>());
+    if (row) { row[0] = e->h_out->distance; row[1] = adver_loss; row[2] = pl.lr; for (int s = 0; s < S; ++s) row[3 + s] = e->h_out->score0[s]; }
+    ++rows;
+  }
+  const int last_iter = broke ? it : p->max_iter - 1;
+  *success_flag = (last_iter < p->max_iter - 1) ? 1 : -1;  // :219
+  if (n_trace) *n_trace = rows;
+  // adver -> int16 (:220)
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N * B));
+  fb_launch_quantize(e->stream, e->adver.as<double>(), N, 16, e->wav.as<int16_t>());
+  HIPCHK(hipMemcpyAsync(adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  if (adver_f64) HIPCHK(hipMemcpyAsync(adver_f64, e->adver.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return FB_OK;
+}
+
+extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, double model_threshold,
+                                     const double *audio, int64_t N, const double *noise_all, int max_total_iters,
+                                     double *score_out, int *n_iters_out, int *n_outer_out, double *thr_final,
+                                     double *adver_f64) {
+  if (!audio || !score_out) return fb_fail(FB_E_ARG, "null argument");
+  if (!p_in) return fb_fail(FB_E_ARG, "null params");
+  if (p_in->task == FB_TASK_CSI) return fb_fail(FB_E_ARG, "no threshold to estimate for CSI (FAKEBOB.py:41-43)");
+  fb_nes_params q = *p_in;
+  q.attack_type = FB_UNTARGETED;  // :73-74
+  FBCHK(check_params(e, &q, N));
+  HIPCHK(hipSetDevice(e->device));
+  const int half = q.samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
+  FBCHK(prepare_nes_batch(e, N, B));
+  FBCHK(ensure_nes_buffers(e, N, B));
+  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
+  if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
+  // Column 0 of every NES batch is the clean adver (noise 0), i.e. exactly what
+  // model.score(audio) (:53) / model.make_decisions(adver) (:89) would score, so one batch
+  // per inner iteration serves both the decision and the gradient.
+  const double one_minus_m = 1.0 - q.momentum;
+  bool have_init = false;
+  double delta = 0.0;
+  int n_iters = 0, n_outer = 0;
+  Plateau pl;
+  pl.lr = q.max_lr;
+  q.threshold = 0.0;
+  int rc = FB_OK;
+  for (;;) {
+    const double *noise_dev = nullptr;
+    if (noise_all && half > 0) {
+      if (n_iters >= max_total_iters) { rc = fb_fail(FB_E_LIMIT, "max_total_iters %d reached", max_total_iters); break; }
+      HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)n_iters * N * half, sizeof(double) * (size_t)N * half,
+                            hipMemcpyHostToDevice, e->stream));
+      noise_dev = e->noise.as<double>();
+    }
+    // the loss depends on q.threshold, which may change below; scores do not.  Score first
+    // with the current threshold, then (rarely) recompute the loss after a sweep step.
+    FBCHK(enqueue_get_grad(e, &q, N, (uint32_t)n_iters, noise_dev, false));
+    FBCHK(fetch_out(e));
+    double s0 = e->h_out->score0[0];
+    for (int s = 1; s < S; ++s) if (e->h_out->score0[s] > s0) s0 = e->h_out->score0[s];
+    bool thr_changed = false;
+    if (!have_init) {  // :53-59
+      delta = fabs(s0 / 10.0);
+      q.threshold = s0 + delta;
+      have_init = true;
+      thr_changed = true;
+    }
+    if (s0 >= model_threshold) { *score_out = s0; break; }  // decision != -1 (:96-103)
+    while (s0 >= q.threshold) {  // early stop of the inner loop (:105-109) -> next outer (:135-137)
+      q.threshold += delta;
+      ++n_outer;
+      pl.lr = q.max_lr;  // :82-83
+      pl.ls.clear();
+      thr_changed = true;
+      if (!(delta > 0.0)) break;
+    }
+    if (n_iters >= max_total_iters) { rc = fb_fail(FB_E_LIMIT, "max_total_iters %d reached", max_total_iters); break; }
+    if (thr_changed) {
+      fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->gmm.M, q.task, q.attack_type,
+                     e->zmean.as<double>(), e->zstd.as<double>(), q.threshold, q.adver_thresh, q.target,
+                     q.true_label, e->dist_part.as<double>(), 0, e->scores.as<double>(), e->loss.as<double>(),
+                     e->nes_out.as<FbNesDev>());
+      FBCHK(fetch_out(e));
+    }
+    e->nes_iters += 1;
+    pl.step(e->h_out->final_loss, &q);
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, q.sigma, q.seed, (uint32_t)n_iters, q.stream,
+                          noise_dev, nullptr, 1, q.momentum, one_minus_m, pl.lr, q.epsilon, e->audio.as<double>(),
+                          e->grad_m.as<double>(), e->adver.as<double>());
+    ++n_iters;
+  }
+  if (n_iters_out) *n_iters_out = n_iters;
+  if (n_outer_out) *n_outer_out = n_outer;
+  if (thr_final) *thr_final = q.threshold;
+  if (adver_f64) HIPCHK(hipMemcpyAsync(adver_f64, e->adver.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return rc;
+}
+
+// ------------------------------------------------------------- debug hooks
+extern "C" int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half,
+                              float *z) {
+  if (!e || !z || N <= 0 || half <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  DevBuf tmp;
+  FBCHK(tmp.ensure(sizeof(float) * (size_t)N * half));
+  fb_launch_noise(e->stream, seed, iter, stream, N, half, tmp.as<float>());
+  hipError_t er = hipMemcpyAsync(z, tmp.p, sizeof(float) * (size_t)N * half, hipMemcpyDeviceToHost, e->stream);
+  if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+  tmp.release();
+  if (er != hipSuccess) return fb_fail(FB_E_HIP, "noise dump failed: %s", hipGetErrorString(er));
+  return FB_OK;
+}
+
+static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
+  if (!e || !wav || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int64_t off[2] = {0, n};
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(e->wav.p, wav, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  FBCHK(prepare_batch(e, off, 1));
+  e->cached_B = -1;
+  const int T = e->h_frame_off[1];
+  const FbFrontendDev &fe = e->fe;
+  FBCHK(e->mfcc.ensure(sizeof(float) * (size_t)T * fe.nc));
+  FBCHK(e->vrank.ensure(sizeof(int) * (size_t)T));
+  FBCHK(e->tv.ensure(sizeof(int)));
+  FBCHK(e->row_off.ensure(sizeof(int) * 2));
+  FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)T * fe.dim));
+  FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
+  hipStream_t s = e->stream;
+  fb_launch_mfcc(s, fe, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), 1, T, e->mfcc.as<float>());
+  fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, e->vrank.as<int>(), e->tv.as<int>());
+  fb_launch_rowscan(s, e->tv.as<int>(), 1, e->row_off.as<int>());
+  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, T, e->dfeat.as<float>());
+  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(), e->row_off.as<int>(), 1,
+                 e->feats.as<float>());
+  HIPCHK(hipGetLastError());
+  return FB_OK;
+}
+
+extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T_out) {
+  if (!mfcc) return fb_fail(FB_E_ARG, "mfcc is NULL");
+  FBCHK(debug_frontend(e, wav, n));
+  const int T = e->h_frame_off[1];
+  HIPCHK(hipMemcpyAsync(mfcc, e->mfcc.p, sizeof(float) * (size_t)T * e->fe.nc, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (T_out) *T_out = T;
+  return FB_OK;
+}
+
+extern "C" int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats, int *Tv, int *T_out) {
+  if (!feats || !Tv) return fb_fail(FB_E_ARG, "null output");
+  FBCHK(debug_frontend(e, wav, n));
+  const int T = e->h_frame_off[1];
+  int tv = 0;
+  HIPCHK(hipMemcpyAsync(&tv, e->tv.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (tv > 0)
+    HIPCHK(hipMemcpy(feats, e->feats.p, sizeof(float) * (size_t)tv * e->fe.dim, hipMemcpyDeviceToHost));
+  *Tv = tv;
+  if (T_out) *T_out = T;
+  return FB_OK;
+}
+
+extern "C" int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames, int64_t *voiced_frames,
+                        int64_t *nes_iters) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (scored_utts) *scored_utts = e->scored_utts;
+  if (scored_frames) *scored_frames = e->scored_frames;
+  if (voiced_frames) *voiced_frames = e->voiced_frames;
+  if (nes_iters) *nes_iters = e->nes_iters;
+  return FB_OK;
+}
+
+extern "C" int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64_t *rows) {
+  if (!e || reps <= 0 || !ms_avg) return fb_fail(FB_E_ARG, "bad argument");
+  if (!e->have_gmm || e->last_total_frames <= 0) return fb_fail(FB_E_STATE, "score a batch first");
+  HIPCHK(hipSetDevice(e->device));
+  const int B = e->last_B, tf = e->last_total_frames;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  fb_launch_gmm(e->stream, e->gmm, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
+                e->part_m.as<float>(), e->part_s.as<float>());
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  for (int r = 0; r < reps; ++r)
+    fb_launch_gmm(e->stream, e->gmm, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
+                  e->part_m.as<float>(), e->part_s.as<float>());
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *ms_avg = (double)ms / reps;
+  if (rows) {
+    int r = 0;
+    HIPCHK(hipMemcpy(&r, e->row_off.as<int>() + B, sizeof(int), hipMemcpyDeviceToHost));
+    *rows = r;
+  }
+  return FB_OK;
+}
+
+extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *audio, int64_t N, int warmup,
+                            int iters, int time_gmm, double *ms_total, double *ms_gmm, int64_t *voiced_rows) {
+  if (!audio || !ms_total || iters <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  FBCHK(check_params(e, p, N));
+  HIPCHK(hipSetDevice(e->device));
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1;
+  FBCHK(prepare_nes_batch(e, N, B));
+  FBCHK(ensure_nes_buffers(e, N, B));
+  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
+  Plateau pl;
+  pl.lr = p->max_lr;
+  const double one_minus_m = 1.0 - p->momentum;
+  double gmm_ms = 0.0;
+  int64_t vrows = 0;
+  (void)time_gmm;
+  for (int it = 0; it < warmup + iters; ++it) {
+    if (it == warmup) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipEventRecord(e->ev0, e->stream));
+    }
+    // identical work to fb_attack's loop body (early stop disabled for timing)
+    FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, nullptr, true));
+    FBCHK(fetch_out(e));
+    e->nes_iters += 1;
+    pl.step(e->h_out->final_loss, p);
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, (uint32_t)it, p->stream,
+                          nullptr, nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
+                          e->grad_m.as<double>(), e->adver.as<double>());
+  }
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *ms_total = (double)ms;
+  {
+    int r = 0;
+    HIPCHK(hipMemcpy(&r, e->row_off.as<int>() + B, sizeof(int), hipMemcpyDeviceToHost));
+    vrows = r;
+  }
+  if (ms_gmm) *ms_gmm = gmm_ms;
+  if (voiced_rows) *voiced_rows = vrows;
+  return FB_OK;
+}

@@ -1,0 +1,89 @@
+// fb_kernels.h -- host-callable launchers of the gfx950 kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fakebob_hip.h"
+
+// ---- device-resident front-end tables (built on the host at fb_set_frontend)
+struct FbFrontendDev {
+  // scalars
+  int L, P, shift, nb, nc, dim, order, dwin, cmn_window, snip_edges, remove_dc, use_energy,
+      raw_energy, vad_ctx;
+  double preemph, log_energy_floor;  // log_energy_floor = -inf when disabled
+  double vad_thr, vad_mean_scale;
+  float vad_prop;
+  // tables (device pointers)
+  const double *window;   // [L]   povey window (float32 values widened)
+  const double *tw_half;  // [P/2][2] exp(-2 pi i m / (P/2))  (complex FFT of size P/2)
+  const double *tw_full;  // [P/2+1][2] exp(-2 pi i k / P)    (real-FFT unpack)
+  const int *mel_first;   // [nb]
+  const int *mel_len;     // [nb]
+  const int *mel_off;     // [nb] offset into mel_w
+  const double *mel_w;    // packed weights (float32 values widened)
+  const double *dct;      // [nc][nb] (float32 values widened)
+  const double *lifter;   // [nc]
+  const double *dscale;   // [(order+1)][2*order*dwin+1] delta kernels (float32 values widened)
+};
+
+// ---- NES ----------------------------------------------------------------
+// q[b][n] = int16((adver[n] + sigma*noise_b[n]) * 2^15), b in [0, 2*half]; column 0 is the
+// un-noised adver.  noise: Philox(seed, iter, stream) or explicit float64 [N][half].
+// dist_part[gridDim.x] gets per-block max |audio - adver| (audio nullable).
+void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
+                       double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
+                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part);
+// plain quantisation of float64 audio (model.score on float input)
+void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q);
+// noise dump (tests)
+void fb_launch_noise(hipStream_t s, uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half,
+                     float *z);
+
+struct FbNesDev {  // device control/result block of one NES iteration
+  double adver_loss, final_loss, distance;
+  int err;       // !=0: utterance (err-1) had no voiced frames
+  int pad;
+  double score0[62];
+};
+// scores + loss + summary (single block).  raw[B][M] -> scores[B][S] -> loss[B].
+void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task,
+                    int attack_type, const double *z_mean, const double *z_std, double threshold,
+                    double adver_thresh, int target, int true_label, const double *dist_part,
+                    int n_dist_part, double *scores, double *loss, FbNesDev *out);
+// grad estimate (numpy-pairwise order) + optional momentum/sign/clip update.
+// do_update: 0 = only grad_out; 1 = momentum+update with lr.
+void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
+                           uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
+                           double *grad_out, int do_update, double momentum, double one_minus_m,
+                           double lr, double epsilon, const double *audio, double *grad_m,
+                           double *adver);
+
+// ---- front-end ------------------------------------------------------------
+// MFCC of every frame of a (ragged) batch.  wav_off[B+1], frame_off[B+1] device arrays.
+void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, const int16_t *wav, const int64_t *wav_off,
+                    const int *frame_off, int B, int total_frames, float *mfcc);
+// VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
+void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                   int *vrank, int *tv);
+// row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
+void fb_launch_rowscan(hipStream_t s, const int *tv, int B, int *row_off);
+// add-deltas
+void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                      int total_frames, float *dfeat);
+// apply-cmvn-sliding + select-voiced-frames -> compact feats[row][dim]
+void fb_launch_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *dfeat, const int *frame_off,
+                    const int *vrank, const int *row_off, int B, float *feats);
+
+// ---- diagonal GMM -----------------------------------------------------------
+struct FbGmmDev {
+  int M, C, D, KH, n_tiles, n_items;  // items per tile = groups + models
+  int img_floats;                     // floats per tile image
+  const float *images;                // [n_tiles][n_items][img_floats]
+  const int *item_model;              // [n_items]: -1 = quadratic (Q) item, else model index
+};
+// part_m/part_s: [n_chunks][M][rows_pad]
+void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
+                   int rows_cap, int n_chunks, float *part_m, float *part_s);
+// raw[b][m] = mean over voiced rows of logsumexp (merging the chunk partials)
+void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
+                            int rows_cap, int n_chunks, const int *row_off, int B, double *raw);

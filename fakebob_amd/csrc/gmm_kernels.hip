@@ -1,0 +1,234 @@
+// gmm_kernels.hip -- K7: diagonal-GMM frame log-likelihoods for all models of a
+// speaker-recognition system, fused with the per-frame logsumexp, on the gfx950
+// matrix cores (exact-f32 MFMA v_mfma_f32_32x32x2_f32).
+//
+// Replaces `gmm-global-get-frame-likes --average=true MODEL feats` run once per
+// model by the reference (gmm_ubm_kaldiHelper.py:202-221) ([EXT] SURVEY.md A.7):
+//     ll_k(x) = gconst_k + (mu/var)_k . x - 1/2 (1/var)_k . x^2 ,  ll = logsumexp_k
+//
+// Mapping (MI355X-first, not a GEMM library call):
+//   * D = P x F : "A" operand = parameters of 32 components, "B" operand = 32
+//     frames.  With the C/D layout of the 32x32 MFMA every lane then owns ONE
+//     frame (col = lane&31) and 16 components of it, so the online logsumexp is
+//     lane-local: no cross-lane traffic in the hot loop.
+//   * A wave keeps its 32 frames (x and x^2, 2*KH VGPRs) in registers for the
+//     whole kernel; parameter tiles stream HBM/L2 -> registers -> LDS
+//     (double-buffered, one barrier per 36-MFMA item) and are shared by the 4
+//     waves (128 frames) of the workgroup.
+//   * Models with bitwise-identical inverse variances (mean-only MAP adaptation,
+//     build_spk_models.py:170) share the quadratic term: acc_q = -1/2 iv . x^2 is
+//     computed once per tile ("Q item") and every model continues the fma chain
+//     from it with its own mu/var ("L item") -- (G + M)*KH MFMAs per tile instead
+//     of 2*M*KH.
+//   * The component range is split into chunks (grid.y) so the launch has >> 256
+//     workgroups; chunk partials (max, sumexp) are merged by k_gmm_finalize, which
+//     also performs the voiced-frame average in float64 in a fixed order
+//     (deterministic, no atomics).
+#include "fb_device.h"
+#include "fb_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FB_GMM_NEG (-3.0e38f)
+
+template <int KH>
+__global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restrict__ feats,
+                                                const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                int rows_cap, float *__restrict__ part_m,
+                                                float *__restrict__ part_s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROWF = 2 * KH + 4;
+  constexpr int IMGF = 32 * ROWF + 32;
+  constexpr int IMG4 = IMGF / 4;
+  constexpr int NST = (IMG4 + 255) / 256;
+  const int n_rows = *n_rows_ptr;
+  const int strip0 = blockIdx.x * 128;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int row = strip0 + w * 32 + j;
+  float *slot0 = lds, *slot1 = lds + IMGF;
+  float *st_m = lds + 2 * IMGF;            // [M][256]
+  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
+
+  // ---- frame fragments: x[h*KH + i], i < KH
+  float xf[KH], xq[KH];
+  {
+    const bool ok = row < n_rows;
+    const float *fr = feats + (size_t)(ok ? row : 0) * g.D + h * KH;
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      const int d = h * KH + i;
+      float v = (ok && d < g.D) ? fr[i] : 0.0f;
+      xf[i] = v;
+      xq[i] = __fmul_rn(v, v);
+    }
+  }
+  for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
+
+  const int tile0 = blockIdx.y * tiles_per_chunk;
+  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
+  const int total_items = (tile1 - tile0) * g.n_items;
+  const float4 *gimg = reinterpret_cast<const float4 *>(g.images + (size_t)tile0 * g.n_items * IMGF);
+
+  float4 stage[NST];
+  // prologue: item 0 -> slot 0
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    const int q = tid + 256 * s;
+    if (q < IMG4) reinterpret_cast<float4 *>(slot0)[q] = gimg[q];
+  }
+  __syncthreads();
+
+  f32x16 accq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accq[r] = 0.0f;
+
+  for (int it = 0; it < total_items; ++it) {
+    float *cur = (it & 1) ? slot1 : slot0;
+    float *nxt = (it & 1) ? slot0 : slot1;
+    const bool more = (it + 1) < total_items;
+    if (more) {
+      const float4 *src = gimg + (size_t)(it + 1) * IMG4;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) {
+        const int q = tid + 256 * s;
+        if (q < IMG4) stage[s] = src[q];
+      }
+    }
+    const int item = it % g.n_items;
+    const int model = g.item_model[item];
+    const float *prow = cur + j * ROWF + h * KH;
+    if (model < 0) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < KH / 4; ++q) {
+        const float4 p = *reinterpret_cast<const float4 *>(prow + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, xq[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, xq[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, xq[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, xq[4 * q + 3], acc, 0, 0, 0);
+      }
+      accq = acc;
+    } else {
+      f32x16 acc = accq;
+#pragma unroll
+      for (int q = 0; q < KH / 4; ++q) {
+        const float4 p = *reinterpret_cast<const float4 *>(prow + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, xf[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, xf[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, xf[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, xf[4 * q + 3], acc, 0, 0, 0);
+      }
+      // epilogue: + gconst, online logsumexp over this lane's 16 components
+      const float *gc = cur + 32 * ROWF + 4 * h;
+      float v[16];
+      float tm = FB_GMM_NEG;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float4 gq = *reinterpret_cast<const float4 *>(gc + 8 * rr);
+        v[4 * rr + 0] = acc[4 * rr + 0] + gq.x;
+        v[4 * rr + 1] = acc[4 * rr + 1] + gq.y;
+        v[4 * rr + 2] = acc[4 * rr + 2] + gq.z;
+        v[4 * rr + 3] = acc[4 * rr + 3] + gq.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, v[r]);
+      const float m_old = st_m[model * 256 + tid], s_old = st_s[model * 256 + tid];
+      const float m_new = fmaxf(m_old, tm);
+      float ssum = s_old * __expf(m_old - m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ssum += __expf(v[r] - m_new);
+      st_m[model * 256 + tid] = m_new;
+      st_s[model * 256 + tid] = ssum;
+    }
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < NST; ++s) {
+        const int q = tid + 256 * s;
+        if (q < IMG4) reinterpret_cast<float4 *>(nxt)[q] = stage[s];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- merge the two lane halves (components 4h..) and publish the chunk partial
+  for (int m = 0; m < g.M; ++m) {
+    const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
+    const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
+    const float mx = fmaxf(mm, m2);
+    const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
+    if (h == 0 && row < n_rows) {
+      const size_t o = ((size_t)blockIdx.y * g.M + m) * rows_cap + row;
+      part_m[o] = mx;
+      part_s[o] = sx;
+    }
+  }
+}
+
+static int fb_gmm_lds_bytes(const FbGmmDev &g) {
+  const int imgf = 32 * (2 * g.KH + 4) + 32;
+  return (2 * imgf + 2 * g.M * 256) * (int)sizeof(float);
+}
+
+template <int KH>
+static void launch_gmm_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                         int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
+  hipLaunchKernelGGL(k_gmm<KH>, grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr, tpc,
+                     rows_cap, part_m, part_s);
+}
+
+void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                   int rows_cap, int n_chunks, float *part_m, float *part_s) {
+  if (rows_cap <= 0) return;
+  const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  switch (g.KH) {
+    case 20: launch_gmm_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 32: launch_gmm_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 36: launch_gmm_t<36>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 40: launch_gmm_t<40>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    default: break;  // fb_load_gmm only produces the KH values above
+  }
+}
+
+// raw[b][m] = (1/Tv) * sum_{voiced rows of b} logsumexp_k ll_k   (float64 sum of
+// float32 per-frame values, fixed order)
+__global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *__restrict__ part_m,
+                                                      const float *__restrict__ part_s, int rows_cap,
+                                                      int n_chunks, const int *__restrict__ row_off, int B,
+                                                      double *__restrict__ raw) {
+  const int b = blockIdx.x, m = blockIdx.y;
+  const int r0 = row_off[b], r1 = row_off[b + 1];
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    float mx = FB_GMM_NEG;
+    for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
+    double ssum = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+      const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
+      ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+    }
+    const float ll = (float)((double)mx + log(ssum));
+    acc += (double)ll;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int tv = r1 - r0;
+    raw[(size_t)b * g.M + m] = tv > 0 ? red[0] / (double)tv : __longlong_as_double(0x7ff8000000000000ll);
+  }
+}
+
+void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
+                            int rows_cap, int n_chunks, const int *row_off, int B, double *raw) {
+  hipLaunchKernelGGL(k_gmm_finalize, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
+                     row_off, B, raw);
+}

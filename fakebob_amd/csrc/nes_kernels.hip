@@ -1,0 +1,274 @@
+// nes_kernels.hip -- NES-side kernels: Philox noise + perturb + int16 quantise
+// (K0/K1), loss (K13/K14), gradient estimate + momentum sign-step (K15/K16).
+//
+// Follows FAKEBOB.py:223-299 (get_grad / loss_fn) and :193-203 (update) of the
+// reference; all float64 arithmetic is written with explicit round-to-nearest
+// mul/add so the results are bit-identical to NumPy's (no FMA contraction).
+#include "fb_device.h"
+#include "fb_kernels.h"
+
+// ------------------------------------------------------------------ perturb
+// grid.x over n4 blocks (4 samples per thread), grid.y over antithetic pairs.
+__global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adver,
+                                                 const double *__restrict__ audio, int64_t N,
+                                                 int half, double sigma, uint64_t seed,
+                                                 uint32_t iter, uint32_t stream,
+                                                 const double *__restrict__ noise_pos,
+                                                 int16_t *__restrict__ q,
+                                                 double *__restrict__ dist_part) {
+  const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  const int64_t n0 = n4 * 4;
+  double dmax = 0.0;
+  if (n0 < N) {
+    double a[4];
+    const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = (k < cnt) ? adver[n0 + k] : 0.0;
+    if (half > 0) {
+      double z[4];
+      if (noise_pos) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (k < cnt) ? noise_pos[(n0 + k) * half + j] : 0.0;
+      } else {
+        float zf[4];
+        fb_noise4(seed, iter, stream, (uint32_t)n4, (uint32_t)j, zf);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (double)zf[k];
+      }
+      int16_t *qp = q + (int64_t)(1 + j) * N + n0;
+      int16_t *qm = q + (int64_t)(1 + half + j) * N + n0;
+      int16_t vp[4], vm[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // noise_audios = sigma * noise + audio            (FAKEBOB.py:237)
+        double xp = __dadd_rn(__dmul_rn(sigma, z[k]), a[k]);
+        double xm = __dadd_rn(__dmul_rn(sigma, -z[k]), a[k]);
+        vp[k] = fb_quantize(xp, 32768.0);
+        vm[k] = fb_quantize(xm, 32768.0);
+      }
+      if (cnt == 4 && ((N & 3) == 0)) {
+        *reinterpret_cast<short4 *>(qp) = make_short4(vp[0], vp[1], vp[2], vp[3]);
+        *reinterpret_cast<short4 *>(qm) = make_short4(vm[0], vm[1], vm[2], vm[3]);
+      } else {
+        for (int k = 0; k < cnt; ++k) { qp[k] = vp[k]; qm[k] = vm[k]; }
+      }
+    }
+    if (j == 0) {
+      for (int k = 0; k < cnt; ++k) {
+        q[n0 + k] = fb_quantize(a[k], 32768.0);  // column 0: the clean adver
+        if (audio) { double d = fabs(__dsub_rn(audio[n0 + k], a[k])); dmax = d > dmax ? d : dmax; }
+      }
+    }
+  }
+  if (blockIdx.y == 0 && dist_part) {
+    __shared__ double red[4];
+    double m = fb_wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = red[0];
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = red[w] > r ? red[w] : r;
+      dist_part[blockIdx.x] = r;
+    }
+  }
+}
+
+void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
+                       double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
+                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part) {
+  int64_t n4 = (N + 3) / 4;
+  dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)(half > 0 ? half : 1));
+  if (n_dist_part) *n_dist_part = (int)grid.x;
+  hipLaunchKernelGGL(k_perturb, grid, dim3(256), 0, s, adver, audio, N, half, sigma, seed, iter, stream,
+                     noise_pos, q, dist_part);
+}
+
+__global__ __launch_bounds__(256) void k_quantize(const double *__restrict__ x, int64_t n, double scale,
+                                                  int16_t *__restrict__ q) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) q[i] = fb_quantize(x[i], scale);
+}
+void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_quantize, dim3(blocks), dim3(256), 0, s, x, n, ldexp(1.0, bits - 1), q);
+}
+
+__global__ __launch_bounds__(256) void k_noise(uint64_t seed, uint32_t iter, uint32_t stream, int64_t N,
+                                               int half, float *__restrict__ z) {
+  const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (n4 * 4 >= N) return;
+  float v[4];
+  fb_noise4(seed, iter, stream, (uint32_t)n4, (uint32_t)j, v);
+  for (int k = 0; k < 4; ++k)
+    if (n4 * 4 + k < N) z[(int64_t)j * N + n4 * 4 + k] = v[k];
+}
+void fb_launch_noise(hipStream_t s, uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half,
+                     float *z) {
+  int64_t n4 = (N + 3) / 4;
+  dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)half);
+  hipLaunchKernelGGL(k_noise, grid, dim3(256), 0, s, seed, iter, stream, N, half, z);
+}
+
+// --------------------------------------------------------------------- loss
+// numpy pairwise summation over elem(i), i in [lo, lo+n)  (see oracle/fb_oracle.c
+// fbo_np_sum; verified bit-for-bit against numpy 2.2.6)
+template <typename F>
+__device__ double fb_np_sum_block(F elem, int lo, int n) {  // n <= 128
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r = __dadd_rn(r, elem(lo + i));
+    return r;
+  }
+  double r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = elem(lo + j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], elem(lo + i + j));
+  }
+  double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                         __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __dadd_rn(res, elem(lo + i));
+  return res;
+}
+template <typename F>
+__device__ double fb_np_sum(F elem, int lo, int n) {
+  // explicit stack replaces numpy's recursion: sum(lo,n) = sum(lo,n2) + sum(lo+n2, n-n2)
+  if (n <= 128) return fb_np_sum_block(elem, lo, n);
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return __dadd_rn(fb_np_sum(elem, lo, n2), fb_np_sum(elem, lo + n2, n - n2));
+}
+
+__global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, const int *__restrict__ tv,
+                                              int B, int M, int task, int attack_type,
+                                              const double *__restrict__ z_mean,
+                                              const double *__restrict__ z_std, double threshold,
+                                              double adver_thresh, int target, int true_label,
+                                              const double *__restrict__ dist_part, int n_dist_part,
+                                              double *__restrict__ scores, double *__restrict__ loss,
+                                              FbNesDev *__restrict__ out) {
+  const int S = (task == FB_TASK_CSI) ? M : M - 1;
+  __shared__ int s_err;
+  if (threadIdx.x == 0) s_err = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (tv && tv[b] <= 0) atomicMax(&s_err, b + 1);
+    const double *r = raw + (size_t)b * M;
+    double *sc = scores + (size_t)b * S;
+    if (task == FB_TASK_CSI) {
+      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r[m], z_mean[m]), z_std[m]);  // gmm_ubm_CSI.py:93
+    } else {
+      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r[1 + m], r[0]);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
+    }
+    double l;
+    if (task == FB_TASK_SV) {
+      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
+    } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
+      double mx = -INFINITY;
+      for (int m = 0; m < S; ++m) mx = sc[m] > mx ? sc[m] : mx;
+      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), mx);  // :269
+    } else if (task == FB_TASK_OSI) {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+      double mx = om > threshold ? om : threshold;
+      l = __dsub_rn(__dadd_rn(mx, adver_thresh), sc[target]);  // :262
+    } else if (attack_type == FB_TARGETED) {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+      l = __dsub_rn(__dadd_rn(om, adver_thresh), sc[target]);  // :281
+    } else {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
+      l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
+    }
+    loss[b] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int spd = B - 1;
+    out->adver_loss = loss[0];
+    auto el = [&](int i) { return loss[1 + i]; };
+    out->final_loss = spd > 0 ? __ddiv_rn(fb_np_sum(el, 0, spd), (double)spd) : 0.0;  // np.mean :243
+    for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
+    double d = 0.0;
+    for (int i = 0; i < n_dist_part; ++i) d = dist_part[i] > d ? dist_part[i] : d;
+    out->distance = d;
+    out->err = s_err;
+  }
+}
+
+void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task,
+                    int attack_type, const double *z_mean, const double *z_std, double threshold,
+                    double adver_thresh, int target, int true_label, const double *dist_part,
+                    int n_dist_part, double *scores, double *loss, FbNesDev *out) {
+  hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, attack_type, z_mean, z_std,
+                     threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out);
+}
+
+// ------------------------------------------------------------- grad + update
+// estimate_grad = np.mean(loss.flatten() * noise, axis=1) / sigma   (FAKEBOB.py:244)
+// then grad = m*pre + (1-m)*grad (:193), adver -= lr*sign(grad), clip (:202-203).
+__global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ loss, int64_t N, int half,
+                                                     double sigma, uint64_t seed, uint32_t iter,
+                                                     uint32_t stream, const double *__restrict__ noise_pos,
+                                                     double *__restrict__ grad_out, int do_update,
+                                                     double momentum, double one_minus_m, double lr,
+                                                     double epsilon, const double *__restrict__ audio,
+                                                     double *__restrict__ grad_m, double *__restrict__ adver) {
+  extern __shared__ double s_loss[];  // loss[1..spd]
+  const int spd = 2 * half;
+  for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint32_t n4 = (uint32_t)(n >> 2);
+  const int k = (int)(n & 3);
+  auto el = [&](int i) -> double {
+    const int j = i < half ? i : i - half;
+    double z;
+    if (noise_pos) {
+      z = noise_pos[n * half + j];
+    } else {
+      float zf[4];
+      fb_noise4(seed, iter, stream, n4, (uint32_t)j, zf);
+      z = (double)(k == 0 ? zf[0] : k == 1 ? zf[1] : k == 2 ? zf[2] : zf[3]);
+    }
+    if (i >= half) z = -z;
+    return __dmul_rn(s_loss[i], z);
+  };
+  double g = 0.0;
+  if (spd > 0) g = __ddiv_rn(__ddiv_rn(fb_np_sum(el, 0, spd), (double)spd), sigma);
+  if (grad_out) grad_out[n] = g;
+  if (do_update) {
+    double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
+    grad_m[n] = gm;
+    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
+    double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
+    double au = audio[n];
+    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
+    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
+    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
+    a = a < lo ? lo : a;
+    a = a > hi ? hi : a;
+    adver[n] = a;
+  }
+}
+
+void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
+                           uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
+                           double *grad_out, int do_update, double momentum, double one_minus_m,
+                           double lr, double epsilon, const double *audio, double *grad_m,
+                           double *adver) {
+  int blocks = (int)((N + 255) / 256);
+  size_t shm = sizeof(double) * (size_t)(2 * half > 0 ? 2 * half : 1);
+  hipLaunchKernelGGL(k_grad_update, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, seed, iter,
+                     stream, noise_pos, grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio,
+                     grad_m, adver);
+}

@@ -1,0 +1,200 @@
+"""Engine: one GPU + one HIP stream worth of device state behind the C ABI.
+
+Thin numpy <-> pointer marshalling only; all arithmetic of the hot path runs
+in libfakebob_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .models import stack_models
+
+
+def nes_params(task, attack_type, adver_thresh=0., epsilon=0.002, max_iter=1000, max_lr=0.001,
+               min_lr=1e-6, samples_per_draw=50, sigma=0.001, momentum=0.9, plateau_length=5,
+               plateau_drop=2., threshold=0., target=None, true=None, seed=42, stream=0):
+    p = N.NesParams()
+    p.task = N.TASK[task]
+    p.attack_type = N.ATTACK[attack_type]
+    p.adver_thresh = float(adver_thresh); p.epsilon = float(epsilon); p.max_iter = int(max_iter)
+    p.max_lr = float(max_lr); p.min_lr = float(min_lr); p.samples_per_draw = int(samples_per_draw)
+    p.sigma = float(sigma); p.momentum = float(momentum); p.plateau_length = int(plateau_length)
+    p.plateau_drop = float(plateau_drop); p.threshold = float(threshold)
+    p.target = 0 if target is None else int(target)
+    p.true_label = 0 if true is None else int(true)
+    p.seed = int(seed); p.stream = int(stream)
+    return p
+
+
+class Engine(object):
+    def __init__(self, device=0):
+        self._L = N.lib()
+        self._h = C.c_void_p()
+        N.check(self._L.fb_engine_create(C.c_int(device), C.byref(self._h)))
+        self.device = device
+        self.task = "OSI"
+        self.n_models = 0
+        self.cfg = N.FrontendCfg()
+        self._L.fb_default_frontend(C.byref(self.cfg))
+
+    def close(self):
+        if self._h:
+            self._L.fb_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration
+    def set_frontend(self, **over):
+        for k, v in over.items():
+            if not hasattr(self.cfg, k):
+                raise KeyError(k)
+            setattr(self.cfg, k, v)
+        N.check(self._L.fb_set_frontend(self._h, C.byref(self.cfg)))
+
+    @property
+    def feat_dim(self):
+        return self.cfg.num_ceps * (self.cfg.delta_order + 1)
+
+    def load_gmm(self, models):
+        gc, miv, iv = stack_models(models)
+        M, Cn, D = miv.shape
+        N.check(self._L.fb_load_gmm(self._h, C.c_int(M), C.c_int(Cn), C.c_int(D), N.ptr(gc),
+                                    N.ptr(miv), N.ptr(iv)))
+        self.n_models = M
+        self.task = "OSI"
+
+    def set_system(self, task, z_mean=None, z_std=None):
+        zm = None if z_mean is None else np.ascontiguousarray(z_mean, np.float64)
+        zs = None if z_std is None else np.ascontiguousarray(z_std, np.float64)
+        N.check(self._L.fb_set_system(self._h, C.c_int(N.TASK[task]),
+                                      None if zm is None else N.ptr(zm),
+                                      None if zs is None else N.ptr(zs)))
+        self.task = task
+
+    @property
+    def n_speakers(self):
+        return self._L.fb_num_speakers(self._h)
+
+    # ---- scoring
+    def score_raw(self, audio_list, bits_per_sample=16):
+        """list of 1-D arrays (int16, or float in [-1,1]) -> raw[B,M], tv[B]."""
+        B = len(audio_list)
+        off = np.zeros(B + 1, np.int64)
+        off[1:] = np.cumsum([a.size for a in audio_list])
+        raw = np.empty((B, self.n_models), np.float64)
+        tv = np.empty(B, np.int32)
+        if all(a.dtype == np.int16 for a in audio_list):
+            cat = np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in audio_list]))
+            N.check(self._L.fb_score_i16(self._h, N.ptr(cat), N.ptr(off), C.c_int(B), N.ptr(raw), N.ptr(tv)))
+        else:
+            # mixed / float input: int16 entries are exact in float64 after /2^(bits-1)
+            scale = float(2 ** (bits_per_sample - 1))
+            parts = [a.reshape(-1).astype(np.float64) / scale if a.dtype == np.int16
+                     else a.reshape(-1).astype(np.float64) for a in audio_list]
+            cat = np.ascontiguousarray(np.concatenate(parts))
+            N.check(self._L.fb_score_f64(self._h, N.ptr(cat), N.ptr(off), C.c_int(B),
+                                         C.c_int(bits_per_sample), N.ptr(raw), N.ptr(tv)))
+        return raw, tv
+
+    def system_scores(self, raw):
+        raw = np.ascontiguousarray(raw, np.float64)
+        B = raw.shape[0]
+        out = np.empty((B, self.n_speakers), np.float64)
+        N.check(self._L.fb_system_scores(self._h, N.ptr(raw), C.c_int(B), N.ptr(out)))
+        return out
+
+    # ---- NES
+    def get_grad(self, params, audio, it=0, noise_pos=None, want_grad=True):
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        n = audio.size
+        npz = None if noise_pos is None else np.ascontiguousarray(noise_pos, np.float64)
+        if npz is not None and npz.shape != (n, params.samples_per_draw // 2):
+            raise ValueError("noise_pos must be (N, samples_per_draw//2)")
+        grad = np.empty(n, np.float64) if want_grad else None
+        fl, al = C.c_double(), C.c_double()
+        sc = np.empty(max(self.n_speakers, 1), np.float64)
+        N.check(self._L.fb_get_grad(self._h, C.byref(params), N.ptr(audio), C.c_int64(n), C.c_uint32(it),
+                                    None if npz is None else N.ptr(npz), C.byref(fl),
+                                    None if grad is None else N.ptr(grad), C.byref(al), N.ptr(sc)))
+        return fl.value, grad, al.value, sc
+
+    def attack(self, params, audio, noise_all=None):
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        n = audio.size
+        na = None if noise_all is None else np.ascontiguousarray(noise_all, np.float64)
+        S = self.n_speakers
+        adv = np.empty(n, np.int16)
+        adv_f = np.empty(n, np.float64)
+        trace = np.zeros((max(params.max_iter, 1), 3 + S), np.float64)
+        nt, flag = C.c_int(), C.c_int()
+        N.check(self._L.fb_attack(self._h, C.byref(params), N.ptr(audio), C.c_int64(n),
+                                  None if na is None else N.ptr(na), N.ptr(adv), N.ptr(adv_f),
+                                  N.ptr(trace), C.byref(nt), C.byref(flag)))
+        return adv, flag.value, adv_f, trace[:nt.value]
+
+    def estimate_threshold(self, params, model_threshold, audio, noise_all=None, max_total_iters=100000):
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        n = audio.size
+        na = None if noise_all is None else np.ascontiguousarray(noise_all, np.float64)
+        sc, tf = C.c_double(), C.c_double()
+        ni, no = C.c_int(), C.c_int()
+        adv_f = np.empty(n, np.float64)
+        N.check(self._L.fb_estimate_threshold(self._h, C.byref(params), C.c_double(model_threshold),
+                                              N.ptr(audio), C.c_int64(n), None if na is None else N.ptr(na),
+                                              C.c_int(max_total_iters), C.byref(sc), C.byref(ni), C.byref(no),
+                                              C.byref(tf), N.ptr(adv_f)))
+        return sc.value, ni.value, no.value, tf.value, adv_f
+
+    # ---- debug / bench hooks
+    def debug_noise(self, seed, it, stream, n, half):
+        z = np.empty((half, n), np.float32)
+        N.check(self._L.fb_debug_noise(self._h, C.c_uint64(seed), C.c_uint32(it), C.c_uint32(stream),
+                                       C.c_int64(n), C.c_int(half), N.ptr(z)))
+        return z
+
+    def _num_frames(self, n):
+        c = self.cfg
+        if c.snip_edges:
+            return 0 if n < c.frame_length else 1 + (n - c.frame_length) // c.frame_shift
+        return (n + c.frame_shift // 2) // c.frame_shift
+
+    def debug_mfcc(self, wav):
+        wav = np.ascontiguousarray(wav, np.int16)
+        T = self._num_frames(wav.size)
+        out = np.empty((T, self.cfg.num_ceps), np.float32)
+        To = C.c_int()
+        N.check(self._L.fb_debug_mfcc(self._h, N.ptr(wav), C.c_int64(wav.size), N.ptr(out), C.byref(To)))
+        return out[:To.value]
+
+    def debug_feats(self, wav):
+        wav = np.ascontiguousarray(wav, np.int16)
+        T = self._num_frames(wav.size)
+        out = np.empty((max(T, 1), self.feat_dim), np.float32)
+        tv, To = C.c_int(), C.c_int()
+        N.check(self._L.fb_debug_feats(self._h, N.ptr(wav), C.c_int64(wav.size), N.ptr(out), C.byref(tv),
+                                       C.byref(To)))
+        return out[:tv.value].copy(), To.value
+
+    def stats(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        N.check(self._L.fb_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(scored_utts=a.value, scored_frames=b.value, voiced_frames=c.value, nes_iters=d.value)
+
+    def bench_gmm_kernel(self, reps=20):
+        ms, rows = C.c_double(), C.c_int64()
+        N.check(self._L.fb_bench_gmm_kernel(self._h, C.c_int(reps), C.byref(ms), C.byref(rows)))
+        return ms.value, rows.value
+
+    def bench_nes(self, params, audio, warmup, iters):
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        ms, msg, rows = C.c_double(), C.c_double(), C.c_int64()
+        N.check(self._L.fb_bench_nes(self._h, C.byref(params), N.ptr(audio), C.c_int64(audio.size),
+                                     C.c_int(warmup), C.c_int(iters), C.c_int(0), C.byref(ms), C.byref(msg),
+                                     C.byref(rows)))
+        return ms.value, msg.value, rows.value

@@ -1,0 +1,125 @@
+"""Model containers and the synthetic workload of SURVEY.md section 8(d).
+
+The reference's speaker models are Kaldi files (`final.dubm`,
+`*-identity.gmm`, build_spk_models.py:166-224) that are not available here, so
+benchmarks and tests run on seeded synthetic models of the same shape.  GMMs
+are handed to the engine in Kaldi's DiagGmm *internal* form (gconsts,
+means_invvars, inv_vars as float32), exactly what `gmm-global-get-frame-likes`
+evaluates ([EXT] SURVEY.md A.7).
+"""
+import numpy as np
+
+
+class DiagGmm(object):
+    """Kaldi DiagGmm internal form (float32)."""
+
+    def __init__(self, gconsts, means_invvars, inv_vars):
+        self.gconsts = np.ascontiguousarray(gconsts, np.float32)
+        self.means_invvars = np.ascontiguousarray(means_invvars, np.float32)
+        self.inv_vars = np.ascontiguousarray(inv_vars, np.float32)
+        assert self.means_invvars.shape == self.inv_vars.shape
+        assert self.gconsts.shape == (self.inv_vars.shape[0],)
+
+    @property
+    def num_gauss(self):
+        return self.inv_vars.shape[0]
+
+    @property
+    def dim(self):
+        return self.inv_vars.shape[1]
+
+    @staticmethod
+    def from_moments(weights, means, variances):
+        """DiagGmm::ComputeGconsts ([EXT] A.7): float64 math, float32 storage."""
+        w = np.asarray(weights, np.float64)
+        mu = np.asarray(means, np.float64)
+        var = np.asarray(variances, np.float64)
+        iv = (1.0 / var).astype(np.float32)
+        miv = (mu / var).astype(np.float32)
+        return DiagGmm.from_internal(w, miv, iv)
+
+    @staticmethod
+    def from_internal(weights, means_invvars, inv_vars):
+        """gconst_k = log w_k - 0.5*(D log 2pi + sum log var + sum mu^2/var), evaluated from the
+        stored float32 (means_invvars, inv_vars) like Kaldi does after reading a model."""
+        w = np.asarray(weights, np.float64)
+        miv = np.asarray(means_invvars, np.float32).astype(np.float64)
+        iv = np.asarray(inv_vars, np.float32).astype(np.float64)
+        D = iv.shape[1]
+        gc = np.log(w) - 0.5 * D * np.log(2.0 * np.pi) + 0.5 * np.sum(np.log(iv), axis=1) \
+            - 0.5 * np.sum(miv * miv / iv, axis=1)
+        return DiagGmm(gc.astype(np.float32), miv.astype(np.float32), iv.astype(np.float32))
+
+    def means(self):
+        return self.means_invvars.astype(np.float64) / self.inv_vars.astype(np.float64)
+
+    def variances(self):
+        return 1.0 / self.inv_vars.astype(np.float64)
+
+
+def stack_models(models):
+    """[DiagGmm] -> (gconsts[M,C], means_invvars[M,C,D], inv_vars[M,C,D]) float32."""
+    gc = np.ascontiguousarray(np.stack([m.gconsts for m in models]), np.float32)
+    miv = np.ascontiguousarray(np.stack([m.means_invvars for m in models]), np.float32)
+    iv = np.ascontiguousarray(np.stack([m.inv_vars for m in models]), np.float32)
+    return gc, miv, iv
+
+
+# ---------------------------------------------------------------- synthetic
+def synthetic_audio(utt=0, n_samples=48000, seed=1234, fs=16000):
+    """harmonic voiced-like signal with a 1/3 low-energy duty cycle so the VAD
+    is exercised; int16-exact float64 in [-1, 1)."""
+    rng = np.random.default_rng(seed + utt)
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=8)
+    xi = rng.normal(size=n_samples)
+    n = np.arange(n_samples, dtype=np.float64)
+    x = np.zeros(n_samples)
+    for h in range(1, 9):
+        x += np.sin(2.0 * np.pi * 110.0 * h * n / fs + phi[h - 1]) / h
+    env = np.where((np.arange(n_samples) // 8000) % 3 != 2, 1.0, 0.02)
+    x = 0.25 * env * x + 0.002 * xi
+    return np.round(x * 32768.0) / 32768.0
+
+
+def _dim_scale(D):
+    s = np.full(D, 0.5)
+    s[:min(24, D)] = 3.0
+    s[24:min(48, D)] = 1.0
+    return s
+
+
+def synthetic_ubm_moments(C=2048, D=72, seed=2001):
+    rng = np.random.default_rng(seed)
+    s = _dim_scale(D)
+    logits = rng.normal(0.0, 0.5, size=C)
+    w = np.exp(logits - logits.max())
+    w /= w.sum()
+    mu = rng.normal(size=(C, D)) * s
+    var = (s ** 2) * np.exp(rng.normal(0.0, 0.3, size=(C, D)))
+    return w, mu, var
+
+
+def synthetic_speaker_means(w, mu, spk=0, seed=2100, tau=10.0, frames=200.0):
+    """Mean-only MAP adaptation (build_spk_models.py:170 update_flags 'm'; [EXT] A.8) from a
+    synthetic 200-voiced-frame enrolment utterance with uneven occupancy."""
+    rng = np.random.default_rng(seed + spk)
+    C, D = mu.shape
+    s = _dim_scale(D)
+    delta = rng.normal(size=(C, D)) * (0.3 * s)
+    u = rng.exponential(1.0, size=C)
+    n = frames * w * u / np.sum(w * u)
+    alpha = n / (n + tau)
+    return mu + alpha[:, None] * delta
+
+
+def synthetic_gmm_system(n_speakers=5, C=2048, D=72, seed_ubm=2001, seed_spk=2100):
+    """Returns (ubm, [speaker models]) as DiagGmm; speakers share weights and variances with
+    the UBM (so the engine's shared-quadratic path applies, as for real MAP-adapted models)."""
+    w, mu, var = synthetic_ubm_moments(C, D, seed_ubm)
+    ubm = DiagGmm.from_moments(w, mu, var)
+    spk = []
+    for s in range(n_speakers):
+        mu_s = synthetic_speaker_means(w, mu, s, seed_spk)
+        m = DiagGmm.from_internal(w, (mu_s / var).astype(np.float32), ubm.inv_vars)
+        spk.append(m)
+    return ubm, spk

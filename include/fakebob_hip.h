@@ -1,0 +1,188 @@
+/*
+ * fakebob_hip.h -- C ABI of libfakebob_hip.so, the MI355X (gfx950) engine for
+ * the FAKEBOB NES attack hot path.
+ *
+ * The reference has no FFI: its hot path crosses a *process* boundary
+ * (subprocess.Popen of Kaldi programs).  Each entry point below replaces one
+ * Python-level interface of the reference; the reference-side binding a
+ * maintainer would add is a ctypes stub.
+ *
+ *   entry point               replaces (reference file:line)
+ *   ------------------------  -------------------------------------------------
+ *   fb_load_gmm               model_list / ubm paths handed to the wrappers
+ *                             (gmm_ubm_OSI.py:15,45; attackMain.py:55,73-83)
+ *   fb_set_frontend           pre-models/conf/{mfcc,vad}.conf + delta_opts read
+ *                             by gmm_ubm_kaldiHelper.py:133,153,191
+ *   fb_score_i16 / _f64       gmm_ubm_kaldiHelper.score (:270-291) and the
+ *                             int16 cast of gmm_ubm_OSI.py:83-85
+ *   fb_system_scores          wrapper post-processing gmm_ubm_OSI.py:89,
+ *                             gmm_ubm_SV.py:77, gmm_ubm_CSI.py:93
+ *   fb_get_grad               FakeBob.get_grad + loss_fn (FAKEBOB.py:223-299)
+ *   fb_attack                 FakeBob.attack (FAKEBOB.py:139-221)
+ *   fb_estimate_threshold     FakeBob.estimate_threshold (FAKEBOB.py:39-137)
+ *
+ * Conventions: plain pointers and sizes, host memory unless a name ends in
+ * _dev; every function returns 0 on success or a negative FB_E_* code and
+ * leaves a message retrievable with fb_last_error() (the reference ignores
+ * subprocess return codes, gmm_ubm_kaldiHelper.py:145-147 -- this is strictly
+ * more).  One engine handle per (GPU, stream); a handle is not thread-safe,
+ * different handles are independent.
+ */
+#ifndef FAKEBOB_HIP_H
+#define FAKEBOB_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_OK 0
+#define FB_E_ARG (-1)        /* bad argument / shape */
+#define FB_E_HIP (-2)        /* HIP runtime error */
+#define FB_E_STATE (-3)      /* model / frontend not loaded */
+#define FB_E_NO_VOICED (-4)  /* an utterance has zero voiced frames (Kaldi
+                                would silently drop it and mis-align rows) */
+#define FB_E_NOMEM (-5)
+#define FB_E_LIMIT (-6)      /* iteration cap reached (estimate_threshold) */
+
+enum { FB_TASK_OSI = 0, FB_TASK_CSI = 1, FB_TASK_SV = 2 };
+enum { FB_UNTARGETED = 0, FB_TARGETED = 1 };
+
+typedef struct fb_engine fb_engine;
+
+/* Kaldi front-end options ([EXT] conf/mfcc.conf, conf/vad.conf, delta_opts;
+ * cmn flags fixed by gmm_ubm_kaldiHelper.py:196).  dither is always 0. */
+typedef struct {
+  double sample_freq;
+  int frame_length;   /* samples */
+  int frame_shift;    /* samples */
+  int padded_length;  /* power of two: 512 */
+  int num_mel_bins;
+  int num_ceps;
+  double low_freq, high_freq;
+  double preemph;
+  double cepstral_lifter;
+  int snip_edges;
+  int remove_dc;
+  int use_energy;
+  int raw_energy;
+  double energy_floor;
+  double vad_energy_threshold;
+  double vad_energy_mean_scale;
+  double vad_proportion_threshold;
+  int vad_frames_context;
+  int delta_window;
+  int delta_order;
+  int cmn_window;
+} fb_frontend_cfg;
+
+/* FakeBob hyper-parameters (FAKEBOB.py:21-37) + attack() arguments (:139) +
+ * the RNG contract that replaces the unseeded np.random.normal (:234). */
+typedef struct {
+  int task;          /* FB_TASK_* */
+  int attack_type;   /* FB_UNTARGETED / FB_TARGETED */
+  double adver_thresh;
+  double epsilon;
+  int max_iter;
+  double max_lr, min_lr;
+  int samples_per_draw;
+  double sigma;
+  double momentum;
+  int plateau_length;
+  double plateau_drop;
+  double threshold;  /* attack(threshold=...) */
+  int target;        /* attack(target=...)  (index into speakers) */
+  int true_label;    /* attack(true=...) */
+  uint64_t seed;     /* Philox4x32-10 key */
+  uint32_t stream;   /* Philox counter word 3 (utterance / attack id) */
+} fb_nes_params;
+
+const char *fb_last_error(void);
+int fb_version(void);
+int fb_device_count(void);
+
+int fb_engine_create(int device, fb_engine **out);
+int fb_engine_destroy(fb_engine *e);
+
+void fb_default_frontend(fb_frontend_cfg *cfg);
+int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *cfg);
+
+/* Diagonal GMMs in Kaldi DiagGmm internal form (float32): gconsts[M*C],
+ * means_invvars[M*C*D], inv_vars[M*C*D].  Models whose inv_vars are bitwise
+ * identical (mean-only MAP adaptation, build_spk_models.py:170) share the
+ * quadratic term on device. */
+int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gconsts,
+                const float *means_invvars, const float *inv_vars);
+
+/* How raw per-model log-likelihoods become system scores:
+ *  OSI / SV: model 0 is the UBM, S = M-1, score = raw[1+s] - raw[0]
+ *  CSI     : S = M, score = (raw - z_mean) / z_std                          */
+int fb_set_system(fb_engine *e, int task, const double *z_mean, const double *z_std);
+int fb_num_speakers(fb_engine *e);
+
+/* Average voiced-frame log-likelihood of every utterance under every model.
+ * wav: concatenated samples, off[B+1] offsets; raw[B*M]; tv[B] (nullable) =
+ * voiced frame counts. */
+int fb_score_i16(fb_engine *e, const int16_t *wav, const int64_t *off, int B,
+                 double *raw, int *tv);
+int fb_score_f64(fb_engine *e, const double *audio, const int64_t *off, int B,
+                 int bits_per_sample, double *raw, int *tv);
+/* raw[B*M] -> scores[B*S] per fb_set_system */
+int fb_system_scores(fb_engine *e, const double *raw, int B, double *scores);
+
+/* One NES gradient estimate at `audio` (FAKEBOB.py:223-246).  noise_pos:
+ * NULL -> Philox(seed, iter, stream); else float64 [N][spd/2] row-major
+ * (the tensor np.random.normal would have produced).  grad[N] nullable,
+ * score0[S]. */
+int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *audio,
+                int64_t N, uint32_t iter, const double *noise_pos,
+                double *final_loss, double *grad, double *adver_loss,
+                double *score0);
+
+/* Whole attack loop on device.  noise_all NULL or [max_iter][N*(spd/2)].
+ * adv_i16[N]; adver_f64[N] nullable; trace[max_iter*(3+S)] nullable rows of
+ * {distance, adver_loss, lr_after_iter, score0[S]}; *n_trace rows written;
+ * *success_flag = +1/-1 with the reference's iter < max_iter-1 rule (:219). */
+int fb_attack(fb_engine *e, const fb_nes_params *p, const double *audio,
+              int64_t N, const double *noise_all, int16_t *adv_i16,
+              double *adver_f64, double *trace, int *n_trace,
+              int *success_flag);
+
+/* Threshold sweep (FAKEBOB.py:39-137).  model_threshold: the system's own
+ * threshold consulted by make_decisions.  Returns FB_E_LIMIT if
+ * max_total_iters gradient steps did not reach acceptance. */
+int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p,
+                          double model_threshold, const double *audio,
+                          int64_t N, const double *noise_all,
+                          int max_total_iters, double *score_out,
+                          int *n_iters, int *n_outer, double *thr_final,
+                          double *adver_f64);
+
+/* --- test / profiling hooks (stable, used by tests/ and bench.py) ------- */
+/* z[half*N] float32 from the device Philox/Box-Muller (bit-exact contract) */
+int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32_t stream,
+                   int64_t N, int half, float *z);
+/* front-end only: MFCC [T*num_ceps] of one utterance */
+int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T);
+/* compacted voiced CMVN'd features of one utterance: feats[Tv*dim] */
+int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
+                   int *Tv, int *T);
+/* counters since engine creation */
+int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames,
+             int64_t *voiced_frames, int64_t *nes_iters);
+/* time `reps` back-to-back launches of the GMM log-likelihood kernel on the
+ * engine's stream with HIP events over the current device feature buffer
+ * (filled by the last score/get_grad call). ms_avg out. */
+int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64_t *rows);
+/* run `iters` NES iterations (get_grad + update, early stop disabled) on the
+ * device without host round trips; returns elapsed ms (HIP events) and the
+ * accumulated time of the GMM kernel alone (events around each launch when
+ * time_gmm != 0). */
+int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *audio,
+                 int64_t N, int warmup, int iters, int time_gmm,
+                 double *ms_total, double *ms_gmm, int64_t *voiced_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,755 @@
+/*
+ * fb_oracle.c -- CPU restatement of the FAKEBOB NES hot path (see fb_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: never linked or called by the product.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; contraction is OFF
+ * so every a*b+c below is two roundings unless written as fma()).
+ *
+ * Reference citations are into /root/reference (FAKEBOB-adversarial-attack/
+ * FAKEBOB).  "[EXT]" marks arithmetic that the reference delegates to Kaldi
+ * executables and that is restated here from Kaldi's published algorithms
+ * (SURVEY.md Appendix A): parity for those parts is UNPINNED.
+ */
+#include "fb_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ cfg */
+void fbo_default_cfg(fbo_frontend_cfg *c) {
+  /* [EXT] voxceleb/v1 conf/mfcc.conf, conf/vad.conf, delta_opts
+   * (SURVEY.md A.1, A.4, A.5); cmn flags: gmm_ubm_kaldiHelper.py:196 */
+  c->sample_freq = 16000.0;
+  c->frame_length = 400;
+  c->frame_shift = 160;
+  c->padded_length = 512;
+  c->num_mel_bins = 30;
+  c->num_ceps = 24;
+  c->low_freq = 20.0;
+  c->high_freq = 7600.0;
+  c->preemph = 0.97;
+  c->cepstral_lifter = 22.0;
+  c->snip_edges = 0;
+  c->remove_dc = 1;
+  c->use_energy = 1;
+  c->raw_energy = 1;
+  c->energy_floor = 0.0;
+  c->vad_energy_threshold = 5.5;
+  c->vad_energy_mean_scale = 0.5;
+  c->vad_proportion_threshold = 0.12;
+  c->vad_frames_context = 2;
+  c->delta_window = 3;
+  c->delta_order = 2;
+  c->cmn_window = 300;
+}
+
+/* --------------------------------------------------------------- Philox */
+/* Philox4x32-10 (Salmon et al., SC'11).  The reference never seeds its RNG
+ * (FAKEBOB.py:234 uses the global numpy state), so "same inputs" must include
+ * the noise: this counter-based stream is the shared contract.             */
+void fbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Box-Muller in float32 built ONLY from exactly-rounded primitives
+ * (int->float, fmaf, *, +, sqrtf) so that the HIP twin is bit-identical. */
+static float fbo_ln_u(float u) { /* u in (0,1] */
+  union { float f; uint32_t i; } v; v.f = u;
+  int e = (int)(v.i >> 23) - 127;
+  v.i = (v.i & 0x007FFFFFu) | 0x3F800000u;
+  float m = v.f;
+  if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+  float t = m - 1.0f; /* exact */
+  /* ln(1+t) = t - t^2/2 + t^3/3 - ... (Horner, 20 terms) */
+  float p = -1.0f / 20.0f;
+  p = fmaf(p, t, 1.0f / 19.0f);
+  p = fmaf(p, t, -1.0f / 18.0f);
+  p = fmaf(p, t, 1.0f / 17.0f);
+  p = fmaf(p, t, -1.0f / 16.0f);
+  p = fmaf(p, t, 1.0f / 15.0f);
+  p = fmaf(p, t, -1.0f / 14.0f);
+  p = fmaf(p, t, 1.0f / 13.0f);
+  p = fmaf(p, t, -1.0f / 12.0f);
+  p = fmaf(p, t, 1.0f / 11.0f);
+  p = fmaf(p, t, -1.0f / 10.0f);
+  p = fmaf(p, t, 1.0f / 9.0f);
+  p = fmaf(p, t, -1.0f / 8.0f);
+  p = fmaf(p, t, 1.0f / 7.0f);
+  p = fmaf(p, t, -1.0f / 6.0f);
+  p = fmaf(p, t, 1.0f / 5.0f);
+  p = fmaf(p, t, -1.0f / 4.0f);
+  p = fmaf(p, t, 1.0f / 3.0f);
+  p = fmaf(p, t, -1.0f / 2.0f);
+  p = fmaf(p, t, 1.0f);
+  p = p * t;
+  return fmaf((float)e, 0.693147182f, p);
+}
+
+static void fbo_sincos_q(float a, float *s, float *c) { /* a in [0, pi/2) */
+  float a2 = a * a;
+  float ps = -1.0f / 1307674368000.0f;           /* -1/15! */
+  ps = fmaf(ps, a2, 1.0f / 6227020800.0f);       /*  1/13! */
+  ps = fmaf(ps, a2, -1.0f / 39916800.0f);        /* -1/11! */
+  ps = fmaf(ps, a2, 1.0f / 362880.0f);           /*  1/9!  */
+  ps = fmaf(ps, a2, -1.0f / 5040.0f);            /* -1/7!  */
+  ps = fmaf(ps, a2, 1.0f / 120.0f);
+  ps = fmaf(ps, a2, -1.0f / 6.0f);
+  ps = fmaf(ps, a2, 1.0f);
+  *s = ps * a;
+  float pc = 1.0f / 20922789888000.0f;           /*  1/16! */
+  pc = fmaf(pc, a2, -1.0f / 87178291200.0f);     /* -1/14! */
+  pc = fmaf(pc, a2, 1.0f / 479001600.0f);        /*  1/12! */
+  pc = fmaf(pc, a2, -1.0f / 3628800.0f);         /* -1/10! */
+  pc = fmaf(pc, a2, 1.0f / 40320.0f);            /*  1/8!  */
+  pc = fmaf(pc, a2, -1.0f / 720.0f);
+  pc = fmaf(pc, a2, 1.0f / 24.0f);
+  pc = fmaf(pc, a2, -0.5f);
+  pc = fmaf(pc, a2, 1.0f);
+  *c = pc;
+}
+
+static void fbo_box_muller(uint32_t r0, uint32_t r1, float *z0, float *z1) {
+  float u1 = (float)((r0 >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24, (0,1] */
+  uint32_t q = r1 >> 30;
+  uint32_t fr = (r1 & 0x3FFFFFFFu) >> 6; /* 24 bits */
+  float a = (float)fr * 9.36227702e-08f;  /* (pi/2) * 2^-24 */
+  float s, c;
+  fbo_sincos_q(a, &s, &c);
+  float rr = sqrtf(-2.0f * fbo_ln_u(u1));
+  float cs, sn;
+  switch (q) {
+    case 0: cs = c; sn = s; break;
+    case 1: cs = -s; sn = c; break;
+    case 2: cs = -c; sn = -s; break;
+    default: cs = s; sn = -c; break;
+  }
+  *z0 = rr * cs;
+  *z1 = rr * sn;
+}
+
+void fbo_noise(uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half, float *z) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int j = 0; j < half; ++j) {
+    for (int64_t n4 = 0; n4 < (N + 3) / 4; ++n4) {
+      uint32_t ctr[4] = {(uint32_t)n4, (uint32_t)j, iter, stream};
+      uint32_t r[4];
+      float v[4];
+      fbo_philox4x32_10(ctr, key, r);
+      fbo_box_muller(r[0], r[1], &v[0], &v[1]);
+      fbo_box_muller(r[2], r[3], &v[2], &v[3]);
+      for (int k = 0; k < 4; ++k) {
+        int64_t n = n4 * 4 + k;
+        if (n < N) z[(int64_t)j * N + n] = v[k];
+      }
+    }
+  }
+}
+
+/* ----------------------------------------------------------- quantise K1 */
+/* (audio * 2**(bits-1)).astype(np.int16): gmm_ubm_OSI.py:83-85,
+ * ivector_PLDA_OSI.py:113-115.  numpy's C cast on x86-64 truncates toward
+ * zero and keeps the low 16 bits (1.0 -> -32768, golden G5). */
+void fbo_quantize(const double *x, int64_t n, int bits_per_sample, int16_t *q) {
+  double scale = ldexp(1.0, bits_per_sample - 1);
+  for (int64_t i = 0; i < n; ++i) {
+    double v = x[i] * scale;
+    int64_t t;
+    if (!(v > -9.2e18 && v < 9.2e18)) t = 0; /* NaN / out of int64: indefinite -> low bits 0 */
+    else t = (int64_t)v;                     /* trunc toward zero */
+    q[i] = (int16_t)(uint16_t)((uint64_t)t & 0xFFFFu);
+  }
+}
+
+/* ------------------------------------------------------------- MFCC [EXT] */
+int fbo_num_frames(const fbo_frontend_cfg *c, int64_t n) {
+  if (c->snip_edges) {
+    if (n < c->frame_length) return 0;
+    return (int)(1 + (n - c->frame_length) / c->frame_shift);
+  }
+  return (int)((n + c->frame_shift / 2) / c->frame_shift);
+}
+int fbo_feat_dim(const fbo_frontend_cfg *c) { return c->num_ceps * (c->delta_order + 1); }
+
+typedef struct {
+  int L, P, nb, nc;
+  float *window;        /* [L] povey, stored float like Kaldi */
+  double *tw_re, *tw_im;/* [P/2] twiddles */
+  int *rev;             /* [P] bit reversal */
+  int *mel_first, *mel_len; /* [nb] */
+  float *mel_w;         /* [nb][P/2] */
+  float *dct;           /* [nc][nb] */
+  float *lifter;        /* [nc] */
+} fbo_mfcc_tables;
+
+static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+
+static fbo_mfcc_tables *mfcc_tables_new(const fbo_frontend_cfg *c) {
+  fbo_mfcc_tables *t = (fbo_mfcc_tables *)calloc(1, sizeof(*t));
+  int L = c->frame_length, P = c->padded_length, nb = c->num_mel_bins, nc = c->num_ceps;
+  t->L = L; t->P = P; t->nb = nb; t->nc = nc;
+  t->window = (float *)malloc(sizeof(float) * L);
+  double a = 2.0 * M_PI / (L - 1);
+  for (int i = 0; i < L; ++i) t->window[i] = (float)pow(0.5 - 0.5 * cos(a * i), 0.85);
+  t->tw_re = (double *)malloc(sizeof(double) * P / 2);
+  t->tw_im = (double *)malloc(sizeof(double) * P / 2);
+  for (int k = 0; k < P / 2; ++k) {
+    t->tw_re[k] = cos(-2.0 * M_PI * k / P);
+    t->tw_im[k] = sin(-2.0 * M_PI * k / P);
+  }
+  t->rev = (int *)malloc(sizeof(int) * P);
+  int bits = 0; while ((1 << bits) < P) ++bits;
+  for (int i = 0; i < P; ++i) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+    t->rev[i] = r;
+  }
+  /* mel banks: triangles linear in mel, evaluated at FFT-bin centres; bins
+   * 0..P/2-1 only */
+  int nfft = P / 2;
+  t->mel_first = (int *)malloc(sizeof(int) * nb);
+  t->mel_len = (int *)malloc(sizeof(int) * nb);
+  t->mel_w = (float *)calloc((size_t)nb * nfft, sizeof(float));
+  double nyq = 0.5 * c->sample_freq;
+  double hi = c->high_freq > 0.0 ? c->high_freq : nyq + c->high_freq;
+  double bw = c->sample_freq / P;
+  double mlo = mel_scale(c->low_freq), mhi = mel_scale(hi);
+  double md = (mhi - mlo) / (nb + 1);
+  for (int b = 0; b < nb; ++b) {
+    double left = mlo + b * md, center = mlo + (b + 1) * md, right = mlo + (b + 2) * md;
+    int first = -1, last = -1;
+    for (int i = 0; i < nfft; ++i) {
+      double mel = mel_scale(bw * i);
+      if (mel > left && mel < right) {
+        double w = mel <= center ? (mel - left) / (center - left) : (right - mel) / (right - center);
+        t->mel_w[(size_t)b * nfft + i] = (float)w;
+        if (first < 0) first = i;
+        last = i;
+      }
+    }
+    t->mel_first[b] = first < 0 ? 0 : first;
+    t->mel_len[b] = first < 0 ? 0 : last - first + 1;
+  }
+  t->dct = (float *)malloc(sizeof(float) * nc * nb);
+  for (int k = 0; k < nc; ++k)
+    for (int n = 0; n < nb; ++n)
+      t->dct[k * nb + n] = (k == 0) ? (float)sqrt(1.0 / nb)
+                                    : (float)(sqrt(2.0 / nb) * cos(M_PI / nb * (n + 0.5) * k));
+  t->lifter = (float *)malloc(sizeof(float) * nc);
+  for (int i = 0; i < nc; ++i)
+    t->lifter[i] = c->cepstral_lifter != 0.0
+                       ? (float)(1.0 + 0.5 * c->cepstral_lifter * sin(M_PI * i / c->cepstral_lifter))
+                       : 1.0f;
+  return t;
+}
+static void mfcc_tables_free(fbo_mfcc_tables *t) {
+  free(t->window); free(t->tw_re); free(t->tw_im); free(t->rev);
+  free(t->mel_first); free(t->mel_len); free(t->mel_w); free(t->dct); free(t->lifter); free(t);
+}
+
+/* plain iterative radix-2 DIT complex FFT, float64 */
+static void fft_c2c(const fbo_mfcc_tables *t, double *re, double *im) {
+  int P = t->P;
+  for (int i = 0; i < P; ++i) {
+    int r = t->rev[i];
+    if (r > i) { double a = re[i]; re[i] = re[r]; re[r] = a; a = im[i]; im[i] = im[r]; im[r] = a; }
+  }
+  for (int len = 2; len <= P; len <<= 1) {
+    int half = len >> 1, step = P / len;
+    for (int s = 0; s < P; s += len)
+      for (int k = 0; k < half; ++k) {
+        double wr = t->tw_re[k * step], wi = t->tw_im[k * step];
+        double xr = re[s + k + half], xi = im[s + k + half];
+        double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+        re[s + k + half] = re[s + k] - tr; im[s + k + half] = im[s + k] - ti;
+        re[s + k] += tr; im[s + k] += ti;
+      }
+  }
+}
+
+int fbo_mfcc(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float *out) {
+  int T = fbo_num_frames(c, n);
+  if (T <= 0) return 0;
+  fbo_mfcc_tables *t = mfcc_tables_new(c);
+  int L = t->L, P = t->P, nb = t->nb, nc = t->nc, nfft = P / 2;
+  double *re = (double *)malloc(sizeof(double) * P), *im = (double *)malloc(sizeof(double) * P);
+  double *pw = (double *)malloc(sizeof(double) * (nfft + 1));
+  double *lm = (double *)malloc(sizeof(double) * nb);
+  for (int f = 0; f < T; ++f) {
+    int64_t start = c->snip_edges ? (int64_t)f * c->frame_shift
+                                  : (int64_t)f * c->frame_shift + c->frame_shift / 2 - L / 2;
+    for (int s = 0; s < L; ++s) {
+      int64_t k = start + s;
+      while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * n - 1 - k; }
+      re[s] = (double)wav[k];
+    }
+    if (c->remove_dc) {
+      double sum = 0.0;
+      for (int s = 0; s < L; ++s) sum += re[s];
+      double mean = sum / L;
+      for (int s = 0; s < L; ++s) re[s] -= mean;
+    }
+    double energy = 0.0;
+    if (c->raw_energy) { for (int s = 0; s < L; ++s) energy += re[s] * re[s]; }
+    if (c->preemph != 0.0) {
+      for (int s = L - 1; s > 0; --s) re[s] -= c->preemph * re[s - 1];
+      re[0] -= c->preemph * re[0];
+    }
+    for (int s = 0; s < L; ++s) re[s] *= (double)t->window[s];
+    if (!c->raw_energy) { for (int s = 0; s < L; ++s) energy += re[s] * re[s]; }
+    double log_energy = log(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
+    for (int s = L; s < P; ++s) re[s] = 0.0;
+    for (int s = 0; s < P; ++s) im[s] = 0.0;
+    fft_c2c(t, re, im);
+    for (int k = 0; k <= nfft; ++k) pw[k] = re[k] * re[k] + im[k] * im[k];
+    for (int b = 0; b < nb; ++b) {
+      double e = 0.0;
+      const float *w = t->mel_w + (size_t)b * nfft;
+      for (int i = t->mel_first[b]; i < t->mel_first[b] + t->mel_len[b]; ++i) e += (double)w[i] * pw[i];
+      if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
+      lm[b] = log(e);
+    }
+    for (int k = 0; k < nc; ++k) {
+      double acc = 0.0;
+      for (int b = 0; b < nb; ++b) acc += (double)t->dct[k * nb + b] * lm[b];
+      acc *= (double)t->lifter[k];
+      out[(size_t)f * nc + k] = (float)acc;
+    }
+    if (c->use_energy) {
+      if (c->energy_floor > 0.0 && log_energy < log(c->energy_floor)) log_energy = log(c->energy_floor);
+      out[(size_t)f * nc] = (float)log_energy;
+    }
+  }
+  free(re); free(im); free(pw); free(lm);
+  mfcc_tables_free(t);
+  return T;
+}
+
+/* --------------------------------------------------------------- VAD [EXT] */
+void fbo_vad(const fbo_frontend_cfg *c, const float *mfcc, int T, uint8_t *voiced) {
+  int nc = c->num_ceps;
+  double sum = 0.0;
+  for (int t = 0; t < T; ++t) sum += (double)mfcc[(size_t)t * nc];
+  float thr = (float)(c->vad_energy_threshold + c->vad_energy_mean_scale * sum / T);
+  int ctx = c->vad_frames_context;
+  for (int t = 0; t < T; ++t) {
+    int num = 0, den = 0;
+    for (int t2 = t - ctx; t2 <= t + ctx; ++t2)
+      if (t2 >= 0 && t2 < T) { ++den; if (mfcc[(size_t)t2 * nc] > thr) ++num; }
+    voiced[t] = ((float)num >= (float)den * (float)c->vad_proportion_threshold) ? 1 : 0;
+  }
+}
+
+/* ------------------------------------------------------- add-deltas [EXT] */
+void fbo_deltas(const fbo_frontend_cfg *c, const float *mfcc, int T, float *out) {
+  int nc = c->num_ceps, order = c->delta_order, W = c->delta_window;
+  int dim = nc * (order + 1);
+  /* scales[i]: kernel of order i, length 2*i*W+1 */
+  int maxlen = 2 * order * W + 1;
+  double *scales = (double *)calloc((size_t)(order + 1) * maxlen, sizeof(double));
+  scales[0] = 1.0;
+  for (int i = 1; i <= order; ++i) {
+    const double *prev = scales + (size_t)(i - 1) * maxlen;
+    double *cur = scales + (size_t)i * maxlen;
+    int prev_off = (i - 1) * W, cur_off = i * W;
+    double normalizer = 0.0;
+    for (int j = -W; j <= W; ++j) {
+      normalizer += (double)j * j;
+      for (int k = -prev_off; k <= prev_off; ++k)
+        cur[j + k + cur_off] += (double)j * prev[k + prev_off];
+    }
+    for (int k = 0; k < 2 * cur_off + 1; ++k) cur[k] = (double)(float)(cur[k] / normalizer);
+  }
+  for (int t = 0; t < T; ++t) {
+    for (int i = 0; i <= order; ++i) {
+      const double *sc = scales + (size_t)i * maxlen;
+      int off = i * W;
+      for (int d = 0; d < nc; ++d) {
+        double acc = 0.0;
+        for (int j = -off; j <= off; ++j) {
+          int tt = t + j; if (tt < 0) tt = 0; if (tt > T - 1) tt = T - 1;
+          double s = sc[j + off];
+          if (s != 0.0) acc += s * (double)mfcc[(size_t)tt * nc + d];
+        }
+        out[(size_t)t * dim + i * nc + d] = (float)acc;
+      }
+    }
+  }
+  free(scales);
+}
+
+/* ----------------------------------------------- apply-cmvn-sliding [EXT] */
+void fbo_cmvn_sliding(const fbo_frontend_cfg *c, float *feats, int T, int dim) {
+  int Wn = c->cmn_window;
+  float *src = (float *)malloc(sizeof(float) * (size_t)T * dim);
+  memcpy(src, feats, sizeof(float) * (size_t)T * dim);
+  double *pre = (double *)calloc((size_t)(T + 1) * dim, sizeof(double)); /* prefix sums */
+  for (int t = 0; t < T; ++t)
+    for (int d = 0; d < dim; ++d)
+      pre[(size_t)(t + 1) * dim + d] = pre[(size_t)t * dim + d] + (double)src[(size_t)t * dim + d];
+  for (int t = 0; t < T; ++t) {
+    int wb = t - Wn / 2, we = wb + Wn;
+    if (wb < 0) { we -= wb; wb = 0; }
+    if (we > T) { wb -= (we - T); we = T; if (wb < 0) wb = 0; }
+    int wf = we - wb;
+    float alpha = (float)(-1.0 / wf);
+    for (int d = 0; d < dim; ++d) {
+      double sum = pre[(size_t)we * dim + d] - pre[(size_t)wb * dim + d];
+      feats[(size_t)t * dim + d] = (float)((double)src[(size_t)t * dim + d] + (double)alpha * sum);
+    }
+  }
+  free(src); free(pre);
+}
+
+/* pipeline order: gmm_ubm_kaldiHelper.py:195-198 (add-deltas | apply-cmvn-
+ * sliding | select-voiced-frames); VAD from the raw MFCC C0 (:151-169). */
+int fbo_frontend(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float *feats, int *T_out) {
+  int T = fbo_num_frames(c, n);
+  if (T_out) *T_out = T;
+  if (T <= 0) return 0;
+  int nc = c->num_ceps, dim = fbo_feat_dim(c);
+  float *mf = (float *)malloc(sizeof(float) * (size_t)T * nc);
+  float *df = (float *)malloc(sizeof(float) * (size_t)T * dim);
+  uint8_t *v = (uint8_t *)malloc(T);
+  fbo_mfcc(c, wav, n, mf);
+  fbo_vad(c, mf, T, v);
+  fbo_deltas(c, mf, T, df);
+  fbo_cmvn_sliding(c, df, T, dim);
+  int tv = 0;
+  for (int t = 0; t < T; ++t)
+    if (v[t]) { memcpy(feats + (size_t)tv * dim, df + (size_t)t * dim, sizeof(float) * dim); ++tv; }
+  free(mf); free(df); free(v);
+  return tv;
+}
+
+/* -------------------------------------- gmm-global-get-frame-likes [EXT] */
+double fbo_diag_gmm_loglikes(const float *gc, const float *miv, const float *iv, int C, int D,
+                             const float *feats, int Tv, float *ll_out) {
+  double total = 0.0;
+  double *x = (double *)malloc(sizeof(double) * 2 * D);
+  double *ll = (double *)malloc(sizeof(double) * C);
+  for (int t = 0; t < Tv; ++t) {
+    const float *f = feats + (size_t)t * D;
+    for (int d = 0; d < D; ++d) { x[d] = (double)f[d]; x[D + d] = (double)(float)(f[d] * f[d]); }
+    double mx = -INFINITY;
+    for (int k = 0; k < C; ++k) {
+      const float *m = miv + (size_t)k * D, *v = iv + (size_t)k * D;
+      double a = 0.0, b = 0.0;
+      for (int d = 0; d < D; ++d) { a += (double)m[d] * x[d]; b += (double)v[d] * x[D + d]; }
+      double l = (double)gc[k] + a - 0.5 * b;
+      ll[k] = l;
+      if (l > mx) mx = l;
+    }
+    double s = 0.0;
+    for (int k = 0; k < C; ++k) s += exp(ll[k] - mx);
+    float lf = (float)(mx + log(s));
+    if (ll_out) ll_out[t] = lf;
+    total += (double)lf;
+  }
+  free(x); free(ll);
+  return total;
+}
+
+int fbo_gmm_score_batch(const fbo_frontend_cfg *c, const int16_t *wav, const int64_t *off, int B,
+                        const float *gc, const float *miv, const float *iv, int M, int C, int D,
+                        double *raw, int *tv_out, int nthreads) {
+  int err = 0;
+  if (fbo_feat_dim(c) != D) return -1000000;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    int64_t n = off[b + 1] - off[b];
+    int T = fbo_num_frames(c, n);
+    float *feats = (float *)malloc(sizeof(float) * (size_t)(T > 0 ? T : 1) * D);
+    int Tt = 0;
+    int tv = fbo_frontend(c, wav + off[b], n, feats, &Tt);
+    if (tv_out) tv_out[b] = tv;
+    if (tv <= 0) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      { if (err == 0 || -(b + 1) > err) err = -(b + 1); }
+      for (int m = 0; m < M; ++m) raw[(size_t)b * M + m] = NAN;
+    } else {
+      for (int m = 0; m < M; ++m) {
+        double tot = fbo_diag_gmm_loglikes(gc + (size_t)m * C, miv + (size_t)m * C * D,
+                                           iv + (size_t)m * C * D, C, D, feats, tv, NULL);
+        raw[(size_t)b * M + m] = tot / tv;
+      }
+    }
+    free(feats);
+  }
+  (void)nthreads;
+  return err;
+}
+
+/* --------------------------------------------------------------- NES core */
+double fbo_np_sum(const double *a, int64_t n) {
+  /* numpy pairwise_sum (loops_utils.h.src), contiguous float64, verified
+   * bit-for-bit against numpy 2.2.6 in tests/test_oracle_nes.py */
+  if (n < 8) {
+    double r = 0.0;
+    for (int64_t i = 0; i < n; ++i) r += a[i];
+    return r;
+  } else if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return fbo_np_sum(a, n2) + fbo_np_sum(a + n2, n - n2);
+  }
+}
+
+void fbo_loss(int task, int attack_type, const double *score, int B, int S, double threshold,
+              double adver_thresh, int target, int true_label, double *loss) {
+  for (int b = 0; b < B; ++b) {
+    const double *s = score + (size_t)b * S;
+    if (task == FBO_TASK_OSI && attack_type == FBO_TARGETED) { /* FAKEBOB.py:256-262 */
+      double om = -INFINITY;
+      for (int j = 0; j < S; ++j) if (j != target && s[j] > om) om = s[j];
+      double mx = om > threshold ? om : threshold; /* np.maximum */
+      loss[b] = (mx + adver_thresh) - s[target];
+    } else if (task == FBO_TASK_OSI) {                          /* :265-269 */
+      double mx = -INFINITY;
+      for (int j = 0; j < S; ++j) if (s[j] > mx) mx = s[j];
+      loss[b] = (threshold + adver_thresh) - mx;
+    } else if (task == FBO_TASK_CSI && attack_type == FBO_TARGETED) { /* :275-281 */
+      double om = -INFINITY;
+      for (int j = 0; j < S; ++j) if (j != target && s[j] > om) om = s[j];
+      loss[b] = (om + adver_thresh) - s[target];
+    } else if (task == FBO_TASK_CSI) {                          /* :285-291 */
+      double om = -INFINITY;
+      for (int j = 0; j < S; ++j) if (j != true_label && s[j] > om) om = s[j];
+      loss[b] = (s[true_label] + adver_thresh) - om;
+    } else {                                                    /* SV :297 */
+      loss[b] = (threshold + adver_thresh) - s[0];
+    }
+  }
+}
+
+int fbo_get_grad(const fbo_nes_params *p, fbo_score_fn fn, void *ctx, const double *audio,
+                 int64_t N, const double *noise_pos, uint64_t seed, uint32_t iter,
+                 uint32_t stream, double *final_loss, double *grad, double *adver_loss,
+                 double *score0) {
+  int half = p->samples_per_draw / 2, spd = 2 * half, B = spd + 1, S = p->n_spk;
+  float *z = NULL;
+  if (!noise_pos) {
+    z = (float *)malloc(sizeof(float) * (size_t)N * (half > 0 ? half : 1));
+    fbo_noise(seed, iter, stream, N, half, z);
+  }
+  double *aud = (double *)malloc(sizeof(double) * (size_t)N * B); /* [B][N] */
+  double *noise = (double *)malloc(sizeof(double) * (size_t)N * (spd > 0 ? spd : 1)); /* [N][spd] */
+  for (int64_t n = 0; n < N; ++n) {
+    aud[n] = p->sigma * 0.0 + audio[n];
+    for (int j = 0; j < half; ++j) {
+      double zz = noise_pos ? noise_pos[(size_t)n * half + j] : (double)z[(size_t)j * N + n];
+      double nz = -1.0 * zz;
+      noise[(size_t)n * spd + j] = zz;
+      noise[(size_t)n * spd + half + j] = nz;
+      aud[(size_t)(1 + j) * N + n] = p->sigma * zz + audio[n];        /* FAKEBOB.py:237 */
+      aud[(size_t)(1 + half + j) * N + n] = p->sigma * nz + audio[n];
+    }
+  }
+  double *scores = (double *)malloc(sizeof(double) * (size_t)B * S);
+  double *loss = (double *)malloc(sizeof(double) * B);
+  int rc = fn(ctx, aud, N, B, scores);
+  if (rc == 0) {
+    fbo_loss(p->task, p->attack_type, scores, B, S, p->threshold, p->adver_thresh, p->target,
+             p->true_label, loss);
+    *adver_loss = loss[0];
+    for (int j = 0; j < S; ++j) score0[j] = scores[j];
+    *final_loss = fbo_np_sum(loss + 1, spd) / (double)spd;            /* np.mean :243 */
+    double *prod = (double *)malloc(sizeof(double) * (spd > 0 ? spd : 1));
+    for (int64_t n = 0; n < N; ++n) {
+      for (int j = 0; j < spd; ++j) prod[j] = loss[1 + j] * noise[(size_t)n * spd + j];
+      grad[n] = (fbo_np_sum(prod, spd) / (double)spd) / p->sigma;     /* :244 */
+    }
+    free(prod);
+  }
+  free(z); free(aud); free(noise); free(scores); free(loss);
+  return rc;
+}
+
+static double sgn(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : (x == 0.0 ? 0.0 : x)); }
+static double clipd(double x, double lo, double hi) { /* np.clip = minimum(maximum(x,lo),hi) */
+  double y = x < lo ? lo : x;
+  return y > hi ? hi : y;
+}
+
+int fbo_attack(const fbo_nes_params *p, fbo_score_fn fn, void *ctx, const double *audio,
+               int64_t N, const double *noise_all, uint64_t seed, uint32_t stream,
+               int16_t *adv_i16, double *adver_out, double *trace, int *n_trace) {
+  int half = p->samples_per_draw / 2, S = p->n_spk;
+  double *adver = (double *)malloc(sizeof(double) * N);
+  double *grad = (double *)calloc(N, sizeof(double));   /* grad = 0 :157 */
+  double *g = (double *)malloc(sizeof(double) * N);
+  double *lower = (double *)malloc(sizeof(double) * N), *upper = (double *)malloc(sizeof(double) * N);
+  double *last_ls = (double *)malloc(sizeof(double) * (p->plateau_length + 1));
+  double *score0 = (double *)malloc(sizeof(double) * S);
+  int n_ls = 0, it = 0, rows = 0, rc = 0;
+  double lr = p->max_lr;
+  fbo_nes_params q = *p;
+  for (int64_t n = 0; n < N; ++n) {
+    adver[n] = audio[n];
+    lower[n] = clipd(audio[n] - p->epsilon, -1.0, 1.0);               /* :163-164 */
+    upper[n] = clipd(audio[n] + p->epsilon, -1.0, 1.0);
+  }
+  int broke = 0;
+  for (it = 0; it < p->max_iter; ++it) {                               /* :168 */
+    double loss, adver_loss;
+    rc = fbo_get_grad(&q, fn, ctx, adver, N,
+                      noise_all ? noise_all + (size_t)it * N * half : NULL, seed, (uint32_t)it,
+                      stream, &loss, g, &adver_loss, score0);
+    if (rc) break;
+    double dist = 0.0;
+    for (int64_t n = 0; n < N; ++n) { double d = fabs(audio[n] - adver[n]); if (d > dist) dist = d; }
+    double *row = trace ? trace + (size_t)rows * (3 + S) : NULL;
+    if (adver_loss < 0.0) {                                            /* :181 */
+      if (row) { row[0] = dist; row[1] = adver_loss; row[2] = lr; memcpy(row + 3, score0, sizeof(double) * S); }
+      ++rows; broke = 1;
+      break;
+    }
+    for (int64_t n = 0; n < N; ++n)                                    /* :193 */
+      grad[n] = p->momentum * grad[n] + (1.0 - p->momentum) * g[n];
+    last_ls[n_ls++] = loss;                                            /* :195-200 */
+    if (n_ls > p->plateau_length) { memmove(last_ls, last_ls + 1, sizeof(double) * p->plateau_length); n_ls = p->plateau_length; }
+    if (last_ls[n_ls - 1] > last_ls[0] && n_ls == p->plateau_length) {
+      if (lr > p->min_lr) { double l2 = lr / p->plateau_drop; lr = l2 > p->min_lr ? l2 : p->min_lr; }
+      n_ls = 0;
+    }
+    for (int64_t n = 0; n < N; ++n) {                                  /* :202-203 */
+      adver[n] -= lr * sgn(grad[n]);
+      adver[n] = clipd(adver[n], lower[n], upper[n]);
+    }
+    if (row) { row[0] = dist; row[1] = adver_loss; row[2] = lr; memcpy(row + 3, score0, sizeof(double) * S); }
+    ++rows;
+  }
+  int last_iter = broke ? it : p->max_iter - 1; /* python `iter` after the loop */
+  int flag = (last_iter < p->max_iter - 1) ? 1 : -1;                   /* :219 */
+  if (p->max_iter <= 0) flag = 0;
+  fbo_quantize(adver, N, 16, adv_i16);                                 /* :220 */
+  if (adver_out) memcpy(adver_out, adver, sizeof(double) * N);
+  if (n_trace) *n_trace = rows;
+  free(adver); free(grad); free(g); free(lower); free(upper); free(last_ls); free(score0);
+  return rc ? 0 : flag;
+}
+
+int fbo_estimate_threshold(const fbo_nes_params *p, double model_threshold, fbo_score_fn fn,
+                           void *ctx, const double *audio, int64_t N, const double *noise_all,
+                           int max_total_iters, uint64_t seed, uint32_t stream,
+                           double *score_out, int *n_iters_out, int *n_outer_out,
+                           double *thr_final, double *adver_out) {
+  if (p->task == FBO_TASK_CSI) return 1;                               /* :41-43 */
+  int half = p->samples_per_draw / 2, S = p->n_spk;
+  double *sc = (double *)malloc(sizeof(double) * S);
+  double *adver = (double *)malloc(sizeof(double) * N);
+  double *grad = (double *)calloc(N, sizeof(double));
+  double *g = (double *)malloc(sizeof(double) * N);
+  double *lower = (double *)malloc(sizeof(double) * N), *upper = (double *)malloc(sizeof(double) * N);
+  double *last_ls = (double *)malloc(sizeof(double) * (p->plateau_length + 1));
+  int rc = fn(ctx, audio, N, 1, sc);                                   /* :53 */
+  double init = sc[0];
+  for (int j = 1; j < S; ++j) if (sc[j] > init) init = sc[j];          /* :54-55 */
+  double delta = fabs(init / 10.0);                                    /* :57 */
+  fbo_nes_params q = *p;
+  q.threshold = init + delta;                                          /* :59 */
+  q.attack_type = FBO_UNTARGETED;                                      /* :73-74 */
+  for (int64_t n = 0; n < N; ++n) {
+    adver[n] = audio[n];
+    lower[n] = clipd(audio[n] - p->epsilon, -1.0, 1.0);
+    upper[n] = clipd(audio[n] + p->epsilon, -1.0, 1.0);
+  }
+  int n_iters = 0, n_outer = 0, done = 0;
+  while (!rc && !done) {                                               /* :76 */
+    double lr = p->max_lr;
+    int n_ls = 0;
+    for (;;) {                                                         /* :85 */
+      rc = fn(ctx, adver, N, 1, sc);                                   /* make_decisions :89 */
+      if (rc) break;
+      double s = sc[0];
+      for (int j = 1; j < S; ++j) if (sc[j] > s) s = sc[j];
+      if (s >= model_threshold) { *score_out = s; done = 1; break; }   /* decision != -1 :96-103 */
+      if (s >= q.threshold) break;                                     /* :105-109 */
+      if (n_iters >= max_total_iters) { rc = -2; break; }
+      double loss, al;
+      rc = fbo_get_grad(&q, fn, ctx, adver, N,
+                        noise_all ? noise_all + (size_t)n_iters * N * half : NULL, seed,
+                        (uint32_t)n_iters, stream, &loss, g, &al, sc);
+      if (rc) break;
+      for (int64_t n = 0; n < N; ++n)
+        grad[n] = p->momentum * grad[n] + (1.0 - p->momentum) * g[n];  /* :114 */
+      last_ls[n_ls++] = loss;
+      if (n_ls > p->plateau_length) { memmove(last_ls, last_ls + 1, sizeof(double) * p->plateau_length); n_ls = p->plateau_length; }
+      if (last_ls[n_ls - 1] > last_ls[0] && n_ls == p->plateau_length) {
+        if (lr > p->min_lr) { double l2 = lr / p->plateau_drop; lr = l2 > p->min_lr ? l2 : p->min_lr; }
+        n_ls = 0;
+      }
+      for (int64_t n = 0; n < N; ++n) {
+        adver[n] -= lr * sgn(grad[n]);
+        adver[n] = clipd(adver[n], lower[n], upper[n]);
+      }
+      ++n_iters;
+    }
+    if (!done && !rc) { q.threshold += delta; ++n_outer; }             /* :135-137 */
+  }
+  if (n_iters_out) *n_iters_out = n_iters;
+  if (n_outer_out) *n_outer_out = n_outer;
+  if (thr_final) *thr_final = q.threshold;
+  if (adver_out) memcpy(adver_out, adver, sizeof(double) * N);
+  free(sc); free(adver); free(grad); free(g); free(lower); free(upper); free(last_ls);
+  return rc;
+}
+
+/* ------------------------------------------- built-in GMM system scorer */
+int fbo_gmm_system_score(void *ctx, const double *audios, int64_t N, int B, double *scores) {
+  fbo_gmm_system *g = (fbo_gmm_system *)ctx;
+  int16_t *wav = (int16_t *)malloc(sizeof(int16_t) * (size_t)N * B);
+  int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (B + 1));
+  fbo_quantize(audios, N * B, 16, wav);
+  for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+  double *raw = (double *)malloc(sizeof(double) * (size_t)B * g->M);
+  int rc = fbo_gmm_score_batch(&g->cfg, wav, off, B, g->gconsts, g->means_invvars, g->inv_vars,
+                               g->M, g->C, g->D, raw, NULL, g->nthreads);
+  g->scored_utts += B;
+  if (rc == 0) {
+    if (g->task == FBO_TASK_CSI) {
+      for (int b = 0; b < B; ++b)
+        for (int m = 0; m < g->M; ++m)
+          scores[(size_t)b * g->M + m] = (raw[(size_t)b * g->M + m] - g->z_mean[m]) / g->z_std[m];
+    } else {
+      int S = g->M - 1;
+      for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s)
+          scores[(size_t)b * S + s] = raw[(size_t)b * g->M + 1 + s] - raw[(size_t)b * g->M];
+    }
+  }
+  free(wav); free(off); free(raw);
+  return rc;
+}

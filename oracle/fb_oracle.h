@@ -1,0 +1,180 @@
+/*
+ * fb_oracle.h -- CPU restatement ("oracle") of the FAKEBOB NES hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.  The
+ * product (fakebob_amd/) never imports, links or calls it.
+ *
+ * PARITY STATUS
+ *   - NES engine (loss_fn, get_grad, attack, estimate_threshold), int16
+ *     quantisation, score post-processing, decision rules: PINNED against
+ *     golden vectors captured by importing the reference's own Python
+ *     (tests/golden/make_golden.py -> tests/golden/ *.npz).
+ *   - MFCC / VAD / deltas / CMVN / GMM log-likelihood / i-vector / PLDA:
+ *     "PARITY UNPINNED".  That arithmetic lives in Kaldi (un-vendored,
+ *     un-pinned `git clone` of master, reference docker/Dockerfile:24), which
+ *     is absent from /root/reference.  The functions below restate Kaldi's
+ *     published algorithms following the reference's
+ *     exact command lines (gmm_ubm_kaldiHelper.py:131-234,
+ *     ivector_PLDA_kaldiHelper.py:156-280) and are validated against
+ *     independent numpy/scipy formulas in tests/.
+ *
+ * Precision policy (differs from Kaldi only by being >= as precise):
+ *   features are float32 at Kaldi's storage points (MFCC matrix, add-deltas
+ *   output, apply-cmvn-sliding output, GMM parameters); everything between
+ *   two storage points is computed in float64.
+ */
+#ifndef FB_ORACLE_H
+#define FB_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Front-end options == Kaldi conf/mfcc.conf + conf/vad.conf + delta_opts +
+ * the apply-cmvn-sliding flags hard-coded at gmm_ubm_kaldiHelper.py:196. */
+typedef struct {
+  double sample_freq;       /* 16000 */
+  int frame_length;         /* samples: 400 (25 ms)  */
+  int frame_shift;          /* samples: 160 (10 ms)  */
+  int padded_length;        /* 512 (round-to-power-of-two) */
+  int num_mel_bins;         /* 30 */
+  int num_ceps;             /* 24 */
+  double low_freq;          /* 20 */
+  double high_freq;         /* 7600 (<=0: offset from nyquist) */
+  double preemph;           /* 0.97 */
+  double cepstral_lifter;   /* 22 */
+  int snip_edges;           /* 0 */
+  int remove_dc;            /* 1 */
+  int use_energy;           /* 1 */
+  int raw_energy;           /* 1 */
+  double energy_floor;      /* 0 */
+  double vad_energy_threshold;     /* 5.5 */
+  double vad_energy_mean_scale;    /* 0.5 */
+  double vad_proportion_threshold; /* 0.12 */
+  int vad_frames_context;          /* 2 */
+  int delta_window;         /* 3 */
+  int delta_order;          /* 2 */
+  int cmn_window;           /* 300, center=true, norm-vars=false */
+} fbo_frontend_cfg;
+
+void fbo_default_cfg(fbo_frontend_cfg *cfg);
+
+/* ---- RNG contract (shared by oracle and product, implemented twice) ---- */
+void fbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* z[j*N + n], j in [0,half): standard normals (float32) for NES iteration
+ * `iter`, stream `stream`. */
+void fbo_noise(uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half, float *z);
+
+/* ---- K1: float64 -> int16, numpy astype semantics (gmm_ubm_OSI.py:83-85) */
+void fbo_quantize(const double *x, int64_t n, int bits_per_sample, int16_t *q);
+
+/* ---- K2..K6 front-end ---- */
+int fbo_num_frames(const fbo_frontend_cfg *cfg, int64_t n_samples);
+int fbo_feat_dim(const fbo_frontend_cfg *cfg); /* num_ceps*(delta_order+1) */
+/* MFCC: out[T*num_ceps] float32.  returns T. */
+int fbo_mfcc(const fbo_frontend_cfg *cfg, const int16_t *wav, int64_t n, float *out);
+/* VAD on C0: voiced[T] in {0,1} */
+void fbo_vad(const fbo_frontend_cfg *cfg, const float *mfcc, int T, uint8_t *voiced);
+/* add-deltas: out[T*num_ceps*(order+1)] */
+void fbo_deltas(const fbo_frontend_cfg *cfg, const float *mfcc, int T, float *out);
+/* apply-cmvn-sliding (center, mean only), in place on [T*dim] */
+void fbo_cmvn_sliding(const fbo_frontend_cfg *cfg, float *feats, int T, int dim);
+/* whole chain: wav -> voiced, CMVN'd feature rows (compacted).  feats must hold
+ * T*dim floats; returns number of voiced frames Tv (rows written); *T_out = T */
+int fbo_frontend(const fbo_frontend_cfg *cfg, const int16_t *wav, int64_t n,
+                 float *feats, int *T_out);
+
+/* ---- K7 diagonal GMM (Kaldi DiagGmm internal form, float32 params) ---- */
+/* per-frame log-likelihood for one model; returns sum over frames (double);
+ * ll_out (optional) gets per-frame float32 values. */
+double fbo_diag_gmm_loglikes(const float *gconsts, const float *means_invvars,
+                             const float *inv_vars, int C, int D,
+                             const float *feats, int Tv, float *ll_out);
+
+/* gmm_ubm_kaldiHelper.score: raw[B*M] = average frame log-likelihood of
+ * utterance b under model m.  wav = concatenated int16, off[B+1] offsets.
+ * models: gconsts[M*C], means_invvars[M*C*D], inv_vars[M*C*D].
+ * returns 0, or -(b+1) if utterance b has no voiced frames. tv_out[B] optional.
+ * nthreads>1 uses OpenMP over utterances (CPU-baseline timing only). */
+int fbo_gmm_score_batch(const fbo_frontend_cfg *cfg, const int16_t *wav,
+                        const int64_t *off, int B, const float *gconsts,
+                        const float *means_invvars, const float *inv_vars,
+                        int M, int C, int D, double *raw, int *tv_out, int nthreads);
+
+/* ---- NES engine (FAKEBOB.py) ---- */
+enum { FBO_TASK_OSI = 0, FBO_TASK_CSI = 1, FBO_TASK_SV = 2 };
+enum { FBO_UNTARGETED = 0, FBO_TARGETED = 1 };
+
+/* FAKEBOB.py:248-299.  score[B*S] (S=1 for SV) -> loss[B] */
+void fbo_loss(int task, int attack_type, const double *score, int B, int S,
+              double threshold, double adver_thresh, int target, int true_label,
+              double *loss);
+
+/* numpy pairwise summation (np.add.reduce over a contiguous float64 run) */
+double fbo_np_sum(const double *a, int64_t n);
+
+/* model.score callback: audios column-major [B][N] float64 -> scores[B*S].
+ * return 0 ok. */
+typedef int (*fbo_score_fn)(void *ctx, const double *audios, int64_t N, int B, double *scores);
+
+typedef struct {
+  int task, attack_type;
+  double adver_thresh, epsilon;
+  int max_iter;
+  double max_lr, min_lr;
+  int samples_per_draw;
+  double sigma, momentum;
+  int plateau_length;
+  double plateau_drop;
+  double threshold;     /* attack(): threshold arg */
+  int target, true_label;
+  int n_spk;            /* S (1 for SV) */
+} fbo_nes_params;
+
+/* FAKEBOB.py:223-246 with explicit noise_pos[N*half] (row-major (N,half) like
+ * numpy) or, when noise_pos==NULL, the Philox contract (seed, iter, stream).
+ * grad[N], score0[S]. */
+int fbo_get_grad(const fbo_nes_params *p, fbo_score_fn fn, void *ctx,
+                 const double *audio, int64_t N, const double *noise_pos,
+                 uint64_t seed, uint32_t iter, uint32_t stream,
+                 double *final_loss, double *grad, double *adver_loss, double *score0);
+
+/* FAKEBOB.py:139-221.  noise_all: NULL (Philox) or [max_iter][N*half].
+ * trace[it*(3+S)] = distance, adver_loss, lr_after, score0[S]; n_trace out.
+ * adv_i16[N]; returns success flag (+1/-1) or 0 on error. */
+int fbo_attack(const fbo_nes_params *p, fbo_score_fn fn, void *ctx,
+               const double *audio, int64_t N, const double *noise_all,
+               uint64_t seed, uint32_t stream, int16_t *adv_i16,
+               double *adver_f64, double *trace, int *n_trace);
+
+/* FAKEBOB.py:39-137.  model_threshold is the *system's* threshold used by
+ * model.make_decisions (gmm_ubm_OSI.py:101-106, gmm_ubm_SV.py:86-90).
+ * noise_all: NULL (Philox, iteration index = running get_grad count) or
+ * [max_total_iters][N*half].  Returns 0 ok, 1 CSI (nothing to do), <0 error /
+ * max_total_iters exhausted.  thr_final = FakeBob.threshold at return. */
+int fbo_estimate_threshold(const fbo_nes_params *p, double model_threshold, fbo_score_fn fn,
+                           void *ctx, const double *audio, int64_t N, const double *noise_all,
+                           int max_total_iters, uint64_t seed, uint32_t stream,
+                           double *score_out, int *n_iters_out, int *n_outer_out,
+                           double *thr_final, double *adver_out);
+
+/* built-in scorer contexts for fbo_score_fn: GMM-UBM OSI/SV/CSI wrapper
+ * (gmm_ubm_OSI.py:83-91, gmm_ubm_CSI.py:93, gmm_ubm_SV.py:77) */
+typedef struct {
+  fbo_frontend_cfg cfg;
+  int task;               /* OSI/SV: model 0 is the UBM; CSI: z-norm */
+  int M, C, D;
+  const float *gconsts, *means_invvars, *inv_vars;
+  const double *z_mean, *z_std; /* CSI */
+  int nthreads;
+  int64_t scored_utts;    /* counter */
+} fbo_gmm_system;
+int fbo_gmm_system_score(void *ctx, const double *audios, int64_t N, int B, double *scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
