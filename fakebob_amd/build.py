@@ -54,7 +54,8 @@ def build(force=False, verbose=False):
 
     def comp(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("FB_EXTRA_HIPCC_FLAGS", "").split()
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return src, obj, r.returncode, r.stdout
 

@@ -85,7 +85,7 @@ __device__ __forceinline__ void fb_box_muller(uint32_t r0, uint32_t r1, float &z
   float a = __fmul_rn((float)fr, 9.36227702e-08f);
   float s, c;
   fb_sincos_q(a, s, c);
-  float rr = __fsqrt_rn(__fmul_rn(-2.0f, fb_ln_u(u1)));
+  float rr = sqrtf(__fmul_rn(-2.0f, fb_ln_u(u1)));  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approx
   float cs, sn;
   if (q == 0) { cs = c; sn = s; }
   else if (q == 1) { cs = -s; sn = c; }

@@ -117,33 +117,69 @@ void fb_launch_noise(hipStream_t s, uint64_t seed, uint32_t iter, uint32_t strea
 // --------------------------------------------------------------------- loss
 // numpy pairwise summation over elem(i), i in [lo, lo+n)  (see oracle/fb_oracle.c
 // fbo_np_sum; verified bit-for-bit against numpy 2.2.6)
-template <typename F>
-__device__ double fb_np_sum_block(F elem, int lo, int n) {  // n <= 128
+struct D1 {
+  double v;
+  __device__ __forceinline__ static D1 zero() { return D1{0.0}; }
+  __device__ __forceinline__ D1 operator+(const D1 &o) const { return D1{__dadd_rn(v, o.v)}; }
+};
+struct D4 {
+  double v[4];
+  __device__ __forceinline__ static D4 zero() { return D4{{0.0, 0.0, 0.0, 0.0}}; }
+  __device__ __forceinline__ D4 operator+(const D4 &o) const {
+    return D4{{__dadd_rn(v[0], o.v[0]), __dadd_rn(v[1], o.v[1]), __dadd_rn(v[2], o.v[2]), __dadd_rn(v[3], o.v[3])}};
+  }
+};
+template <typename T, typename F>
+__device__ __forceinline__ T fb_np_sum_block(F elem, int lo, int n) {  // n <= 128
   if (n < 8) {
-    double r = 0.0;
-    for (int i = 0; i < n; ++i) r = __dadd_rn(r, elem(lo + i));
+    T r = T::zero();
+    for (int i = 0; i < n; ++i) r = r + elem(lo + i);
     return r;
   }
-  double r[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = elem(lo + j);
+  T r0 = elem(lo + 0), r1 = elem(lo + 1), r2 = elem(lo + 2), r3 = elem(lo + 3);
+  T r4 = elem(lo + 4), r5 = elem(lo + 5), r6 = elem(lo + 6), r7 = elem(lo + 7);
   int i = 8;
   for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], elem(lo + i + j));
+    r0 = r0 + elem(lo + i + 0); r1 = r1 + elem(lo + i + 1); r2 = r2 + elem(lo + i + 2);
+    r3 = r3 + elem(lo + i + 3); r4 = r4 + elem(lo + i + 4); r5 = r5 + elem(lo + i + 5);
+    r6 = r6 + elem(lo + i + 6); r7 = r7 + elem(lo + i + 7);
   }
-  double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
-                         __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-  for (; i < n; ++i) res = __dadd_rn(res, elem(lo + i));
+  T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res = res + elem(lo + i);
   return res;
 }
-template <typename F>
-__device__ double fb_np_sum(F elem, int lo, int n) {
-  // explicit stack replaces numpy's recursion: sum(lo,n) = sum(lo,n2) + sum(lo+n2, n-n2)
-  if (n <= 128) return fb_np_sum_block(elem, lo, n);
-  int n2 = n / 2;
-  n2 -= n2 % 8;
-  return __dadd_rn(fb_np_sum(elem, lo, n2), fb_np_sum(elem, lo + n2, n - n2));
+// numpy recurses sum(lo,n) = sum(lo,n2) + sum(lo+n2,n-n2), n2 = n/2 - (n/2)%8, above 128
+// elements; an explicit post-order stack replaces the recursion (no device call stack).
+template <typename T, typename F>
+__device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
+  if (n <= 128) return fb_np_sum_block<T>(elem, lo, n);
+  int lo_s[14], n_s[14], st_s[14];
+  T left_s[14];
+  int sp = 0;
+  T ret = T::zero();
+  lo_s[0] = lo; n_s[0] = n; st_s[0] = 0;
+  while (sp >= 0) {
+    const int cn = n_s[sp], cl = lo_s[sp];
+    if (cn <= 128) {
+      ret = fb_np_sum_block<T>(elem, cl, cn);
+      --sp;
+    } else {
+      int n2 = cn / 2;
+      n2 -= n2 % 8;
+      if (st_s[sp] == 0) {
+        st_s[sp] = 1;
+        ++sp; lo_s[sp] = cl; n_s[sp] = n2; st_s[sp] = 0;
+      } else if (st_s[sp] == 1) {
+        left_s[sp] = ret;
+        st_s[sp] = 2;
+        ++sp; lo_s[sp] = cl + n2; n_s[sp] = cn - n2; st_s[sp] = 0;
+      } else {
+        ret = left_s[sp] + ret;
+        --sp;
+      }
+    }
+  }
+  return ret;
 }
 
 __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, const int *__restrict__ tv,
@@ -194,8 +230,8 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
   if (threadIdx.x == 0) {
     const int spd = B - 1;
     out->adver_loss = loss[0];
-    auto el = [&](int i) { return loss[1 + i]; };
-    out->final_loss = spd > 0 ? __ddiv_rn(fb_np_sum(el, 0, spd), (double)spd) : 0.0;  // np.mean :243
+    auto el = [&](int i) { return D1{loss[1 + i]}; };
+    out->final_loss = spd > 0 ? __ddiv_rn(fb_np_sum<D1>(el, 0, spd).v, (double)spd) : 0.0;  // np.mean :243
     for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
     double d = 0.0;
     for (int i = 0; i < n_dist_part; ++i) d = dist_part[i] > d ? dist_part[i] : d;
@@ -212,6 +248,13 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
                      threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out);
 }
 
+// Kept out of line on purpose: with the 8+ fully inlined copies that the pairwise-sum unrolling
+// creates, hipcc (ROCm 7.2, -O1 and -O3) corrupts the second Box-Muller output (z1) of some
+// copies -- caught by the philox-vs-explicit-noise parity test.  One shared copy is correct.
+__device__ __noinline__ void fb_noise4_noinline(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t n4,
+                                                uint32_t j, float z[4]) {
+  fb_noise4(seed, iter, stream, n4, j, z);
+}
 // ------------------------------------------------------------- grad + update
 // estimate_grad = np.mean(loss.flatten() * noise, axis=1) / sigma   (FAKEBOB.py:244)
 // then grad = m*pre + (1-m)*grad (:193), adver -= lr*sign(grad), clip (:202-203).
@@ -226,38 +269,48 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
   const int spd = 2 * half;
   for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
   __syncthreads();
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const uint32_t n4 = (uint32_t)(n >> 2);
-  const int k = (int)(n & 3);
-  auto el = [&](int i) -> double {
+  const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 samples per thread
+  const int64_t n0 = n4 * 4;
+  if (n0 >= N) return;
+  const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
+  auto el = [&](int i) -> D4 {
     const int j = i < half ? i : i - half;
-    double z;
+    D4 z;
     if (noise_pos) {
-      z = noise_pos[n * half + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z.v[k] = k < cnt ? noise_pos[(n0 + k) * half + j] : 0.0;
     } else {
       float zf[4];
-      fb_noise4(seed, iter, stream, n4, (uint32_t)j, zf);
-      z = (double)(k == 0 ? zf[0] : k == 1 ? zf[1] : k == 2 ? zf[2] : zf[3]);
+      fb_noise4_noinline(seed, iter, stream, (uint32_t)n4, (uint32_t)j, zf);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z.v[k] = (double)zf[k];
     }
-    if (i >= half) z = -z;
-    return __dmul_rn(s_loss[i], z);
+    const double l = s_loss[i];
+    D4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = __dmul_rn(l, i >= half ? -z.v[k] : z.v[k]);
+    return r;
   };
-  double g = 0.0;
-  if (spd > 0) g = __ddiv_rn(__ddiv_rn(fb_np_sum(el, 0, spd), (double)spd), sigma);
-  if (grad_out) grad_out[n] = g;
-  if (do_update) {
-    double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
-    grad_m[n] = gm;
-    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
-    double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
-    double au = audio[n];
-    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
-    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
-    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
-    a = a < lo ? lo : a;
-    a = a > hi ? hi : a;
-    adver[n] = a;
+  D4 sum = D4::zero();
+  if (spd > 0) sum = fb_np_sum<D4>(el, 0, spd);
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t n = n0 + k;
+    double g = 0.0;
+    if (spd > 0) g = __ddiv_rn(__ddiv_rn(sum.v[k], (double)spd), sigma);
+    if (grad_out) grad_out[n] = g;
+    if (do_update) {
+      double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
+      grad_m[n] = gm;
+      double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
+      double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
+      double au = audio[n];
+      double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
+      lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
+      hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
+      a = a < lo ? lo : a;
+      a = a > hi ? hi : a;
+      adver[n] = a;
+    }
   }
 }
 
@@ -266,7 +319,7 @@ void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int hal
                            double *grad_out, int do_update, double momentum, double one_minus_m,
                            double lr, double epsilon, const double *audio, double *grad_m,
                            double *adver) {
-  int blocks = (int)((N + 255) / 256);
+  int blocks = (int)(((N + 3) / 4 + 255) / 256);
   size_t shm = sizeof(double) * (size_t)(2 * half > 0 ? 2 * half : 1);
   hipLaunchKernelGGL(k_grad_update, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, seed, iter,
                      stream, noise_pos, grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio,
