@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""bench.py -- NES iterations/s of the FAKEBOB hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): GMM-UBM OSI targeted attack, 5 enrolled speakers + UBM
+(C=2048 diagonal Gaussians, D=72), samples_per_draw=50 -> 51 utterances of 3 s @ 16 kHz scored
+per NES iteration.  One "step" = one full NES iteration exactly as FakeBob.attack runs it
+(FAKEBOB.py:168-214): Philox noise -> perturb -> int16 -> MFCC/VAD/deltas/CMVN -> GMM
+log-likelihoods of all 6 models -> scores -> loss -> gradient estimate -> momentum sign step +
+clip, with the early-stop *test* evaluated but not taken so that exactly K steps are timed.
+Synthetic audio and seeded synthetic models: no dataset / Kaldi models exist
+offline.
+
+Multi-GPU: utterances are independent (attackMain.py:324-409), so each rank attacks its own
+utterance ("weak" scaling, no data-path collective); RCCL is used only for the barrier, the
+max-over-ranks time and the final counter reduction.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+S_SPK, C_GAUSS, D_FEAT, SPD, N_SAMPLES = 5, 2048, 72, 50, 48000
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+README_GMM_ITS = 0.20         # reference README.md:113 (~5 s / iteration, unspecified CPU)
+
+
+def cpu_baseline(audio, models, params_kw):
+    """Times the CPU oracle (the build's C restatement of the identical computation; Kaldi itself
+    cannot be installed offline) on one full NES iteration of the same workload, 1 thread --
+    the reference's default n_jobs=1 (attackMain.sh:34)."""
+    from oracle import oracle as O
+    from fakebob_amd.models import stack_models
+    gc, miv, iv = stack_models(models)
+    ctx = O.GmmSystemCtx(O.default_cfg(), "OSI", gc, miv, iv, nthreads=1)
+    po = O.nes_params("OSI", "targeted", ctx.S, **params_kw)
+    t0 = time.perf_counter()
+    O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=0, stream=0)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "NES iterations/s", "cores": 1, "kind": "port",
+            "sample": "1 full NES iteration (51 utterances x 3 s, 6 models) of the same workload, "
+                      "CPU oracle single thread, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch  # device sync + torch.distributed (RCCL); imported before the HIP library
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from fakebob_amd.engine import Engine, nes_params
+    from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
+
+    ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
+    models = [ubm] + spk
+    eng = Engine(local_rank)
+    eng.load_gmm(models)
+    eng.set_system("OSI")
+    audio = synthetic_audio(rank, N_SAMPLES)  # utterance `rank`
+    kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_lr=0.001, min_lr=1e-6, momentum=0.9,
+              plateau_length=5, plateau_drop=2.0, adver_thresh=0.0, max_iter=1000, target=0, threshold=0.2277)
+    p = nes_params("OSI", "targeted", seed=42, stream=rank, **kw)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        eng.bench_nes(p, audio, 0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ms_dev, ms_gmm, rows = eng.bench_nes(p, audio, 0, args.steps, time_gmm=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # final counter reduction (mirrors success_cnt / total_cnt, attackMain.py:312,411)
+        cnt = torch.tensor([args.steps, args.steps * (SPD + 1), rows], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    its = world * args.steps / dt
+    out = None
+    if rank == 0:
+        gmm_ms_avg = ms_gmm / args.steps
+        flops_launch = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * rows  # (S+1)*C*4D*F_voiced
+        achieved = flops_launch / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
+        out = {
+            "metric": "NES iterations/sec (and scored-utts/sec) at samples_per_draw=50, 3 s@16 kHz",
+            "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (MFMA f32 GMM; f64 front-end/NES)",
+            "data": "synthetic",
+            "scored_utts_per_s": its * (SPD + 1),
+            "vs_readme_nominal": its / README_GMM_ITS,
+            "config": {"workload": "GMM-UBM OSI targeted, 5 speakers+UBM, C=2048, D=72, spd=50, "
+                                   "N=48000 (3 s @ 16 kHz), 1 utterance per GPU",
+                       "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
+                       "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
+            "roofline": {"kernel": "k_gmm<36> (diag-GMM log-likelihood + logsumexp, f32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": gmm_ms_avg,
+                         "algorithmic_flops_per_launch": flops_launch,
+                         "gmm_share_of_step": ms_gmm / ms_dev if ms_dev > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ckw = dict(kw)
+            out["cpu_baseline"] = cpu_baseline(audio, models, ckw)
+            out["gpu_over_cpu_port"] = its / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

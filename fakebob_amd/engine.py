@@ -191,10 +191,13 @@ class Engine(object):
         N.check(self._L.fb_bench_gmm_kernel(self._h, C.c_int(reps), C.byref(ms), C.byref(rows)))
         return ms.value, rows.value
 
-    def bench_nes(self, params, audio, warmup, iters):
+    def bench_nes(self, params, audio, warmup, iters, time_gmm=False):
+        """Runs warmup+iters NES iterations (identical work to attack(), early stop disabled).
+        Returns (ms over the timed iters [HIP events], summed GMM-kernel ms [HIP events around
+        each launch on the engine stream], voiced rows of the last batch)."""
         audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
         ms, msg, rows = C.c_double(), C.c_double(), C.c_int64()
         N.check(self._L.fb_bench_nes(self._h, C.byref(params), N.ptr(audio), C.c_int64(audio.size),
-                                     C.c_int(warmup), C.c_int(iters), C.c_int(0), C.byref(ms), C.byref(msg),
-                                     C.byref(rows)))
+                                     C.c_int(warmup), C.c_int(iters), C.c_int(1 if time_gmm else 0),
+                                     C.byref(ms), C.byref(msg), C.byref(rows)))
         return ms.value, msg.value, rows.value
