@@ -1,0 +1,238 @@
+"""Validates the oracle's Kaldi-side restatement (parity unpinned at the Kaldi boundary: Kaldi is
+absent) against INDEPENDENT math available here: numpy.fft, scipy logsumexp, closed forms.  Also
+pins the RNG contract (Philox4x32-10 known-answer vectors) and the int16 cast against numpy."""
+import numpy as np
+import pytest
+from scipy.special import logsumexp
+
+from fakebob_amd.models import DiagGmm, synthetic_audio, synthetic_ubm_moments
+
+FLT_EPS = float(np.finfo(np.float32).eps)
+
+
+# ------------------------------------------------------------------ RNG contract
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors (philox4x32-10)
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_noise_is_standard_normal_and_counter_based(oracle):
+    from scipy import stats
+    z = oracle.noise(42, 0, 0, 200000, 2)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    assert abs((z ** 4).mean() - 3.0) < 0.05
+    assert stats.kstest(z.ravel()[:100000].astype(np.float64), "norm").pvalue > 1e-3
+    # counter-based: any sub-range / pair can be regenerated independently
+    z2 = oracle.noise(42, 0, 0, 1000, 2)
+    assert np.array_equal(z[:, :1000], z2)
+    assert not np.array_equal(oracle.noise(42, 1, 0, 1000, 2), z2)
+    assert not np.array_equal(oracle.noise(42, 0, 1, 1000, 2), z2)
+    assert not np.array_equal(oracle.noise(43, 0, 0, 1000, 2), z2)
+
+
+def test_quantize_matches_numpy_astype(oracle):
+    x = np.array([0.5, -0.5, 0.99999, 1.0, -1.0, 1.00004, 2.7e-5, -2.7e-5, 0.0, 1.5, -1.5, 3.0000305,
+                  0.999984741, -0.99998, 1.0 - 2 ** -16, 123.456, -7.25])
+    with np.errstate(invalid="ignore"):
+        want = (x * 2 ** 15).astype(np.int16)
+    assert np.array_equal(oracle.quantize(x), want)
+    assert list(oracle.quantize(x[:7])) == [16384, -16384, 32767, -32768, -32768, -32767, 0]
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=100000) * 0.7
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(oracle.quantize(y), (y * 2 ** 15).astype(np.int16))
+        assert np.array_equal(oracle.quantize(y, bits=8), (y * 2 ** 7).astype(np.int16))
+
+
+# ------------------------------------------------------- independent numpy front-end
+def np_mfcc(wav, L=400, shift=160, P=512, nb=30, nc=24, lo=20.0, hi=7600.0, fs=16000.0, pre=0.97, lift=22.0):
+    wav = wav.astype(np.float64)
+    n = wav.size
+    T = (n + shift // 2) // shift
+    idx = (np.arange(T)[:, None] * shift + shift // 2 - L // 2) + np.arange(L)[None, :]
+    while ((idx < 0) | (idx >= n)).any():          # Kaldi reflects repeatedly for very short waves
+        idx = np.where(idx < 0, -idx - 1, idx)
+        idx = np.where(idx >= n, 2 * n - 1 - idx, idx)
+    fr = wav[idx]
+    fr = fr - fr.mean(axis=1, keepdims=True)
+    log_e = np.log(np.maximum((fr ** 2).sum(axis=1), FLT_EPS))
+    fr = np.concatenate([fr[:, :1] * (1 - pre), fr[:, 1:] - pre * fr[:, :-1]], axis=1)
+    win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(L) / (L - 1))) ** 0.85
+    fr = fr * win.astype(np.float32).astype(np.float64)
+    spec = np.abs(np.fft.rfft(fr, n=P, axis=1)) ** 2
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    edges = np.linspace(mel(lo), mel(hi), nb + 2)
+    fmel = mel(np.arange(P // 2) * fs / P)
+    W = np.zeros((nb, P // 2 + 1))
+    for b in range(nb):
+        l, c, r = edges[b], edges[b + 1], edges[b + 2]
+        up = (fmel - l) / (c - l)
+        dn = (r - fmel) / (r - c)
+        w = np.where(fmel <= c, up, dn)
+        W[b, :P // 2] = np.where((fmel > l) & (fmel < r), w, 0.0).astype(np.float32)
+    lm = np.log(np.maximum(spec @ W.T, FLT_EPS))
+    k = np.arange(nc)[:, None]
+    nn = np.arange(nb)[None, :]
+    dct = np.sqrt(2.0 / nb) * np.cos(np.pi / nb * (nn + 0.5) * k)
+    dct[0] = np.sqrt(1.0 / nb)
+    cep = lm @ dct.astype(np.float32).astype(np.float64).T
+    cep = cep * (1.0 + 0.5 * lift * np.sin(np.pi * np.arange(nc) / lift)).astype(np.float32)
+    cep[:, 0] = log_e
+    return cep
+
+
+def _wavs():
+    rng = np.random.default_rng(3)
+    return [(synthetic_audio(0, 16000) * 32768).astype(np.int16),
+            (rng.normal(size=8000) * 3000).astype(np.int16),
+            rng.integers(-32768, 32767, size=4321).astype(np.int16),
+            np.zeros(1600, np.int16),
+            (np.sin(np.arange(3000) * 0.05) * 20000).astype(np.int16)]
+
+
+def test_mfcc_vs_numpy_fft(oracle):
+    cfg = oracle.default_cfg()
+    for w in _wavs():
+        got = oracle.mfcc(cfg, w).astype(np.float64)
+        want = np_mfcc(w)
+        assert got.shape == want.shape
+        assert oracle.num_frames(cfg, w.size) == want.shape[0]
+        assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max())
+
+
+def test_num_frames_and_edges(oracle):
+    cfg = oracle.default_cfg()
+    assert oracle.num_frames(cfg, 48000) == 300
+    assert oracle.num_frames(cfg, 79) == 0 and oracle.num_frames(cfg, 80) == 1
+    cfg2 = oracle.default_cfg(snip_edges=1)
+    assert oracle.num_frames(cfg2, 399) == 0 and oracle.num_frames(cfg2, 400) == 1
+    assert oracle.num_frames(cfg2, 48000) == 298
+    # a 1-frame utterance is pure reflection padding
+    w = (np.arange(100) * 50).astype(np.int16)
+    assert np.abs(oracle.mfcc(cfg, w).astype(np.float64) - np_mfcc(w)).max() < 1e-4
+
+
+def test_vad_vs_numpy(oracle):
+    cfg = oracle.default_cfg()
+    rng = np.random.default_rng(1)
+    for T in [1, 2, 5, 300, 777]:
+        mf = (rng.normal(size=(T, 24)) * 3 + 10).astype(np.float32)
+        c0 = mf[:, 0]
+        thr = np.float32(5.5 + 0.5 * c0.astype(np.float64).sum() / T)
+        want = np.zeros(T, np.uint8)
+        for t in range(T):
+            lo, hi = max(0, t - 2), min(T, t + 3)
+            num = int((c0[lo:hi] > thr).sum())
+            want[t] = 1 if np.float32(num) >= np.float32(hi - lo) * np.float32(0.12) else 0
+        assert np.array_equal(oracle.vad(cfg, mf), want)
+
+
+def test_deltas_vs_closed_form(oracle):
+    cfg = oracle.default_cfg()
+    rng = np.random.default_rng(2)
+    for T in [1, 4, 50]:
+        mf = rng.normal(size=(T, 24)).astype(np.float32)
+        got = oracle.deltas(cfg, mf).astype(np.float64)
+        k1 = np.arange(-3, 4) / 28.0
+        k2 = np.convolve(k1, k1)
+        x = mf.astype(np.float64)
+
+        def filt(kern):
+            off = (len(kern) - 1) // 2
+            out = np.zeros_like(x)
+            for t in range(T):
+                for j in range(-off, off + 1):
+                    out[t] += kern[j + off] * x[min(max(t + j, 0), T - 1)]
+            return out
+        want = np.concatenate([x, filt(k1), filt(k2)], axis=1)
+        assert got.shape == (T, 72)
+        assert np.abs(got - want).max() <= 2e-6
+    # a linear ramp has constant first delta = slope and zero second delta away from the edges
+    ramp = (np.arange(40)[:, None] * np.ones((1, 24)) * 0.5).astype(np.float32)
+    d = oracle.deltas(cfg, ramp)
+    assert np.allclose(d[8:32, 24:48], 0.5, atol=1e-6) and np.allclose(d[8:32, 48:], 0.0, atol=1e-6)
+
+
+def test_cmvn_sliding_vs_numpy(oracle):
+    cfg = oracle.default_cfg()
+    rng = np.random.default_rng(4)
+    for T in [1, 7, 300, 301, 450, 1000]:
+        f = (rng.normal(size=(T, 72)) * 4 + 1).astype(np.float32)
+        got = oracle.cmvn_sliding(cfg, f).astype(np.float64)
+        want = np.empty((T, 72))
+        for t in range(T):
+            wb, we = t - 150, t - 150 + 300
+            if wb < 0:
+                we -= wb
+                wb = 0
+            if we > T:
+                wb -= we - T
+                we = T
+                wb = max(wb, 0)
+            want[t] = f[t].astype(np.float64) - f[wb:we].astype(np.float64).mean(axis=0)
+        assert np.abs(got - want).max() <= 2e-6
+    f = (rng.normal(size=(200, 72))).astype(np.float32)      # T <= window: whole-utterance mean
+    assert np.abs(oracle.cmvn_sliding(cfg, f).astype(np.float64).mean(axis=0)).max() < 1e-6
+
+
+def test_frontend_chain_order(oracle):
+    """add-deltas | apply-cmvn-sliding | select-voiced-frames with the VAD taken from raw C0
+    (gmm_ubm_kaldiHelper.py:151-169,195-198): CMVN statistics include the unvoiced frames."""
+    cfg = oracle.default_cfg()
+    w = (synthetic_audio(1, 24000) * 32768).astype(np.int16)
+    feats, T = oracle.frontend(cfg, w)
+    mf = oracle.mfcc(cfg, w)
+    v = oracle.vad(cfg, mf).astype(bool)
+    want = oracle.cmvn_sliding(cfg, oracle.deltas(cfg, mf))[v]
+    assert T == mf.shape[0] and 0 < v.sum() < T
+    assert np.array_equal(feats, want)
+
+
+# ----------------------------------------------------------------------- GMM
+def test_diag_gmm_vs_scipy(oracle):
+    w, mu, var = synthetic_ubm_moments(64, 72, seed=9)
+    g = DiagGmm.from_moments(w, mu, var)
+    rng = np.random.default_rng(6)
+    x = (rng.normal(size=(37, 72)) * 2).astype(np.float32)
+    ll, tot = oracle.diag_gmm_loglikes(g.gconsts, g.means_invvars, g.inv_vars, x)
+    xd = x.astype(np.float64)
+    # textbook density from the moments (independent of the gconst/means_invvars form)
+    comp = np.log(w)[None, :] - 0.5 * (72 * np.log(2 * np.pi) + np.log(var).sum(axis=1))[None, :] \
+        - 0.5 * (((xd[:, None, :] - mu[None, :, :]) ** 2) / var[None, :, :]).sum(axis=2)
+    want = logsumexp(comp, axis=1)
+    assert np.abs(ll.astype(np.float64) - want).max() <= 2e-4     # float32 parameter storage
+    # exact restatement check: same float32 parameters, float64 math
+    miv, iv, gc = g.means_invvars.astype(np.float64), g.inv_vars.astype(np.float64), g.gconsts.astype(np.float64)
+    x2 = (x * x).astype(np.float64)
+    comp2 = gc[None, :] + xd @ miv.T - 0.5 * (x2 @ iv.T)
+    want2 = logsumexp(comp2, axis=1)
+    assert np.abs(ll.astype(np.float64) - want2).max() <= 2e-5
+    assert abs(tot - ll.astype(np.float64).sum()) < 1e-9
+
+
+def test_gmm_score_batch_is_average_over_voiced_frames(oracle):
+    cfg = oracle.default_cfg()
+    models = []
+    for s in range(2):
+        w, mu, var = synthetic_ubm_moments(32, 72, seed=20 + s)
+        models.append(DiagGmm.from_moments(w, mu, var))
+    wavs = [(synthetic_audio(u, n) * 32768).astype(np.int16) for u, n in [(0, 16000), (1, 9000)]]
+    gc = np.stack([m.gconsts for m in models])
+    miv = np.stack([m.means_invvars for m in models])
+    iv = np.stack([m.inv_vars for m in models])
+    raw, tv = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv)
+    for b, wv in enumerate(wavs):
+        feats, _ = oracle.frontend(cfg, wv)
+        assert tv[b] == feats.shape[0]
+        for m, g in enumerate(models):
+            ll, tot = oracle.diag_gmm_loglikes(g.gconsts, g.means_invvars, g.inv_vars, feats)
+            assert raw[b, m] == tot / feats.shape[0]
+    # OpenMP path (used by the CPU baseline) gives the same numbers
+    raw2, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=2)
+    assert np.array_equal(raw, raw2)
+    silent = [np.zeros(4000, np.int16)]
+    with pytest.raises(RuntimeError):
+        oracle.gmm_score_batch(cfg, silent, gc, miv, iv)
