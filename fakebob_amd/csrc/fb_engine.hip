@@ -795,6 +795,21 @@ extern "C" int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32
   return FB_OK;
 }
 
+extern "C" int fb_debug_quantize(fb_engine *e, const double *x, int64_t n, int bits, int16_t *q) {
+  if (!e || !x || !q || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (bits < 2 || bits > 16) return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported", bits);
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->cached_B = -1;
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)n));
+  FBCHK(e->stage_f64.ensure(sizeof(double) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(e->stage_f64.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  fb_launch_quantize(e->stream, e->stage_f64.as<double>(), n, bits, e->wav.as<int16_t>());
+  HIPCHK(hipMemcpyAsync(q, e->wav.p, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return FB_OK;
+}
+
 static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   if (!e || !wav || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(e->device));

@@ -158,6 +158,12 @@ class Engine(object):
                                        C.c_int64(n), C.c_int(half), N.ptr(z)))
         return z
 
+    def debug_quantize(self, x, bits_per_sample=16):
+        x = np.ascontiguousarray(x, np.float64).reshape(-1)
+        q = np.empty(x.size, np.int16)
+        N.check(self._L.fb_debug_quantize(self._h, N.ptr(x), C.c_int64(x.size), C.c_int(bits_per_sample), N.ptr(q)))
+        return q
+
     def _num_frames(self, n):
         c = self.cfg
         if c.snip_edges:

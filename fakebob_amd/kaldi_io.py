@@ -1,0 +1,187 @@
+"""Readers/writers for the Kaldi on-disk objects the reference's pickled speaker models point at
+(`final.dubm`, `*-identity.gmm`: attackMain.py:40-55, build_spk_models.py:146-224).
+
+[EXT] The formats are Kaldi's (not in /root/reference): binary files start with "\\0B"; tokens
+are space-terminated; int32 is written as a size byte (4) + little-endian value; a float vector
+is "FV " + int32 dim + raw float32, a matrix "FM " + int32 rows + int32 cols + row-major data
+("DV"/"DM" for float64).  DiagGmm: <DiagGMM> <GCONSTS> v <WEIGHTS> v <MEANS_INVVARS> m
+<INV_VARS> m </DiagGMM>.  Real Kaldi files are unavailable offline, so these are validated by
+round trip and against hand-written text fixtures only.
+"""
+import io
+import os
+import struct
+
+import numpy as np
+
+from .models import DiagGmm
+
+
+class _Reader(object):
+    def __init__(self, data):
+        self.b = data
+        self.i = 0
+        self.binary = data[:2] == b"\x00B"
+        if self.binary:
+            self.i = 2
+
+    def _skip_ws(self):
+        while self.i < len(self.b) and self.b[self.i:self.i + 1] in b" \t\r\n":
+            self.i += 1
+
+    def token(self):
+        self._skip_ws()
+        j = self.i
+        while j < len(self.b) and self.b[j:j + 1] not in b" \t\r\n":
+            j += 1
+        t = self.b[self.i:j].decode("ascii")
+        self.i = j + 1 if self.binary else j
+        return t
+
+    def peek_token(self):
+        i = self.i
+        t = self.token()
+        self.i = i
+        return t
+
+    def expect(self, tok):
+        t = self.token()
+        if t != tok:
+            raise ValueError("kaldi_io: expected %s, got %r" % (tok, t))
+
+    def int32(self):
+        if self.binary:
+            sz = self.b[self.i]
+            if sz != 4:
+                raise ValueError("kaldi_io: bad int size byte %d" % sz)
+            v = struct.unpack_from("<i", self.b, self.i + 1)[0]
+            self.i += 5
+            return v
+        return int(self.token())
+
+    def vector(self):
+        if self.binary:
+            t = self.token()
+            if t not in ("FV", "DV"):
+                raise ValueError("kaldi_io: expected FV/DV, got %r" % t)
+            dt = np.dtype("<f4") if t == "FV" else np.dtype("<f8")
+            n = self.int32()
+            v = np.frombuffer(self.b, dt, n, self.i).astype(np.float64)
+            self.i += n * dt.itemsize
+            return v
+        self.expect("[")
+        vals = []
+        while True:
+            t = self.token()
+            if t == "]":
+                break
+            vals.append(float(t))
+        return np.asarray(vals, np.float64)
+
+    def matrix(self):
+        if self.binary:
+            t = self.token()
+            if t not in ("FM", "DM"):
+                raise ValueError("kaldi_io: expected FM/DM, got %r" % t)
+            dt = np.dtype("<f4") if t == "FM" else np.dtype("<f8")
+            r, c = self.int32(), self.int32()
+            m = np.frombuffer(self.b, dt, r * c, self.i).astype(np.float64).reshape(r, c)
+            self.i += r * c * dt.itemsize
+            return m
+        self.expect("[")
+        rows, cur = [], []
+        while True:
+            self._skip_ws()
+            # rows are newline separated; the closing bracket ends the last row
+            j = self.i
+            while j < len(self.b) and self.b[j:j + 1] not in b"\n]":
+                j += 1
+            line = self.b[self.i:j].decode("ascii").split()
+            if line:
+                rows.append([float(x) for x in line])
+            if self.b[j:j + 1] == b"]":
+                self.i = j + 1
+                break
+            self.i = j + 1
+        del cur
+        return np.asarray(rows, np.float64)
+
+
+def read_diag_gmm(path_or_bytes):
+    """Kaldi DiagGmm (binary or text) -> models.DiagGmm.  gconsts are recomputed from the stored
+    weights / means_invvars / inv_vars exactly as DiagGmm::Read + ComputeGconsts does."""
+    data = path_or_bytes
+    if not isinstance(data, (bytes, bytearray)):
+        with open(path_or_bytes, "rb") as r:
+            data = r.read()
+    rd = _Reader(bytes(data))
+    t = rd.token()
+    if t == "<DiagGMMBegin>":  # legacy alias
+        t = "<DiagGMM>"
+    if t != "<DiagGMM>":
+        raise ValueError("kaldi_io: not a DiagGmm (first token %r)" % t)
+    weights = miv = iv = None
+    while True:
+        t = rd.token()
+        if t in ("</DiagGMM>", "<DiagGMMEnd>"):
+            break
+        if t == "<GCONSTS>":
+            rd.vector()
+        elif t == "<WEIGHTS>":
+            weights = rd.vector()
+        elif t == "<MEANS_INVVARS>":
+            miv = rd.matrix()
+        elif t == "<INV_VARS>":
+            iv = rd.matrix()
+        else:
+            raise ValueError("kaldi_io: unexpected token %r in DiagGmm" % t)
+    if weights is None or miv is None or iv is None:
+        raise ValueError("kaldi_io: incomplete DiagGmm")
+    return DiagGmm.from_internal(weights, miv.astype(np.float32), iv.astype(np.float32)), weights
+
+
+def write_diag_gmm(path, gmm, weights, binary=True):
+    """Inverse of read_diag_gmm (used for tests and to export synthetic systems)."""
+    w = np.asarray(weights, np.float32)
+    out = io.BytesIO()
+    if binary:
+        out.write(b"\x00B")
+
+        def tok(s):
+            out.write(s.encode("ascii") + b" ")
+
+        def i32(v):
+            out.write(b"\x04" + struct.pack("<i", int(v)))
+
+        def vec(v):
+            tok("FV"); i32(v.size); out.write(np.asarray(v, "<f4").tobytes())
+
+        def mat(m):
+            tok("FM"); i32(m.shape[0]); i32(m.shape[1]); out.write(np.ascontiguousarray(m, "<f4").tobytes())
+        tok("<DiagGMM>"); tok("<GCONSTS>"); vec(gmm.gconsts); tok("<WEIGHTS>"); vec(w)
+        tok("<MEANS_INVVARS>"); mat(gmm.means_invvars); tok("<INV_VARS>"); mat(gmm.inv_vars); tok("</DiagGMM>")
+    else:
+        def vec_t(v):
+            return " [ " + " ".join("%.9g" % x for x in v) + " ]\n"
+
+        def mat_t(m):
+            return " [\n" + "\n".join("  " + " ".join("%.9g" % x for x in row) for row in m) + " ]\n"
+        s = "<DiagGMM> \n<GCONSTS> " + vec_t(gmm.gconsts) + "<WEIGHTS> " + vec_t(w) + \
+            "<MEANS_INVVARS> " + mat_t(gmm.means_invvars) + "<INV_VARS> " + mat_t(gmm.inv_vars) + "</DiagGMM> \n"
+        out.write(s.encode("ascii"))
+    with open(path, "wb") as wf:
+        wf.write(out.getvalue())
+
+
+def load_gmm_any(loc):
+    """identity_location / ubm argument of the wrappers -> DiagGmm.  Accepts a DiagGmm, a Kaldi
+    model file, or an .npz with gconsts / means_invvars / inv_vars."""
+    if isinstance(loc, DiagGmm):
+        return loc
+    if isinstance(loc, (str, os.PathLike)):
+        p = os.fspath(loc)
+        if p.endswith(".npz"):
+            z = np.load(p)
+            return DiagGmm(z["gconsts"], z["means_invvars"], z["inv_vars"])
+        return read_diag_gmm(p)[0]
+    raise TypeError("cannot load a GMM from %r" % (loc,))

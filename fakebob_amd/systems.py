@@ -1,0 +1,147 @@
+"""Speaker-recognition systems behind the reference's `model` plugin API (README.md:136):
+`score(audios, fs, bits_per_sample, debug, n_jobs)` and `make_decisions(...)`, attributes
+`spk_ids` / `threshold`.  Same class names, constructor arguments, return shapes and decision
+rules as the reference wrappers (gmm_ubm_OSI.py, gmm_ubm_CSI.py, gmm_ubm_SV.py); the scoring
+itself (wav -> MFCC -> VAD -> deltas -> CMVN -> GMM log-likelihoods) runs on the GPU through
+libfakebob_hip.so instead of >= 10 Kaldi subprocesses per call.  `n_jobs`, `debug` and `fs` are
+accepted and ignored; `bits_per_sample` drives the int16 cast exactly as in the reference.
+"""
+import os
+
+import numpy as np
+
+from .engine import Engine
+from .kaldi_io import load_gmm_any
+
+
+def default_device():
+    return int(os.environ.get("FAKEBOB_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def _to_audio_list(audios):
+    """Input normalisation of the reference wrappers (gmm_ubm_OSI.py:70-81): an (N,)/(N,1)/(1,N)
+    ndarray is ONE utterance, an (N,B) ndarray is B columns, anything else is an iterable of 1-D
+    arrays of possibly different lengths.  Inputs are never modified (the reference deep-copies)."""
+    if isinstance(audios, np.ndarray):
+        if audios.ndim == 1 or (audios.ndim == 2 and (audios.shape[0] == 1 or audios.shape[1] == 1)):
+            return [np.ascontiguousarray(audios).reshape(-1)]
+        if audios.ndim == 2:
+            return [np.ascontiguousarray(audios[:, i]) for i in range(audios.shape[1])]
+        raise ValueError("audios must be 1-D or 2-D")
+    return [np.asarray(a).reshape(-1) for a in audios]
+
+
+class _GmmSystem(object):
+    task = None
+
+    def _setup(self, group_id, models, spk_ids, utt_ids, locations, z_means, z_stds, pre_model_dir, engine):
+        self.pre_model_dir = os.path.abspath(pre_model_dir)
+        self.group_id = os.path.abspath(group_id)
+        self.spk_ids = spk_ids
+        self.utt_ids = utt_ids
+        self.identity_locations = locations
+        self.n_speakers = len(spk_ids)
+        self._engine = engine if engine is not None else Engine(default_device())
+        conf = os.path.join(self.pre_model_dir, "conf")
+        if os.path.isdir(conf):
+            from .config import frontend_from_kaldi_conf
+            over = frontend_from_kaldi_conf(self.pre_model_dir)
+            if over:
+                self._engine.set_frontend(**over)
+        self._engine.load_gmm(models)
+        self._engine.set_system(self.task, z_means, z_stds)
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def _raw(self, audios, bits_per_sample):
+        lst = _to_audio_list(audios)
+        raw, _tv = self._engine.score_raw(lst, bits_per_sample=bits_per_sample)
+        return raw
+
+
+class gmm_OSI(_GmmSystem):
+    """gmm_ubm_OSI.py:13-112"""
+    task = "OSI"
+
+    def __init__(self, group_id, model_list, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None):
+        self.threshold = threshold
+        locs = [m[2] for m in model_list]
+        self.model_list = [ubm] + locs  # UBM first (gmm_ubm_OSI.py:45)
+        models = [load_gmm_any(x) for x in self.model_list]
+        self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs, None, None,
+                    pre_model_dir, engine)
+
+    def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
+        raw = self._raw(audios, bits_per_sample)
+        final = raw[:, 1:] - raw[:, 0:1]                     # :89
+        return final if final.shape[0] > 1 else final[0]     # :91
+
+    def make_decisions(self, audios, fs=16000, bits_per_sample=16, n_jobs=5, debug=False):
+        score = self.score(audios, fs=fs, bits_per_sample=bits_per_sample, debug=debug, n_jobs=n_jobs)
+        if score.ndim == 1:
+            score = score[np.newaxis, :]
+        max_score = np.max(score, axis=1)
+        decisions = list(np.argmax(score, axis=1))
+        for i, v in enumerate(max_score):
+            if v < self.threshold:                           # strict < (:105)
+                decisions[i] = -1
+        if score.shape[0] == 1:
+            return decisions[0], score.flatten()
+        return decisions, score
+
+
+class gmm_CSI(_GmmSystem):
+    """gmm_ubm_CSI.py:13-110 -- no UBM, z-normalised raw log-likelihoods."""
+    task = "CSI"
+
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None):
+        locs = [m[2] for m in model_list]
+        self.model_list = locs
+        self.z_norm_means = np.array([m[3] for m in model_list], np.float64)
+        self.z_norm_stds = np.array([m[4] for m in model_list], np.float64)
+        models = [load_gmm_any(x) for x in locs]
+        self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs,
+                    self.z_norm_means, self.z_norm_stds, pre_model_dir, engine)
+
+    def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
+        raw = self._raw(audios, bits_per_sample)
+        final = (raw - self.z_norm_means) / self.z_norm_stds  # :93
+        return final if final.shape[0] > 1 else final[0]
+
+    def make_decisions(self, audios, fs=16000, bits_per_sample=16, n_jobs=5, debug=False):
+        score = self.score(audios, fs=fs, bits_per_sample=bits_per_sample, debug=debug, n_jobs=n_jobs)
+        if score.ndim == 1:
+            score = score[np.newaxis, :]
+        decisions = list(np.argmax(score, axis=1))
+        if score.shape[0] == 1:
+            return decisions[0], score.flatten()
+        return decisions, score
+
+
+class gmm_SV(_GmmSystem):
+    """gmm_ubm_SV.py:13-92 -- one enrolled speaker against the UBM."""
+    task = "SV"
+
+    def __init__(self, spk_id, model, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None):
+        self.threshold = threshold
+        self.utt_id = model[1]
+        self.identity_location = model[2]
+        self.model_list = [ubm, self.identity_location]
+        models = [load_gmm_any(x) for x in self.model_list]
+        self._setup(spk_id, models, [model[0]], [model[1]], [model[2]], None, None, pre_model_dir, engine)
+        self.spk_id = self.group_id
+
+    def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
+        raw = self._raw(audios, bits_per_sample)
+        final = raw[:, 1] - raw[:, 0]                        # :77
+        return final if final.shape[0] > 1 else final[0]     # (B,) or scalar
+
+    def make_decisions(self, audios, fs=16000, bits_per_sample=16, n_jobs=5, debug=False):
+        score = self.score(audios, fs=fs, bits_per_sample=bits_per_sample, debug=debug, n_jobs=n_jobs)
+        if isinstance(score, np.ndarray):
+            decisions = [1 if s >= self.threshold else -1 for s in score]   # >= (:87)
+        else:
+            decisions = 1 if score >= self.threshold else -1
+        return decisions, score

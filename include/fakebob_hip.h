@@ -162,6 +162,8 @@ int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p,
 /* z[half*N] float32 from the device Philox/Box-Muller (bit-exact contract) */
 int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32_t stream,
                    int64_t N, int half, float *z);
+/* the device int16 cast of model.score's float input (gmm_ubm_OSI.py:83-85) */
+int fb_debug_quantize(fb_engine *e, const double *x, int64_t n, int bits_per_sample, int16_t *q);
 /* front-end only: MFCC [T*num_ceps] of one utterance */
 int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T);
 /* compacted voiced CMVN'd features of one utterance: feats[Tv*dim] */

@@ -221,3 +221,66 @@ def test_no_voiced_frames_is_an_error(engine, small_system):
     with pytest.raises(NativeError) as ei:
         engine.score_raw([w])
     assert ei.value.code == FB_E_NO_VOICED
+
+
+def test_device_int16_cast_matches_reference_golden(engine):
+    """G5: the int16 arrays the reference's wrapper handed to Kaldi (captured by import)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5678_wrappers.npz"))
+    vals = z["g5_vals"]
+    assert np.array_equal(engine.debug_quantize(vals), z["g5_q_1d"])
+    assert np.array_equal(engine.debug_quantize(vals, 8), z["g5_q_bits8"])
+    for i in range(3):
+        assert np.array_equal(engine.debug_quantize(z["g5_mat"][:, i]), z["g5_q_mat_%d" % i])
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=200001) * 0.9
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(engine.debug_quantize(y), (y * 2 ** 15).astype(np.int16))
+
+
+def test_reference_python_surface(tmp_path, small_system):
+    """FakeBob / gmm_OSI with the reference's signatures, return shapes and trace pickle layout
+    (FAKEBOB.py:139-221, gmm_ubm_OSI.py:50-112)."""
+    import pickle
+    from fakebob_amd.attack import FakeBob
+    from fakebob_amd.systems import gmm_CSI, gmm_OSI, gmm_SV
+    ubm, spk = small_system
+    ml = [["spk%d" % i, "utt%d" % i, g, -60.0 - i, 2.0 + i] for i, g in enumerate(spk)]
+    model = gmm_OSI(str(tmp_path / "gmm-OSI-targeted"), ml, ubm, pre_model_dir=str(tmp_path), threshold=0.05)
+    audio = synthetic_audio(8, 16000)
+    s1 = model.score(audio)
+    assert s1.shape == (3,)
+    sB = model.score(np.stack([audio, audio * 0.5, audio], axis=1))
+    assert sB.shape == (3, 3) and np.array_equal(sB[0], s1) and np.array_equal(sB[2], s1)
+    sL = model.score([audio[:8000], (audio * 32768).astype(np.int16)])     # ragged list, mixed dtypes
+    assert sL.shape == (2, 3) and np.array_equal(sL[1], s1)
+    dec, sc = model.make_decisions(audio)
+    assert np.array_equal(sc, s1) and dec in (-1, 0, 1, 2)
+    fb = FakeBob("OSI", "targeted", model, samples_per_draw=10, max_iter=4, seed=5, verbose=False)
+    cp = str(tmp_path / "t.cp")
+    adv, flag = fb.attack(audio, cp, threshold=float(s1.max()) + 1.0, target=int(np.argmin(s1)))
+    assert adv.shape == (16000, 1) and adv.dtype == np.int16 and flag in (1, -1)
+    assert np.abs(adv[:, 0] / 32768.0 - audio).max() <= 0.002 + 1 / 32768.0
+    with open(cp, "rb") as r:
+        trace = pickle.load(r)
+    assert len(trace) == 4 and all(len(row) == 4 for row in trace)
+    assert trace[0][0] == 0.0 and trace[0][1].shape == (1,) and trace[0][2].shape == (3,)
+    fl, grad, al, score = fb.get_grad(audio)
+    assert grad.shape == (16000, 1) and al.shape == (1,) and score.shape == (3,)
+    loss, score_b = fb.loss_fn(np.stack([audio, audio], axis=1))
+    assert loss.shape == (2, 1) and abs(loss[0, 0] - al[0]) < 1e-12
+    # SV / CSI shapes
+    sv = gmm_SV(str(tmp_path / "sv"), ml[0], ubm, pre_model_dir=str(tmp_path), threshold=0.0)
+    assert np.ndim(sv.score(audio)) == 0 and sv.score(np.stack([audio, audio], axis=1)).shape == (2,)
+    d, s = sv.make_decisions(audio)
+    assert d in (1, -1)
+    fbs = FakeBob("SV", "targeted", sv, samples_per_draw=6, max_iter=2, seed=1, verbose=False)
+    _, _, _, sc_sv = fbs.get_grad(audio)
+    assert np.ndim(sc_sv) == 0
+    r = fbs.estimate_threshold(audio, max_total_iters=3) if s >= 0.0 else None
+    csi = gmm_CSI(str(tmp_path / "csi"), ml, pre_model_dir=str(tmp_path))
+    assert csi.score(audio).shape == (3,)
+    fbc = FakeBob("CSI", "untargeted", csi, samples_per_draw=6, max_iter=2, seed=1, verbose=False)
+    assert fbc.estimate_threshold(audio) is None
+    adv, flag = fbc.attack(audio, None, true=int(np.argmax(csi.score(audio))))
+    assert adv.shape == (16000, 1)

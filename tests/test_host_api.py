@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference interface (no GPU): C-ABI surface, wrapper input
+normalisation / post-processing / decision rules against the golden vectors captured from the
+reference's six wrappers (G5-G8), Kaldi file + conf readers."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fakebob_amd import _native
+from fakebob_amd.models import DiagGmm, synthetic_ubm_moments
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _native.lib()
+    hdr = open(os.path.join(ROOT, "include", "fakebob_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fb_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert set(_native.EXPORTS) == declared
+    assert L.fb_version() >= 100
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import ctypes as C
+    L = _native.lib()
+    if L.fb_device_count() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = L.fb_engine_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+    assert len(L.fb_last_error()) > 0
+    from fakebob_amd.engine import Engine
+    with pytest.raises(_native.NativeError):
+        Engine(0)
+
+
+def test_struct_layout_matches_header_order():
+    hdr = open(os.path.join(ROOT, "include", "fakebob_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("Kaldi front-end options")):hdr.index("} fb_frontend_cfg;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if not decl:
+            continue
+        typ, rest = decl.split(None, 1)
+        names += [(typ, n.strip()) for n in rest.split(",")]
+    assert [n for _, n in names] == [f[0] for f in _native.FrontendCfg._fields_]
+    for (typ, n), (fn, ft) in zip(names, _native.FrontendCfg._fields_):
+        assert {"double": "c_double", "int": "c_int"}[typ] == ft.__name__
+    body = hdr[hdr.index("typedef struct {", hdr.index("FakeBob hyper-parameters")):hdr.index("} fb_nes_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if decl:
+            names += [n.strip() for n in decl.split(None, 1)[1].split(",")]
+    assert names == [f[0] for f in _native.NesParams._fields_]
+
+
+# ----------------------------------------------------- wrappers vs goldens
+class FakeEngine(object):
+    """Captures what the wrappers hand to the engine and returns canned raw scores."""
+
+    def __init__(self):
+        self.ret = None
+        self.audio = None
+        self.bits = None
+
+    def set_frontend(self, **kw):
+        pass
+
+    def load_gmm(self, models):
+        self.n_models = len(models)
+
+    def set_system(self, task, zm=None, zs=None):
+        self.task, self.zm, self.zs = task, zm, zs
+
+    @property
+    def n_speakers(self):
+        return self.n_models if self.task == "CSI" else self.n_models - 1
+
+    def score_raw(self, lst, bits_per_sample=16):
+        self.audio = [a.copy() for a in lst]
+        self.bits = bits_per_sample
+        return self.ret.copy(), np.ones(len(lst), np.int32)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(G, "golden_meta.json")) as r:
+        meta = json.load(r)["g5678"]
+    return meta, np.load(os.path.join(G, "g5678_wrappers.npz"))
+
+
+def _dummy_gmm(seed):
+    w, mu, var = synthetic_ubm_moments(4, 72, seed=seed)
+    return DiagGmm.from_moments(w, mu, var)
+
+
+def _systems(meta, tmp_path):
+    from fakebob_amd.systems import gmm_CSI, gmm_OSI, gmm_SV
+    ml = [[m[0], m[1], _dummy_gmm(i), m[3], m[4]] for i, m in enumerate(meta["spk_models"])]
+    ubm = _dummy_gmm(99)
+    osi = gmm_OSI(str(tmp_path / "o"), ml, ubm, pre_model_dir=str(tmp_path), threshold=0.25, engine=FakeEngine())
+    csi = gmm_CSI(str(tmp_path / "c"), ml, pre_model_dir=str(tmp_path), engine=FakeEngine())
+    sv = gmm_SV(str(tmp_path / "s"), ml[0], ubm, pre_model_dir=str(tmp_path), threshold=0.25, engine=FakeEngine())
+    return osi, csi, sv
+
+
+def test_wrapper_attributes_and_model_order(gold, tmp_path):
+    meta, z = gold
+    osi, csi, sv = _systems(meta, tmp_path)
+    assert osi.spk_ids == meta["gmm_spk_ids"] == csi.spk_ids      # CLI order, NOT sorted (unlike iv_*)
+    assert len(osi.model_list) == len(meta["gmm_model_list"]) and osi.engine.n_models == 4
+    assert len(csi.model_list) == len(meta["gmm_csi_model_list"]) and csi.engine.n_models == 3
+    assert osi.engine.task == "OSI" and csi.engine.task == "CSI" and sv.engine.task == "SV"
+    assert osi.threshold == 0.25 and osi.n_speakers == 3
+    assert list(csi.engine.zm) == [m[3] for m in meta["spk_models"]]
+
+
+def test_g5_input_normalisation(gold, tmp_path, oracle):
+    """What reaches the scorer: one utterance for 1-D/(N,1)/(1,N), columns for (N,B), ragged lists
+    with int16 passed through; the int16 cast itself (golden q arrays) is pinned on the oracle here
+    and on the GPU kernel in test_gpu_parity.py."""
+    meta, z = gold
+    osi, _, _ = _systems(meta, tmp_path)
+    e = osi.engine
+    vals = z["g5_vals"]
+    e.ret = np.zeros((1, 4))
+    for arr in (vals, vals[:, None], vals[None, :]):
+        osi.score(arr)
+        assert len(e.audio) == 1 and np.array_equal(e.audio[0], vals)
+    assert np.array_equal(oracle.quantize(vals), z["g5_q_1d"])
+    assert np.array_equal(oracle.quantize(vals), z["g5_q_col"]) and np.array_equal(oracle.quantize(vals), z["g5_q_row"])
+    assert np.array_equal(oracle.quantize(vals, bits=8), z["g5_q_bits8"])
+    osi.score(vals, bits_per_sample=8)
+    assert e.bits == 8
+    mat = z["g5_mat"]
+    e.ret = np.zeros((3, 4))
+    osi.score(mat)
+    assert len(e.audio) == 3
+    for i in range(3):
+        assert np.array_equal(e.audio[i], mat[:, i])
+        assert np.array_equal(oracle.quantize(mat[:, i]), z["g5_q_mat_%d" % i])
+    lst = [z["g5_list_in_%d" % i] for i in range(3)]
+    keep = [a.copy() for a in lst]
+    osi.score(lst)
+    assert [a.dtype for a in e.audio] == [a.dtype for a in lst]           # int16 entry passed through
+    for i in range(3):
+        q = e.audio[i] if e.audio[i].dtype == np.int16 else oracle.quantize(e.audio[i])
+        assert np.array_equal(q, z["g5_q_list_%d" % i])
+        assert np.array_equal(lst[i], keep[i])                           # caller's arrays untouched
+    assert meta["g5_list_input_unchanged"]
+
+
+def test_g6_g7_gmm_postprocessing_and_decisions(gold, tmp_path):
+    meta, z = gold
+    osi, csi, sv = _systems(meta, tmp_path)
+    x = np.zeros((8, 4))
+    osi.engine.ret = z["g6_raw_osi"]
+    assert np.array_equal(osi.score(x), z["g6_osi_scores"])
+    dec, sc = osi.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_osi_dec"]) and np.array_equal(sc, z["g7_osi_sc"])
+    assert isinstance(dec, list)
+    osi.engine.ret = z["g6_raw_osi"][:1]
+    s1 = osi.score(np.zeros(8))
+    assert s1.shape == (3,) and np.array_equal(s1, z["g6_osi_scores_b1"])
+    osi.engine.ret = z["g6_raw_osi"][1:2]                 # max == threshold exactly: accepted (strict <)
+    dec, sc = osi.make_decisions(np.zeros(8))
+    assert dec == meta["g7_osi_b1_dec"] and np.array_equal(sc, z["g7_osi_b1_sc"]) and sc.ndim == 1
+    sv.engine.ret = z["g6_raw_sv"]
+    assert np.array_equal(sv.score(x), z["g6_sv_scores"])
+    dec, sc = sv.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_sv_dec"]) and np.array_equal(sc, z["g7_sv_sc"])
+    sv.engine.ret = z["g6_raw_sv"][1:2]
+    r = sv.score(np.zeros(8))
+    assert np.ndim(r) == 0 and float(r) == float(z["g6_sv_b1"])
+    dec, _ = sv.make_decisions(np.zeros(8))
+    assert dec == meta["g7_sv_b1_dec"]
+    csi.engine.ret = z["g6_raw_csi"]
+    assert np.array_equal(csi.score(x), z["g6_csi_scores"])
+    dec, sc = csi.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_csi_dec"])
+    csi.engine.ret = z["g6_raw_csi"][:1]
+    dec, sc = csi.make_decisions(np.zeros(8))
+    assert dec == meta["g7_csi_b1_dec"] and np.array_equal(sc, z["g7_csi_b1_sc"])
+
+
+# ------------------------------------------------------------- file readers
+def test_kaldi_diag_gmm_round_trip(tmp_path):
+    from fakebob_amd.kaldi_io import load_gmm_any, read_diag_gmm, write_diag_gmm
+    w, mu, var = synthetic_ubm_moments(16, 72, seed=3)
+    g = DiagGmm.from_moments(w, mu, var)
+    for binary in (True, False):
+        p = str(tmp_path / ("m_%d.gmm" % binary))
+        write_diag_gmm(p, g, w, binary=binary)
+        g2, w2 = read_diag_gmm(p)
+        assert np.array_equal(g2.means_invvars, g.means_invvars) and np.array_equal(g2.inv_vars, g.inv_vars)
+        assert np.allclose(w2, w, rtol=1e-6)
+        assert np.abs(g2.gconsts - g.gconsts).max() < 1e-4
+        assert np.array_equal(load_gmm_any(p).inv_vars, g.inv_vars)
+    head = open(str(tmp_path / "m_1.gmm"), "rb").read(12)
+    assert head.startswith(b"\x00B<DiagGMM> ")
+    with pytest.raises(ValueError):
+        read_diag_gmm(b"\x00B<FullGMM> ")
+
+
+def test_kaldi_conf_parsing(tmp_path):
+    from fakebob_amd.config import frontend_from_kaldi_conf, frontend_overrides
+    mf = "--sample-frequency=16000\n--frame-length=25 # ms\n--low-freq=20\n--high-freq=7600\n" \
+         "--num-mel-bins=30\n--num-ceps=24\n--snip-edges=false\n"
+    vd = "--vad-energy-threshold=5.5\n--vad-energy-mean-scale=0.5\n--vad-proportion-threshold=0.12\n--vad-frames-context=2\n"
+    o = frontend_overrides(mf, vd, "--delta-window=3 --delta-order=2\n")
+    assert o["frame_length"] == 400 and o["padded_length"] == 512 and o["snip_edges"] == 0
+    assert o["num_ceps"] == 24 and o["high_freq"] == 7600.0 and o["vad_frames_context"] == 2
+    assert o["delta_window"] == 3 and o["delta_order"] == 2
+    (tmp_path / "conf").mkdir()
+    (tmp_path / "conf" / "mfcc.conf").write_text(mf)
+    (tmp_path / "conf" / "vad.conf").write_text(vd)
+    (tmp_path / "delta_opts").write_text("--delta-window=3 --delta-order=2\n")
+    assert frontend_from_kaldi_conf(str(tmp_path)) == o
+    with pytest.raises(ValueError):
+        frontend_overrides("--window-type=hamming")
+    for k in o:                                            # every override is a real struct field
+        assert k in [f[0] for f in _native.FrontendCfg._fields_]
+
+
+def test_fakebob_rejects_models_without_the_engine():
+    from fakebob_amd.attack import FakeBob
+
+    class Plain(object):
+        def score(self, a, **k):
+            return 0.0
+    with pytest.raises(TypeError):
+        FakeBob("SV", "targeted", Plain())
