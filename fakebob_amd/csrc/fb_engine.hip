@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -79,6 +80,7 @@ struct fb_engine {
   bool have_fe = false;
   fb_frontend_cfg cfg;
   FbFrontendDev fe;
+  int melw_n = 0;  // packed mel weight count
   DevBuf fe_tables;
   // gmm
   bool have_gmm = false;
@@ -90,14 +92,15 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf wav, wav_off, frame_off, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
+  DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
-  std::vector<int> h_frame_off;
+  std::vector<int> h_frame_off, h_chunk_off;
+  bool any_long = false;  // some utterance has T > cmn_window
   int cached_B = -1;
   int64_t cached_N = -1;
   int last_total_frames = 0, last_B = 0, last_chunks = 1;
   // NES state
-  DevBuf audio, adver, grad_m, grad, noise, scores, loss, dist_part, nes_out, stage_f64;
+  DevBuf audio, adver, grad_m, grad, noise, zbuf, scores, loss, dist_part, nes_out, stage_f64;
   FbNesDev *h_out = nullptr;  // pinned
   int *h_tv = nullptr;        // pinned, grows
   size_t h_tv_cap = 0;
@@ -133,8 +136,8 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_off, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
-                    &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise,
+                    &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
@@ -160,11 +163,12 @@ extern "C" void fb_default_frontend(fb_frontend_cfg *c) {
 }
 
 static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+int fb_mfcc_layout_doubles(int P, int L, int nb, int nc, int melw_n);  // frontend_kernels.hip
 
 extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   if (!e || !c) return fb_fail(FB_E_ARG, "null argument");
   const int L = c->frame_length, P = c->padded_length, nb = c->num_mel_bins, nc = c->num_ceps;
-  if (L <= 1 || L > 512 || P < L || (P & (P - 1)) || P < 8 || P > 4096)
+  if (L <= 1 || L > 512 || P < L || (P & (P - 1)) || P < 8 || P > 512)
     return fb_fail(FB_E_ARG, "frame_length %d / padded_length %d unsupported (need L<=512, P power of 2)", L, P);
   if (nb <= 0 || nb > 128 || nc <= 0 || nc > nb || c->frame_shift <= 0)
     return fb_fail(FB_E_ARG, "bad mel/ceps/shift configuration");
@@ -271,6 +275,9 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   fe.mel_len = (const int *)(base + o_ml); fe.mel_off = (const int *)(base + o_mo);
   fe.mel_w = (const double *)(base + o_mw); fe.dct = (const double *)(base + o_dct);
   fe.lifter = (const double *)(base + o_lift); fe.dscale = (const double *)(base + o_ds);
+  e->melw_n = (int)mel_w.size();
+  if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, e->melw_n)) > 150 * 1024)
+    return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
   e->cfg = *c;
   e->have_fe = true;
   e->cached_B = -1;
@@ -387,14 +394,21 @@ extern "C" int fb_num_speakers(fb_engine *e) {
 static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
   e->h_wav_off.assign(off, off + B + 1);
   e->h_frame_off.resize(B + 1);
+  e->h_chunk_off.resize(B + 1);
   e->h_frame_off[0] = 0;
+  e->h_chunk_off[0] = 0;
+  e->any_long = false;
   for (int b = 0; b < B; ++b) {
     const int64_t n = off[b + 1] - off[b];
     if (n <= 0) return fb_fail(FB_E_ARG, "utterance %d is empty", b);
     const int T = num_frames(e->cfg, n);
     if (T <= 0) return fb_fail(FB_E_ARG, "utterance %d (%lld samples) is shorter than one frame", b, (long long)n);
     e->h_frame_off[b + 1] = e->h_frame_off[b] + T;
+    e->h_chunk_off[b + 1] = e->h_chunk_off[b] + (T + 31) / 32;
+    if (T > e->cfg.cmn_window) e->any_long = true;
   }
+  FBCHK(e->chunk_off.ensure(sizeof(int) * (B + 1)));
+  HIPCHK(hipMemcpyAsync(e->chunk_off.p, e->h_chunk_off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, e->stream));
   FBCHK(e->wav_off.ensure(sizeof(int64_t) * (B + 1)));
   FBCHK(e->frame_off.ensure(sizeof(int) * (B + 1)));
   HIPCHK(hipMemcpyAsync(e->wav_off.p, e->h_wav_off.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, e->stream));
@@ -404,9 +418,14 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
   return FB_OK;
 }
 
+// Split the component tiles into chunks so that the launch is ONE fully resident round:
+// ~4 workgroups per CU (VGPR/LDS budget of k_gmm) x 256 CUs.  A second, partially filled round
+// would idle most of the chip for a whole chunk's duration.
 static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   const int strips = (rows_cap + 127) / 128;
-  int want = (1536 + strips - 1) / strips;
+  const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
+  const int target = ev ? atoi(ev) : 1024;
+  int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;
   const int tpc = (g.n_tiles + want - 1) / want;
@@ -428,12 +447,16 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
   FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * g.M));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), B, total_frames,
+  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), B, total_frames,
                  e->mfcc.as<float>());
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>());
   fb_launch_rowscan(s, e->tv.as<int>(), B, e->row_off.as<int>());
-  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, total_frames, e->dfeat.as<float>());
-  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(), e->row_off.as<int>(), B,
+  const int total_chunks = e->h_chunk_off[B];
+  FBCHK(e->chunk_sum.ensure(sizeof(double) * (size_t)total_chunks * fe.dim));
+  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(), B, total_chunks,
+                   e->dfeat.as<float>(), e->chunk_sum.as<double>());
+  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
+                 e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), B, total_chunks, e->any_long,
                  e->feats.as<float>());
   if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
   fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
@@ -567,6 +590,7 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B) {
   FBCHK(e->loss.ensure(sizeof(double) * (size_t)B));
   FBCHK(e->dist_part.ensure(sizeof(double) * (size_t)((N + 1023) / 1024 + 1)));
   FBCHK(e->nes_out.ensure(sizeof(FbNesDev)));
+  FBCHK(e->zbuf.ensure(sizeof(float) * (size_t)N * (size_t)((B - 1) / 2 > 0 ? (B - 1) / 2 : 1)));
   return FB_OK;
 }
 
@@ -577,7 +601,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   int ndp = 0;
   fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
                     p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
-                    e->dist_part.as<double>(), &ndp);
+                    e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>());
   FBCHK(run_scoring(e, B, e->h_frame_off[B]));
   fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->gmm.M, p->task, p->attack_type,
                  e->zmean.as<double>(), e->zstd.as<double>(), p->threshold, p->adver_thresh, p->target,
@@ -618,7 +642,7 @@ extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *a
     noise_dev = e->noise.as<double>();
   }
   FBCHK(enqueue_get_grad(e, p, N, iter, noise_dev, false));
-  fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, iter, p->stream, noise_dev,
+  fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
                         e->grad.as<double>(), 0, 0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr);
   if (grad) HIPCHK(hipMemcpyAsync(grad, e->grad.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
   FBCHK(fetch_out(e));
@@ -680,9 +704,9 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
       break;
     }
     pl.step(e->h_out->final_loss, p);
-    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, (uint32_t)it, p->stream,
-                          noise_dev, nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon,
-                          e->audio.as<double>(), e->grad_m.as<double>(), e->adver.as<double>());
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
+                          nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
+                          e->grad_m.as<double>(), e->adver.as<double>());
     if (row) { row[0] = e->h_out->distance; row[1] = adver_loss; row[2] = pl.lr; for (int s = 0; s < S; ++s) row[3 + s] = e->h_out->score0[s]; }
     ++rows;
   }
@@ -767,8 +791,8 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
     }
     e->nes_iters += 1;
     pl.step(e->h_out->final_loss, &q);
-    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, q.sigma, q.seed, (uint32_t)n_iters, q.stream,
-                          noise_dev, nullptr, 1, q.momentum, one_minus_m, pl.lr, q.epsilon, e->audio.as<double>(),
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, q.sigma, e->zbuf.as<float>(), noise_dev,
+                          nullptr, 1, q.momentum, one_minus_m, pl.lr, q.epsilon, e->audio.as<double>(),
                           e->grad_m.as<double>(), e->adver.as<double>());
     ++n_iters;
   }
@@ -828,11 +852,15 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)T * fe.dim));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), 1, T, e->mfcc.as<float>());
+  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), 1, T, e->mfcc.as<float>());
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, e->vrank.as<int>(), e->tv.as<int>());
   fb_launch_rowscan(s, e->tv.as<int>(), 1, e->row_off.as<int>());
-  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, T, e->dfeat.as<float>());
-  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(), e->row_off.as<int>(), 1,
+  const int total_chunks = e->h_chunk_off[1];
+  FBCHK(e->chunk_sum.ensure(sizeof(double) * (size_t)total_chunks * fe.dim));
+  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(), 1, total_chunks,
+                   e->dfeat.as<float>(), e->chunk_sum.as<double>());
+  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
+                 e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), 1, total_chunks, e->any_long,
                  e->feats.as<float>());
   HIPCHK(hipGetLastError());
   return FB_OK;
@@ -926,8 +954,8 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
     FBCHK(fetch_out(e));
     e->nes_iters += 1;
     pl.step(e->h_out->final_loss, p);
-    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, p->seed, (uint32_t)it, p->stream,
-                          nullptr, nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), nullptr,
+                          nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
                           e->grad_m.as<double>(), e->adver.as<double>());
   }
   HIPCHK(hipEventRecord(e->ev1, e->stream));

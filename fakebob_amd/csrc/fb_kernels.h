@@ -32,7 +32,8 @@ struct FbFrontendDev {
 // dist_part[gridDim.x] gets per-block max |audio - adver| (audio nullable).
 void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
-                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part);
+                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part,
+                       float *zbuf /* nullable: float32 normals [half][N] for the gradient kernel */);
 // plain quantisation of float64 audio (model.score on float input)
 void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q);
 // noise dump (tests)
@@ -53,26 +54,27 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 // grad estimate (numpy-pairwise order) + optional momentum/sign/clip update.
 // do_update: 0 = only grad_out; 1 = momentum+update with lr.
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
-                           uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
-                           double *grad_out, int do_update, double momentum, double one_minus_m,
-                           double lr, double epsilon, const double *audio, double *grad_m,
-                           double *adver);
+                           const float *zbuf, const double *noise_pos, double *grad_out, int do_update,
+                           double momentum, double one_minus_m, double lr, double epsilon,
+                           const double *audio, double *grad_m, double *adver);
 
 // ---- front-end ------------------------------------------------------------
 // MFCC of every frame of a (ragged) batch.  wav_off[B+1], frame_off[B+1] device arrays.
-void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, const int16_t *wav, const int64_t *wav_off,
-                    const int *frame_off, int B, int total_frames, float *mfcc);
+void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav,
+                    const int64_t *wav_off, const int *frame_off, int B, int total_frames, float *mfcc);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                    int *vrank, int *tv);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
 void fb_launch_rowscan(hipStream_t s, const int *tv, int B, int *row_off);
-// add-deltas
-void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
-                      int total_frames, float *dfeat);
+// add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk
+// column sums for the CMVN mean
+void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
+                      const int *chunk_off, int B, int total_chunks, float *dfeat, double *chunk_sum);
 // apply-cmvn-sliding + select-voiced-frames -> compact feats[row][dim]
 void fb_launch_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *dfeat, const int *frame_off,
-                    const int *vrank, const int *row_off, int B, float *feats);
+                    const int *chunk_off, const double *chunk_sum, const int *vrank, const int *row_off, int B,
+                    int total_chunks, bool any_long, float *feats);
 
 // ---- diagonal GMM -----------------------------------------------------------
 struct FbGmmDev {

@@ -21,137 +21,215 @@ __device__ __forceinline__ int fb_find_utt(const int *__restrict__ frame_off, in
   return lo;
 }
 
+__device__ __forceinline__ void fb_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------- MFCC
-// One wave per frame, 4 frames per 256-thread block.  LDS per wave:
-//   A[P] doubles (P/2 complex), Bf[P] doubles, PW[P/2+1] doubles.
+// One wave per frame, 4 frames in flight per 256-thread workgroup, workgroups persistent over
+// frames.  LDS: the constant tables (window, FFT twiddles, packed mel weights, DCT, lifter) are
+// staged once per workgroup; each wave owns two P-double ping-pong buffers (complex FFT of size
+// P/2 + real-FFT unpack; power spectrum and log-mel energies alias them).
 #define FB_MFCC_MAXI 8  // samples per lane: frame_length <= 512
 
-__global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, const int16_t *__restrict__ wav,
+struct MfccLds {  // offsets in doubles from the dynamic LDS base
+  int tw, win, melw, dct, lift, melidx, wave0, per_wave;
+};
+__host__ __device__ inline MfccLds fb_mfcc_layout(int P, int L, int nb, int nc, int melw_n) {
+  MfccLds o;
+  int off = 0;
+  o.tw = off; off += P;                        // (P/2) double2
+  o.win = off; off += (L + 1) / 2;             // L floats
+  o.melw = off; off += (melw_n + 1) / 2 + 1;   // packed mel weights, floats
+  o.dct = off; off += (nc * nb + 1) / 2 + 1;   // floats
+  o.lift = off; off += (nc + 1) / 2 + 1;       // floats
+  o.melidx = off; off += (3 * nb + 1) / 2 + 1; // ints: first, len, off
+  off = (off + 1) & ~1;
+  o.wave0 = off;
+  o.per_wave = 2 * P;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, const int16_t *__restrict__ wav,
                                               const int64_t *__restrict__ wav_off,
                                               const int *__restrict__ frame_off, int B, int total_frames,
                                               float *__restrict__ mfcc) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int P = fe.P, Nc = P >> 1, L = fe.L;
-  const int per_wave = 2 * P + (Nc + 8);
-  double *A = smem + (size_t)w * per_wave;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int P = fe.P, Nc = P >> 1, L = fe.L, nb = fe.nb, nc = fe.nc;
+  const MfccLds lo = fb_mfcc_layout(P, L, nb, nc, melw_n);
+  double2 *s_tw = reinterpret_cast<double2 *>(smem + lo.tw);
+  float *s_win = reinterpret_cast<float *>(smem + lo.win);
+  float *s_melw = reinterpret_cast<float *>(smem + lo.melw);
+  float *s_dct = reinterpret_cast<float *>(smem + lo.dct);
+  float *s_lift = reinterpret_cast<float *>(smem + lo.lift);
+  int *s_mfirst = reinterpret_cast<int *>(smem + lo.melidx), *s_mlen = s_mfirst + nb, *s_moff = s_mlen + nb;
+  double *A = smem + lo.wave0 + (size_t)w * lo.per_wave;
   double *Bf = A + P;
-  double *PW = Bf + P;
-  int f = blockIdx.x * 4 + w;
-  const bool valid = f < total_frames;
-  if (!valid) f = total_frames - 1;
-  const int b = fb_find_utt(frame_off, B, f);
-  const int t = f - frame_off[b];
-  const int64_t n = wav_off[b + 1] - wav_off[b];
-  const int16_t *wv = wav + wav_off[b];
-  const int64_t start = fe.snip_edges ? (int64_t)t * fe.shift : (int64_t)t * fe.shift + fe.shift / 2 - L / 2;
-
-  // ---- load, DC removal, raw energy
-  double xs[FB_MFCC_MAXI];
-  double sum = 0.0;
-#pragma unroll
-  for (int i = 0; i < FB_MFCC_MAXI; ++i) {
-    const int s = lane + 64 * i;
-    double v = 0.0;
-    if (s < L) {
-      int64_t k = start + s;
-      while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * n - 1 - k; }
-      v = (double)wv[k];
-    }
-    xs[i] = v;
-    sum += v;  // integers: exact in any order
-  }
-  sum = fb_wave_sum(sum);
-  const double mean = fe.remove_dc ? sum / (double)L : 0.0;
-  double en = 0.0;
-#pragma unroll
-  for (int i = 0; i < FB_MFCC_MAXI; ++i) {
-    const int s = lane + 64 * i;
-    if (s < L) { xs[i] -= mean; en = fma(xs[i], xs[i], en); Bf[s] = xs[i]; }
-  }
-  double energy = fb_wave_sum(en);
+  // ---- stage the tables (float32-valued constants are stored as float in LDS)
+  for (int i = tid; i < Nc; i += 256) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
+  for (int i = tid; i < L; i += 256) s_win[i] = (float)fe.window[i];
+  for (int i = tid; i < melw_n; i += 256) s_melw[i] = (float)fe.mel_w[i];
+  for (int i = tid; i < nc * nb; i += 256) s_dct[i] = (float)fe.dct[i];
+  for (int i = tid; i < nc; i += 256) s_lift[i] = (float)fe.lifter[i];
+  for (int i = tid; i < nb; i += 256) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
   __syncthreads();
-  // ---- pre-emphasis + window, packed as P/2 complex points (re=y[2k], im=y[2k+1])
-  double en2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < FB_MFCC_MAXI; ++i) {
-    const int s = lane + 64 * i;
-    if (s < P) {
-      double y = 0.0;
-      if (s < L) {
-        const double prev = Bf[s > 0 ? s - 1 : 0];
-        y = (xs[i] - fe.preemph * prev) * fe.window[s];
-        en2 = fma(y, y, en2);
-      }
-      A[s] = y;
-    }
-  }
-  if (!fe.raw_energy) energy = fb_wave_sum(en2);
-  double log_energy = log(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
-  if (log_energy < fe.log_energy_floor) log_energy = fe.log_energy_floor;
-  __syncthreads();
-  // ---- Stockham radix-2 complex FFT of size Nc
-  double2 *src = reinterpret_cast<double2 *>(A), *dst = reinterpret_cast<double2 *>(Bf);
-  const double2 *tw = reinterpret_cast<const double2 *>(fe.tw_half);
-  for (int Ns = 1; Ns < Nc; Ns <<= 1) {
-    const int tstep = Nc / (2 * Ns);
-    for (int j = lane; j < Nc / 2; j += 64) {
-      const int k = j & (Ns - 1);
-      const double2 wv2 = tw[k * tstep];
-      const double2 v0 = src[j], x1 = src[j + Nc / 2];
-      double2 v1;
-      v1.x = x1.x * wv2.x - x1.y * wv2.y;
-      v1.y = x1.x * wv2.y + x1.y * wv2.x;
-      const int idx = ((j - k) << 1) + k;
-      dst[idx] = make_double2(v0.x + v1.x, v0.y + v1.y);
-      dst[idx + Ns] = make_double2(v0.x - v1.x, v0.y - v1.y);
-    }
-    __syncthreads();
-    double2 *tmp = src; src = dst; dst = tmp;
-  }
-  // ---- real-FFT unpack + power spectrum, bins 0..Nc
   const double2 *twf = reinterpret_cast<const double2 *>(fe.tw_full);
-  for (int k = lane; k <= Nc; k += 64) {
-    const double2 zk = src[k & (Nc - 1)];
-    const double2 zr = src[(Nc - k) & (Nc - 1)];
-    const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);  // E = (Zk + conj(Zr))/2
-    const double dr = zk.x - zr.x, di = zk.y + zr.y;                  // d = Zk - conj(Zr)
-    const double orr = 0.5 * di, oi = -0.5 * dr;                      // O = -i/2 * d
-    const double2 wk = twf[k];
-    const double xr = er + (wk.x * orr - wk.y * oi);
-    const double xi = ei + (wk.x * oi + wk.y * orr);
-    PW[k] = xr * xr + xi * xi;
-  }
-  __syncthreads();
-  // ---- mel filterbank + log   (LM aliases dst)
-  double *LM = reinterpret_cast<double *>(dst);
-  for (int m = lane; m < fe.nb; m += 64) {
-    const double *wm = fe.mel_w + fe.mel_off[m];
-    const int first = fe.mel_first[m], len = fe.mel_len[m];
-    double e = 0.0;
-    for (int i = 0; i < len; ++i) e += wm[i] * PW[first + i];
-    if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
-    LM[m] = log(e);
-  }
-  __syncthreads();
-  // ---- DCT-II, lifter, C0 <- log energy
-  for (int c = lane; c < fe.nc; c += 64) {
-    const double *dr = fe.dct + (size_t)c * fe.nb;
-    double acc = 0.0;
-    for (int m = 0; m < fe.nb; ++m) acc += dr[m] * LM[m];
-    acc *= fe.lifter[c];
-    float o = (float)acc;
-    if (c == 0 && fe.use_energy) o = (float)log_energy;
-    if (valid) mfcc[(size_t)f * fe.nc + c] = o;
+
+  // Waves are independent from here on: each owns its LDS buffers and walks its own frames, so
+  // only wave-level ordering is needed (LDS executes one wave's DS ops in order; the fence +
+  // wave_barrier pair stops the compiler from moving LDS accesses across the phase boundary).
+  for (int f = blockIdx.x * 4 + w; f < total_frames; f += gridDim.x * 4) {
+    const bool valid = true;
+    const int b = fb_find_utt(frame_off, B, f);
+    const int t = f - frame_off[b];
+    const int64_t n = wav_off[b + 1] - wav_off[b];
+    const int16_t *wv = wav + wav_off[b];
+    const int64_t start = fe.snip_edges ? (int64_t)t * fe.shift : (int64_t)t * fe.shift + fe.shift / 2 - L / 2;
+
+    // ---- load (reflect at the edges), DC removal, raw energy
+    double xs[FB_MFCC_MAXI];
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < FB_MFCC_MAXI; ++i) {
+      const int s = lane + 64 * i;
+      double v = 0.0;
+      if (s < L) {
+        int64_t k = start + s;
+        while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * n - 1 - k; }
+        v = (double)wv[k];
+      }
+      xs[i] = v;
+      sum += v;  // integers: exact in any order
+    }
+    sum = fb_wave_sum(sum);
+    const double mean = fe.remove_dc ? sum / (double)L : 0.0;
+    double en = 0.0;
+#pragma unroll
+    for (int i = 0; i < FB_MFCC_MAXI; ++i) {
+      const int s = lane + 64 * i;
+      if (s < L) { xs[i] -= mean; en = fma(xs[i], xs[i], en); Bf[s] = xs[i]; }
+    }
+    double energy = fb_wave_sum(en);
+    fb_wave_sync();
+    // ---- pre-emphasis + window, packed as P/2 complex points (re=y[2k], im=y[2k+1])
+    double en2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < FB_MFCC_MAXI; ++i) {
+      const int s = lane + 64 * i;
+      if (s < P) {
+        double y = 0.0;
+        if (s < L) {
+          const double prev = Bf[s > 0 ? s - 1 : 0];
+          y = (xs[i] - fe.preemph * prev) * (double)s_win[s];
+          en2 = fma(y, y, en2);
+        }
+        A[s] = y;
+      }
+    }
+    if (!fe.raw_energy) energy = fb_wave_sum(en2);
+    double log_energy = log(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
+    if (log_energy < fe.log_energy_floor) log_energy = fe.log_energy_floor;
+    fb_wave_sync();
+    // ---- Stockham radix-2 complex FFT of size Nc (ping-pong A <-> Bf)
+    double2 *src = reinterpret_cast<double2 *>(A), *dst = reinterpret_cast<double2 *>(Bf);
+    for (int Ns = 1; Ns < Nc; Ns <<= 1) {
+      const int tstep = Nc / (2 * Ns);
+      for (int j = lane; j < Nc / 2; j += 64) {
+        const int k = j & (Ns - 1);
+        const double2 wv2 = s_tw[k * tstep];
+        const double2 v0 = src[j], x1 = src[j + Nc / 2];
+        double2 v1;
+        v1.x = x1.x * wv2.x - x1.y * wv2.y;
+        v1.y = x1.x * wv2.y + x1.y * wv2.x;
+        const int idx = ((j - k) << 1) + k;
+        dst[idx] = make_double2(v0.x + v1.x, v0.y + v1.y);
+        dst[idx + Ns] = make_double2(v0.x - v1.x, v0.y - v1.y);
+      }
+      fb_wave_sync();
+      double2 *tmp = src; src = dst; dst = tmp;
+    }
+    // ---- real-FFT unpack + power spectrum, bins 0..Nc  -> PW (aliases dst)
+    double pwv[FB_MFCC_MAXI];
+#pragma unroll
+    for (int i = 0; i < FB_MFCC_MAXI; ++i) {
+      const int k = lane + 64 * i;
+      pwv[i] = 0.0;
+      if (k <= Nc) {
+        const double2 zk = src[k & (Nc - 1)];
+        const double2 zr = src[(Nc - k) & (Nc - 1)];
+        const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);  // E = (Zk + conj(Zr))/2
+        const double dr = zk.x - zr.x, di = zk.y + zr.y;                  // d = Zk - conj(Zr)
+        const double orr = 0.5 * di, oi = -0.5 * dr;                      // O = -i/2 * d
+        const double2 wk = twf[k];
+        const double xr = er + (wk.x * orr - wk.y * oi);
+        const double xi = ei + (wk.x * oi + wk.y * orr);
+        pwv[i] = xr * xr + xi * xi;
+      }
+    }
+    double *PW = reinterpret_cast<double *>(dst);
+#pragma unroll
+    for (int i = 0; i < FB_MFCC_MAXI; ++i) {
+      const int k = lane + 64 * i;
+      if (k <= Nc) PW[k] = pwv[i];
+    }
+    fb_wave_sync();
+    // ---- mel filterbank + log: two lanes per filter, LM aliases src
+    double *LM = reinterpret_cast<double *>(src);
+    for (int m2 = lane; m2 < 2 * ((nb + 31) / 32) * 32; m2 += 64) {
+      const int m = m2 >> 1, part = m2 & 1;
+      double e = 0.0;
+      if (m < nb) {
+        const float *wm = s_melw + s_moff[m];
+        const int first = s_mfirst[m], len = s_mlen[m];
+        const int h0 = (len + 1) >> 1;
+        const int i0 = part ? h0 : 0, i1 = part ? len : h0;
+        for (int i = i0; i < i1; ++i) e = fma((double)wm[i], PW[first + i], e);
+      }
+      e += __shfl_xor(e, 1, 64);
+      if (m < nb && part == 0) {
+        if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
+        LM[m] = log(e);
+      }
+    }
+    fb_wave_sync();
+    // ---- DCT-II, lifter, C0 <- log energy: two lanes per coefficient
+    for (int c2 = lane; c2 < 2 * ((nc + 31) / 32) * 32; c2 += 64) {
+      const int c = c2 >> 1, part = c2 & 1;
+      double acc = 0.0;
+      if (c < nc) {
+        const float *dr = s_dct + c * nb;
+        const int h0 = (nb + 1) >> 1;
+        const int i0 = part ? h0 : 0, i1 = part ? nb : h0;
+        for (int m = i0; m < i1; ++m) acc = fma((double)dr[m], LM[m], acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      if (c < nc && part == 0) {
+        acc *= (double)s_lift[c];
+        float o = (float)acc;
+        if (c == 0 && fe.use_energy) o = (float)log_energy;
+        if (valid) mfcc[(size_t)f * nc + c] = o;
+      }
+    }
+    fb_wave_sync();  // buffers are reused by the next frame
   }
 }
 
-void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, const int16_t *wav, const int64_t *wav_off,
-                    const int *frame_off, int B, int total_frames, float *mfcc) {
+int fb_mfcc_layout_doubles(int P, int L, int nb, int nc, int melw_n) {
+  const MfccLds lo = fb_mfcc_layout(P, L, nb, nc, melw_n);
+  return lo.wave0 + 4 * lo.per_wave;
+}
+
+void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav,
+                    const int64_t *wav_off, const int *frame_off, int B, int total_frames, float *mfcc) {
   if (total_frames <= 0) return;
-  const int per_wave = 2 * fe.P + (fe.P / 2 + 8);
-  size_t shm = sizeof(double) * (size_t)per_wave * 4;
-  hipLaunchKernelGGL(k_mfcc, dim3((total_frames + 3) / 4), dim3(256), shm, s, fe, wav, wav_off, frame_off, B,
+  const MfccLds lo = fb_mfcc_layout(fe.P, fe.L, fe.nb, fe.nc, melw_n);
+  size_t shm = sizeof(double) * (size_t)(lo.wave0 + 4 * lo.per_wave);
+  int blocks = (total_frames + 3) / 4;
+  if (blocks > 768) blocks = 768;
+  hipLaunchKernelGGL(k_mfcc, dim3(blocks), dim3(256), shm, s, fe, melw_n, wav, wav_off, frame_off, B,
                      total_frames, mfcc);
 }
 
@@ -229,97 +307,123 @@ void fb_launch_rowscan(hipStream_t s, const int *tv, int B, int *row_off) {
 }
 
 // ------------------------------------------------------------------ deltas
+// One workgroup per 32-frame chunk of one utterance.  Besides add-deltas it leaves the per-chunk
+// column sums of the delta features (float64, fixed order) so that the whole-utterance CMVN mean
+// needs no second pass over the features and no atomics.
+#define FB_CHUNK 32
 __global__ __launch_bounds__(256) void k_deltas(FbFrontendDev fe, const float *__restrict__ mfcc,
-                                                const int *__restrict__ frame_off, int B, int total_frames,
-                                                float *__restrict__ dfeat) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int f = (int)(gid / fe.nc), d = (int)(gid % fe.nc);
-  if (f >= total_frames) return;
-  const int b = fb_find_utt(frame_off, B, f);
-  const int base = frame_off[b], T = frame_off[b + 1] - base, t = f - base;
+                                                const int *__restrict__ frame_off,
+                                                const int *__restrict__ chunk_off, int B,
+                                                float *__restrict__ dfeat, double *__restrict__ chunk_sum) {
+  extern __shared__ float s_df[];  // [FB_CHUNK][dim]
+  const int ch = blockIdx.x;
+  const int b = fb_find_utt(chunk_off, B, ch);
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const int t0 = (ch - chunk_off[b]) * FB_CHUNK;
+  const int nt = min(FB_CHUNK, T - t0);
+  const int nc = fe.nc, dim = fe.dim;
   const int maxlen = 2 * fe.order * fe.dwin + 1;
-  for (int i = 0; i <= fe.order; ++i) {
-    const double *sc = fe.dscale + (size_t)i * maxlen;
-    const int off = i * fe.dwin;
-    double acc = 0.0;
-    for (int j = -off; j <= off; ++j) {
-      int tt = t + j;
-      tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-      const double sv = sc[j + off];
-      if (sv != 0.0) acc = __dadd_rn(acc, __dmul_rn(sv, (double)mfcc[(size_t)(base + tt) * fe.nc + d]));
+  for (int it = threadIdx.x; it < nt * nc; it += 256) {
+    const int tl = it / nc, d = it - tl * nc, t = t0 + tl;
+    for (int i = 0; i <= fe.order; ++i) {
+      const double *sc = fe.dscale + (size_t)i * maxlen;
+      const int off = i * fe.dwin;
+      double acc = 0.0;
+      for (int j = -off; j <= off; ++j) {
+        int tt = t + j;
+        tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+        const double sv = sc[j + off];
+        if (sv != 0.0) acc = __dadd_rn(acc, __dmul_rn(sv, (double)mfcc[(size_t)(base + tt) * nc + d]));
+      }
+      const float o = (float)acc;
+      s_df[tl * dim + i * nc + d] = o;
+      dfeat[(size_t)(base + t) * dim + i * nc + d] = o;
     }
-    dfeat[(size_t)f * fe.dim + i * fe.nc + d] = (float)acc;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dim; d += 256) {
+    double acc = 0.0;
+    for (int tl = 0; tl < nt; ++tl) acc += (double)s_df[tl * dim + d];
+    chunk_sum[(size_t)ch * dim + d] = acc;
   }
 }
-void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
-                      int total_frames, float *dfeat) {
-  int64_t n = (int64_t)total_frames * fe.nc;
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_deltas, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fe, mfcc, frame_off, B,
-                     total_frames, dfeat);
+void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
+                      const int *chunk_off, int B, int total_chunks, float *dfeat, double *chunk_sum) {
+  if (total_chunks <= 0) return;
+  hipLaunchKernelGGL(k_deltas, dim3(total_chunks), dim3(256), sizeof(float) * FB_CHUNK * fe.dim, s, fe, mfcc,
+                     frame_off, chunk_off, B, dfeat, chunk_sum);
 }
 
 // -------------------------------------------------------- CMVN + selection
-// One block per utterance.  T <= cmn_window: every window is the whole utterance
-// (column mean); otherwise a per-dimension running window sum in Kaldi's order.
+// apply-cmvn-sliding --center=true --norm-vars=false + select-voiced-frames.
+// Fast path (T <= cmn_window, every NES batch): every window is the whole utterance, so the
+// mean is the sum of the chunk sums; one workgroup per 32-frame chunk.
 __global__ __launch_bounds__(256) void k_cmvn(FbFrontendDev fe, const float *__restrict__ dfeat,
                                               const int *__restrict__ frame_off,
+                                              const int *__restrict__ chunk_off,
+                                              const double *__restrict__ chunk_sum,
                                               const int *__restrict__ vrank, const int *__restrict__ row_off,
-                                              float *__restrict__ feats) {
-  extern __shared__ double s_sum[];  // [groups][dim]
+                                              int B, float *__restrict__ feats) {
+  extern __shared__ double s_sum[];  // [dim]
+  const int ch = blockIdx.x, dim = fe.dim;
+  const int b = fb_find_utt(chunk_off, B, ch);
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  if (T > fe.cmn_window) return;  // handled by k_cmvn_sliding
+  const int c0 = chunk_off[b], c1 = chunk_off[b + 1];
+  for (int d = threadIdx.x; d < dim; d += 256) {
+    double acc = 0.0;
+    for (int c = c0; c < c1; ++c) acc += chunk_sum[(size_t)c * dim + d];
+    s_sum[d] = acc;
+  }
+  __syncthreads();
+  const int t0 = (ch - c0) * FB_CHUNK;
+  const int nt = min(FB_CHUNK, T - t0);
+  const int rbase = row_off[b];
+  const double alpha = (double)(float)(-1.0 / (double)T);
+  for (int i = threadIdx.x; i < nt * dim; i += 256) {
+    const int tl = i / dim, d = i - tl * dim;
+    const int r = vrank[base + t0 + tl];
+    if (r >= 0)
+      feats[(size_t)(rbase + r) * dim + d] =
+          (float)__dadd_rn((double)dfeat[(size_t)(base + t0 + tl) * dim + d], __dmul_rn(alpha, s_sum[d]));
+  }
+}
+// General path (T > cmn_window): per-dimension running window sum in Kaldi's order, one
+// workgroup per utterance (long enrolment / test utterances, never inside the NES loop).
+__global__ __launch_bounds__(256) void k_cmvn_sliding(FbFrontendDev fe, const float *__restrict__ dfeat,
+                                                      const int *__restrict__ frame_off,
+                                                      const int *__restrict__ vrank,
+                                                      const int *__restrict__ row_off,
+                                                      float *__restrict__ feats) {
   const int b = blockIdx.x, dim = fe.dim;
   const int base = frame_off[b], T = frame_off[b + 1] - base;
   const int rbase = row_off[b];
   const int Wn = fe.cmn_window;
-  if (T <= 0) return;
-  if (T <= Wn) {
-    const int groups = 256 / dim > 0 ? 256 / dim : 1;
-    const int g = threadIdx.x / dim, d = threadIdx.x % dim;
-    if (g < groups) {
-      const int per = (T + groups - 1) / groups;
-      const int lo = g * per, hi = min(T, lo + per);
-      double acc = 0.0;
-      for (int t = lo; t < hi; ++t) acc += (double)dfeat[(size_t)(base + t) * dim + d];
-      s_sum[g * dim + d] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < dim) {
-      double acc = 0.0;
-      for (int g2 = 0; g2 < groups; ++g2) acc += s_sum[g2 * dim + threadIdx.x];
-      s_sum[threadIdx.x] = acc;
-    }
-    __syncthreads();
-    const double alpha = (double)(float)(-1.0 / (double)T);
-    for (int i = threadIdx.x; i < T * dim; i += 256) {
-      const int t = i / dim, d2 = i - t * dim;
+  if (T <= Wn) return;
+  for (int d = threadIdx.x; d < dim; d += 256) {
+    double cur = 0.0;
+    int lwb = 0, lwe = 0;
+    for (int t = 0; t < T; ++t) {
+      int wb = t - Wn / 2, we = wb + Wn;
+      if (wb < 0) { we -= wb; wb = 0; }
+      if (we > T) { wb -= (we - T); we = T; if (wb < 0) wb = 0; }
+      for (; lwe < we; ++lwe) cur += (double)dfeat[(size_t)(base + lwe) * dim + d];
+      for (; lwb < wb; ++lwb) cur -= (double)dfeat[(size_t)(base + lwb) * dim + d];
       const int r = vrank[base + t];
-      if (r >= 0)
-        feats[(size_t)(rbase + r) * dim + d2] =
-            (float)__dadd_rn((double)dfeat[(size_t)(base + t) * dim + d2], __dmul_rn(alpha, s_sum[d2]));
-    }
-  } else {
-    for (int d = threadIdx.x; d < dim; d += 256) {
-      double cur = 0.0;
-      int lwb = 0, lwe = 0;
-      for (int t = 0; t < T; ++t) {
-        int wb = t - Wn / 2, we = wb + Wn;
-        if (wb < 0) { we -= wb; wb = 0; }
-        if (we > T) { wb -= (we - T); we = T; if (wb < 0) wb = 0; }
-        for (; lwe < we; ++lwe) cur += (double)dfeat[(size_t)(base + lwe) * dim + d];
-        for (; lwb < wb; ++lwb) cur -= (double)dfeat[(size_t)(base + lwb) * dim + d];
-        const int r = vrank[base + t];
-        if (r >= 0) {
-          const double alpha = (double)(float)(-1.0 / (double)(we - wb));
-          feats[(size_t)(rbase + r) * dim + d] =
-              (float)__dadd_rn((double)dfeat[(size_t)(base + t) * dim + d], __dmul_rn(alpha, cur));
-        }
+      if (r >= 0) {
+        const double alpha = (double)(float)(-1.0 / (double)(we - wb));
+        feats[(size_t)(rbase + r) * dim + d] =
+            (float)__dadd_rn((double)dfeat[(size_t)(base + t) * dim + d], __dmul_rn(alpha, cur));
       }
     }
   }
 }
 void fb_launch_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *dfeat, const int *frame_off,
-                    const int *vrank, const int *row_off, int B, float *feats) {
-  const int groups = 256 / fe.dim > 0 ? 256 / fe.dim : 1;
-  size_t shm = sizeof(double) * (size_t)groups * fe.dim;
-  hipLaunchKernelGGL(k_cmvn, dim3(B), dim3(256), shm, s, fe, dfeat, frame_off, vrank, row_off, feats);
+                    const int *chunk_off, const double *chunk_sum, const int *vrank, const int *row_off, int B,
+                    int total_chunks, bool any_long, float *feats) {
+  if (total_chunks <= 0) return;
+  hipLaunchKernelGGL(k_cmvn, dim3(total_chunks), dim3(256), sizeof(double) * fe.dim, s, fe, dfeat, frame_off,
+                     chunk_off, chunk_sum, vrank, row_off, B, feats);
+  if (any_long)
+    hipLaunchKernelGGL(k_cmvn_sliding, dim3(B), dim3(256), 0, s, fe, dfeat, frame_off, vrank, row_off, feats);
 }

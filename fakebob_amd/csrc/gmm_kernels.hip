@@ -56,13 +56,22 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
   {
     const bool ok = row < n_rows;
     const float *fr = feats + (size_t)(ok ? row : 0) * g.D + h * KH;
+    if (g.D == 2 * KH) {  // rows are 16-byte aligned and fully used: 9 x 16-byte loads per lane
 #pragma unroll
-    for (int i = 0; i < KH; ++i) {
-      const int d = h * KH + i;
-      float v = (ok && d < g.D) ? fr[i] : 0.0f;
-      xf[i] = v;
-      xq[i] = __fmul_rn(v, v);
+      for (int q = 0; q < KH / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(fr + 4 * q);
+        xf[4 * q + 0] = ok ? v.x : 0.0f; xf[4 * q + 1] = ok ? v.y : 0.0f;
+        xf[4 * q + 2] = ok ? v.z : 0.0f; xf[4 * q + 3] = ok ? v.w : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KH; ++i) {
+        const int d = h * KH + i;
+        xf[i] = (ok && d < g.D) ? fr[i] : 0.0f;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < KH; ++i) xq[i] = __fmul_rn(xf[i], xf[i]);
   }
   for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
 
@@ -73,10 +82,12 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
 
   float4 stage[NST];
   // prologue: item 0 -> slot 0
+  // (indices are clamped instead of predicated: a predicated "load or keep" forces the staging
+  //  registers to scratch and serialises every load behind s_waitcnt vmcnt(0))
 #pragma unroll
   for (int s = 0; s < NST; ++s) {
-    const int q = tid + 256 * s;
-    if (q < IMG4) reinterpret_cast<float4 *>(slot0)[q] = gimg[q];
+    const int q = min(tid + 256 * s, IMG4 - 1);
+    reinterpret_cast<float4 *>(slot0)[q] = gimg[q];
   }
   __syncthreads();
 
@@ -87,14 +98,10 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
   for (int it = 0; it < total_items; ++it) {
     float *cur = (it & 1) ? slot1 : slot0;
     float *nxt = (it & 1) ? slot0 : slot1;
-    const bool more = (it + 1) < total_items;
-    if (more) {
-      const float4 *src = gimg + (size_t)(it + 1) * IMG4;
+    {  // unconditional prefetch of the next item (the last iteration re-loads its own item)
+      const float4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
 #pragma unroll
-      for (int s = 0; s < NST; ++s) {
-        const int q = tid + 256 * s;
-        if (q < IMG4) stage[s] = src[q];
-      }
+      for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
     }
     const int item = it % g.n_items;
     const int model = g.item_model[item];
@@ -144,13 +151,8 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
       st_m[model * 256 + tid] = m_new;
       st_s[model * 256 + tid] = ssum;
     }
-    if (more) {
 #pragma unroll
-      for (int s = 0; s < NST; ++s) {
-        const int q = tid + 256 * s;
-        if (q < IMG4) reinterpret_cast<float4 *>(nxt)[q] = stage[s];
-      }
-    }
+    for (int s = 0; s < NST; ++s) reinterpret_cast<float4 *>(nxt)[min(tid + 256 * s, IMG4 - 1)] = stage[s];
     __syncthreads();
   }
 

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
                                                  uint32_t iter, uint32_t stream,
                                                  const double *__restrict__ noise_pos,
                                                  int16_t *__restrict__ q,
-                                                 double *__restrict__ dist_part) {
+                                                 double *__restrict__ dist_part,
+                                                 float *__restrict__ zbuf) {
   const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
   const int64_t n0 = n4 * 4;
@@ -35,6 +36,11 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
         fb_noise4(seed, iter, stream, (uint32_t)n4, (uint32_t)j, zf);
 #pragma unroll
         for (int k = 0; k < 4; ++k) z[k] = (double)zf[k];
+        if (zbuf) {  // keep the float32 normals for the gradient kernel (4.8 MB at spd=50, N=48000)
+          float *zp = zbuf + (int64_t)j * N + n0;
+          if (cnt == 4 && ((N & 3) == 0)) *reinterpret_cast<float4 *>(zp) = make_float4(zf[0], zf[1], zf[2], zf[3]);
+          else for (int k = 0; k < cnt; ++k) zp[k] = zf[k];
+        }
       }
       int16_t *qp = q + (int64_t)(1 + j) * N + n0;
       int16_t *qm = q + (int64_t)(1 + half + j) * N + n0;
@@ -76,12 +82,12 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
 
 void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
-                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part) {
+                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part, float *zbuf) {
   int64_t n4 = (N + 3) / 4;
   dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)(half > 0 ? half : 1));
   if (n_dist_part) *n_dist_part = (int)grid.x;
   hipLaunchKernelGGL(k_perturb, grid, dim3(256), 0, s, adver, audio, N, half, sigma, seed, iter, stream,
-                     noise_pos, q, dist_part);
+                     noise_pos, q, dist_part, zbuf);
 }
 
 __global__ __launch_bounds__(256) void k_quantize(const double *__restrict__ x, int64_t n, double scale,
@@ -248,19 +254,14 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
                      threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out);
 }
 
-// Kept out of line on purpose: with the 8+ fully inlined copies that the pairwise-sum unrolling
-// creates, hipcc (ROCm 7.2, -O1 and -O3) corrupts the second Box-Muller output (z1) of some
-// copies -- caught by the philox-vs-explicit-noise parity test.  One shared copy is correct.
-__device__ __noinline__ void fb_noise4_noinline(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t n4,
-                                                uint32_t j, float z[4]) {
-  fb_noise4(seed, iter, stream, n4, j, z);
-}
 // ------------------------------------------------------------- grad + update
 // estimate_grad = np.mean(loss.flatten() * noise, axis=1) / sigma   (FAKEBOB.py:244)
 // then grad = m*pre + (1-m)*grad (:193), adver -= lr*sign(grad), clip (:202-203).
+// The normals come back from the buffer k_perturb wrote (zbuf, float32 [half][N]) or from the
+// caller's float64 tensor (noise_pos [N][half]); products are summed in numpy's pairwise order.
 __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ loss, int64_t N, int half,
-                                                     double sigma, uint64_t seed, uint32_t iter,
-                                                     uint32_t stream, const double *__restrict__ noise_pos,
+                                                     double sigma, const float *__restrict__ zbuf,
+                                                     const double *__restrict__ noise_pos,
                                                      double *__restrict__ grad_out, int do_update,
                                                      double momentum, double one_minus_m, double lr,
                                                      double epsilon, const double *__restrict__ audio,
@@ -269,59 +270,38 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
   const int spd = 2 * half;
   for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
   __syncthreads();
-  const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 samples per thread
-  const int64_t n0 = n4 * 4;
-  if (n0 >= N) return;
-  const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
-  auto el = [&](int i) -> D4 {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  auto el = [&](int i) -> D1 {
     const int j = i < half ? i : i - half;
-    D4 z;
-    if (noise_pos) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) z.v[k] = k < cnt ? noise_pos[(n0 + k) * half + j] : 0.0;
-    } else {
-      float zf[4];
-      fb_noise4_noinline(seed, iter, stream, (uint32_t)n4, (uint32_t)j, zf);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) z.v[k] = (double)zf[k];
-    }
-    const double l = s_loss[i];
-    D4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r.v[k] = __dmul_rn(l, i >= half ? -z.v[k] : z.v[k]);
-    return r;
+    double z = noise_pos ? noise_pos[n * half + j] : (double)zbuf[(int64_t)j * N + n];
+    if (i >= half) z = -z;
+    return D1{__dmul_rn(s_loss[i], z)};
   };
-  D4 sum = D4::zero();
-  if (spd > 0) sum = fb_np_sum<D4>(el, 0, spd);
-  for (int k = 0; k < cnt; ++k) {
-    const int64_t n = n0 + k;
-    double g = 0.0;
-    if (spd > 0) g = __ddiv_rn(__ddiv_rn(sum.v[k], (double)spd), sigma);
-    if (grad_out) grad_out[n] = g;
-    if (do_update) {
-      double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
-      grad_m[n] = gm;
-      double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
-      double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
-      double au = audio[n];
-      double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
-      lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
-      hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
-      a = a < lo ? lo : a;
-      a = a > hi ? hi : a;
-      adver[n] = a;
-    }
+  double g = 0.0;
+  if (spd > 0) g = __ddiv_rn(__ddiv_rn(fb_np_sum<D1>(el, 0, spd).v, (double)spd), sigma);
+  if (grad_out) grad_out[n] = g;
+  if (do_update) {
+    double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
+    grad_m[n] = gm;
+    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
+    double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
+    double au = audio[n];
+    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
+    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
+    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
+    a = a < lo ? lo : a;
+    a = a > hi ? hi : a;
+    adver[n] = a;
   }
 }
 
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
-                           uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
-                           double *grad_out, int do_update, double momentum, double one_minus_m,
-                           double lr, double epsilon, const double *audio, double *grad_m,
-                           double *adver) {
-  int blocks = (int)(((N + 3) / 4 + 255) / 256);
+                           const float *zbuf, const double *noise_pos, double *grad_out, int do_update,
+                           double momentum, double one_minus_m, double lr, double epsilon,
+                           const double *audio, double *grad_m, double *adver) {
+  int blocks = (int)((N + 255) / 256);
   size_t shm = sizeof(double) * (size_t)(2 * half > 0 ? 2 * half : 1);
-  hipLaunchKernelGGL(k_grad_update, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, seed, iter,
-                     stream, noise_pos, grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio,
-                     grad_m, adver);
+  hipLaunchKernelGGL(k_grad_update, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, noise_pos,
+                     grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio, grad_m, adver);
 }

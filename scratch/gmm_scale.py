@@ -1,0 +1,12 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+from fakebob_amd.engine import Engine, nes_params
+from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
+for C in (512, 1024, 2048, 4096):
+    ubm, spk = synthetic_gmm_system(5, C, 72)
+    e = Engine(0); e.load_gmm([ubm] + spk); e.set_system("OSI")
+    p = nes_params("OSI", "targeted", samples_per_draw=50, target=0, threshold=0.2277)
+    e.get_grad(p, synthetic_audio(0, 48000), it=0, want_grad=False)
+    ms, rows = e.bench_gmm_kernel(50)
+    print("C %d gmm_ms %.4f rows %d  alg TF/s %.1f" % (C, ms, rows, 6*C*4*72*rows/ms/1e9))
+    e.close()

@@ -36,7 +36,8 @@ def test_mfcc_parity(engine, oracle):
         err = np.abs(mg.astype(np.float64) - mo.astype(np.float64))
         assert err.max() <= 2e-5 * max(1.0, np.abs(mo).max()), err.max()
         # float32 storage point: almost every value must be bit-identical
-        assert np.mean(mg.view(np.uint32) != mo.view(np.uint32)) < 0.02
+        differs = (mg.view(np.uint32) != mo.view(np.uint32)) & (err > 1e-9)  # ignore +-1e-15 residues of exact zeros
+        assert np.mean(differs) < 0.02
 
 
 def test_frontend_feats_parity(engine, oracle):
