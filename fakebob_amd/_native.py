@@ -42,11 +42,24 @@ class NesParams(C.Structure):
     ]
 
 
+class IvectorSystem(C.Structure):
+    """fb_ivector_system"""
+    _fields_ = [
+        ("C", C.c_int), ("D", C.c_int), ("R", C.c_int), ("L", C.c_int), ("S", C.c_int),
+        ("lda_cols", C.c_int), ("num_gselect", C.c_int), ("min_post", C.c_double),
+        ("prior_offset", C.c_double), ("fg_weights", C.c_void_p), ("fg_means_invcovars", C.c_void_p),
+        ("fg_inv_covars", C.c_void_p), ("ie_M", C.c_void_p), ("ie_sigma_inv", C.c_void_p),
+        ("mean_vec", C.c_void_p), ("lda", C.c_void_p), ("plda_mean", C.c_void_p),
+        ("plda_transform", C.c_void_p), ("plda_psi", C.c_void_p), ("enrolled", C.c_void_p),
+        ("z_mean", C.c_void_p), ("z_std", C.c_void_p),
+    ]
+
+
 EXPORTS = [
     "fb_last_error", "fb_version", "fb_device_count", "fb_engine_create", "fb_engine_destroy",
-    "fb_default_frontend", "fb_set_frontend", "fb_load_gmm", "fb_set_system", "fb_num_speakers",
+    "fb_default_frontend", "fb_set_frontend", "fb_load_gmm", "fb_load_ivector", "fb_set_system", "fb_num_speakers",
     "fb_score_i16", "fb_score_f64", "fb_system_scores", "fb_get_grad", "fb_attack",
-    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_stats",
+    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_ivectors", "fb_stats",
     "fb_bench_gmm_kernel", "fb_bench_nes",
 ]
 

@@ -87,6 +87,13 @@ struct fb_engine {
   FbGmmDev gmm;
   DevBuf gmm_images, gmm_items;
   int n_groups = 0;
+  // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
+  int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
+  int n_out = 0;  // columns of `raw`: models (GMM) or enrolled speakers (i-vector)
+  FbIvDev iv;
+  DevBuf iv_fg, iv_tri, iv_sim, iv_u, iv_backend;
+  DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_ivec, iv_fail;
+  int iv_kchunks = 96;
   // system
   int task = FB_TASK_OSI;
   DevBuf zmean, zstd;
@@ -138,7 +145,9 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
-                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64};
+                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
+                    &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_ivec, &e->iv_fail};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -355,6 +364,8 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.item_model = e->gmm_items.as<int>();
   e->n_groups = G;
   e->have_gmm = true;
+  e->kind = 0;
+  e->n_out = M;
   // default system: OSI (UBM first) without z-norm
   e->h_zmean.assign(M, 0.0);
   e->h_zstd.assign(M, 1.0);
@@ -369,7 +380,8 @@ extern "C" int fb_set_system(fb_engine *e, int task, const double *z_mean, const
   if (!e) return fb_fail(FB_E_ARG, "null engine");
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "load a model first");
   if (task != FB_TASK_OSI && task != FB_TASK_CSI && task != FB_TASK_SV) return fb_fail(FB_E_ARG, "bad task");
-  const int M = e->gmm.M;
+  if (e->kind == 1) return fb_fail(FB_E_STATE, "i-vector systems take their task and z-norm from fb_load_ivector");
+  const int M = e->n_out;
   if (task != FB_TASK_CSI && M < 2) return fb_fail(FB_E_ARG, "OSI/SV need the UBM + >=1 speaker model");
   if (task == FB_TASK_SV && M != 2) return fb_fail(FB_E_ARG, "SV takes exactly [ubm, speaker]");
   HIPCHK(hipSetDevice(e->device));
@@ -386,7 +398,8 @@ extern "C" int fb_set_system(fb_engine *e, int task, const double *z_mean, const
 
 extern "C" int fb_num_speakers(fb_engine *e) {
   if (!e || !e->have_gmm) return 0;
-  return e->task == FB_TASK_CSI ? e->gmm.M : e->gmm.M - 1;
+  if (e->kind == 1) return e->n_out;
+  return e->task == FB_TASK_CSI ? e->n_out : e->n_out - 1;
 }
 
 // ------------------------------------------------------- scoring pipeline
@@ -443,9 +456,11 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
   const int n_chunks = choose_chunks(g, total_frames);
-  FBCHK(e->part_m.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
-  FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
-  FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * g.M));
+  if (e->kind == 0) {
+    FBCHK(e->part_m.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
+    FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
+  }
+  FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * e->n_out));
   hipStream_t s = e->stream;
   fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), B, total_frames,
                  e->mfcc.as<float>());
@@ -458,12 +473,42 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
                  e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), B, total_chunks, e->any_long,
                  e->feats.as<float>());
-  if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
-  fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
-                e->part_m.as<float>(), e->part_s.as<float>());
-  if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
-  fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
-                         e->row_off.as<int>(), B, e->raw.as<double>());
+  if (e->kind == 0) {
+    if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
+    fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
+                  e->part_m.as<float>(), e->part_s.as<float>());
+    if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
+    fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
+                           e->row_off.as<int>(), B, e->raw.as<double>());
+  } else {
+    const FbIvDev &iv = e->iv;
+    const int64_t Q = (int64_t)iv.C * iv.D;
+    FBCHK(e->iv_ll.ensure(sizeof(float) * (size_t)total_frames * iv.Cpad));
+    FBCHK(e->iv_sel.ensure(sizeof(int) * (size_t)total_frames * iv.nsel));
+    FBCHK(e->iv_post.ensure(sizeof(float) * (size_t)total_frames * iv.nsel));
+    FBCHK(e->iv_gamma.ensure(sizeof(double) * (size_t)B * iv.C));
+    FBCHK(e->iv_X.ensure(sizeof(double) * (size_t)B * Q));
+    FBCHK(e->iv_linp.ensure(sizeof(double) * (size_t)e->iv_kchunks * B * iv.R));
+    FBCHK(e->iv_quad.ensure(sizeof(double) * (size_t)B * iv.triR));
+    FBCHK(e->iv_A.ensure(sizeof(double) * (size_t)B * iv.R * iv.R));
+    FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
+    FBCHK(e->iv_fail.ensure(sizeof(int)));
+    HIPCHK(hipMemsetAsync(e->iv_fail.p, 0, sizeof(int), s));
+    // the whole extraction chain is timed as "the dominant kernel group" when bench asks for it
+    if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
+    fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
+                       e->iv_ll.as<float>());
+    fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
+                             total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>());
+    fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_sel.as<int>(),
+                       e->iv_post.as<float>(), B, e->iv_gamma.as<double>(), e->iv_X.as<double>());
+    fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, e->iv_kchunks,
+                          e->iv_linp.as<double>(), e->iv_quad.as<double>());
+    fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
+                       e->iv_A.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
+    if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
+  }
   HIPCHK(hipGetLastError());
   e->last_total_frames = total_frames;
   e->last_B = B;
@@ -485,9 +530,14 @@ static int ensure_host_tv(fb_engine *e, int B) {
 
 static int finish_score(fb_engine *e, int B, double *raw, int *tv) {
   FBCHK(ensure_host_tv(e, B));
-  HIPCHK(hipMemcpyAsync(raw, e->raw.p, sizeof(double) * (size_t)B * e->gmm.M, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(raw, e->raw.p, sizeof(double) * (size_t)B * e->n_out, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_tv, e->tv.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->kind == 1) {
+    int fail = 0;
+    HIPCHK(hipMemcpy(&fail, e->iv_fail.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (fail) return fb_fail(FB_E_ARG, "i-vector system of utterance %d is not positive definite", fail - 1);
+  }
   int bad = -1;
   for (int b = 0; b < B; ++b) {
     if (tv) tv[b] = e->h_tv[b];
@@ -535,8 +585,8 @@ extern "C" int fb_score_f64(fb_engine *e, const double *audio, const int64_t *of
 extern "C" int fb_system_scores(fb_engine *e, const double *raw, int B, double *scores) {
   if (!e || !raw || !scores || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no model loaded");
-  const int M = e->gmm.M;
-  if (e->task == FB_TASK_CSI) {
+  const int M = e->n_out;
+  if (e->task == FB_TASK_CSI || e->kind == 1) {
     for (int b = 0; b < B; ++b)
       for (int m = 0; m < M; ++m)
         scores[(size_t)b * M + m] = (raw[(size_t)b * M + m] - e->h_zmean[m]) / e->h_zstd[m];
@@ -545,6 +595,205 @@ extern "C" int fb_system_scores(fb_engine *e, const double *raw, int B, double *
     for (int b = 0; b < B; ++b)
       for (int s = 0; s < S; ++s) scores[(size_t)b * S + s] = raw[(size_t)b * M + 1 + s] - raw[(size_t)b * M];
   }
+  return FB_OK;
+}
+
+
+// ----------------------------------------------------------------- i-vector
+// in-place Cholesky of a dense SPD matrix (lower), returns false when not PD
+static bool host_chol(std::vector<double> &A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = v / d;
+    }
+  }
+  return true;
+}
+static void host_chol_solve(const std::vector<double> &Lm, int n, double *b) {
+  for (int i = 0; i < n; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= Lm[(size_t)i * n + k] * b[k];
+    b[i] = v / Lm[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = b[i];
+    for (int k = i + 1; k < n; ++k) v -= Lm[(size_t)k * n + i] * b[k];
+    b[i] = v / Lm[(size_t)i * n + i];
+  }
+}
+
+// raw i-vector -> PLDA space, host float64 (same math as k_iv_backend; used once per enrolled
+// speaker at load time): ivector-subtract-global-mean | transform-vec | ivector-normalize-length,
+// then Plda::TransformIvector (normalize_length, n = 1)  ([EXT] SURVEY.md A.10)
+static void host_backend(const fb_ivector_system *sy, const float *ivec, double *y) {
+  const int R = sy->R, L = sy->L;
+  std::vector<double> x(R), z(L);
+  for (int r = 0; r < R; ++r) x[r] = (double)ivec[r] - (double)sy->mean_vec[r];
+  double nrm = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const float *row = sy->lda + (size_t)l * sy->lda_cols;
+    double acc = sy->lda_cols == R + 1 ? (double)row[R] : 0.0;
+    for (int r = 0; r < R; ++r) acc += (double)row[r] * x[r];
+    z[l] = acc;
+    nrm += acc * acc;
+  }
+  const double ratio = sqrt(nrm) / sqrt((double)L);
+  if (ratio != 0.0) for (int l = 0; l < L; ++l) z[l] /= ratio;
+  double dot = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double *row = sy->plda_transform + (size_t)l * L;
+    double acc = 0.0;
+    for (int m = 0; m < L; ++m) acc += row[m] * (z[m] - sy->plda_mean[m]);
+    y[l] = acc;
+    dot += acc * acc / (sy->plda_psi[l] + 1.0);
+  }
+  const double nf = sqrt((double)L / dot);
+  for (int l = 0; l < L; ++l) y[l] *= nf;
+}
+
+extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int task) {
+  if (!e || !sy) return fb_fail(FB_E_ARG, "null argument");
+  if (task != FB_TASK_OSI && task != FB_TASK_CSI && task != FB_TASK_SV) return fb_fail(FB_E_ARG, "bad task");
+  const int C = sy->C, D = sy->D, R = sy->R, L = sy->L, S = sy->S;
+  if (C <= 0 || D <= 0 || R <= 0 || L <= 0 || S <= 0) return fb_fail(FB_E_ARG, "bad i-vector system shape");
+  if (!e->have_fe || e->fe.dim != D) return fb_fail(FB_E_ARG, "UBM dim %d != front-end feature dim %d", D, e->have_fe ? e->fe.dim : -1);
+  if (R > 512 || L > 512 || D > 80 || D > 255) return fb_fail(FB_E_ARG, "unsupported sizes R=%d L=%d D=%d (R,L <= 512, D <= 80)", R, L, D);
+  if (S > 60) return fb_fail(FB_E_ARG, "at most 60 enrolled speakers per engine");
+  if (task == FB_TASK_SV && S != 1) return fb_fail(FB_E_ARG, "SV takes exactly one enrolled speaker");
+  if (sy->num_gselect <= 0 || sy->num_gselect > 64 || sy->num_gselect > C) return fb_fail(FB_E_ARG, "num_gselect must be in [1, min(64, C)]");
+  if (sy->lda_cols != R && sy->lda_cols != R + 1) return fb_fail(FB_E_ARG, "transform.mat must have R or R+1 columns");
+  if (!sy->fg_weights || !sy->fg_means_invcovars || !sy->fg_inv_covars || !sy->ie_M || !sy->ie_sigma_inv ||
+      !sy->mean_vec || !sy->lda || !sy->plda_mean || !sy->plda_transform || !sy->plda_psi || !sy->enrolled ||
+      !sy->z_mean || !sy->z_std)
+    return fb_fail(FB_E_ARG, "null array in fb_ivector_system");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int triD = D * (D + 1) / 2, triR = R * (R + 1) / 2;
+  // ---- fgmm-global-to-gmm (DiagGmm::CopyFromFullGmm) + FullGmm::ComputeGconsts, float64 on host
+  std::vector<float> dg_gc(C), dg_miv((size_t)C * D), dg_iv((size_t)C * D), fg_gc(C);
+  {
+    std::vector<double> P((size_t)D * D), col(D), mean(D);
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    for (int k = 0; k < C; ++k) {
+      const float *pk = sy->fg_inv_covars + (size_t)k * triD;
+      for (int r = 0; r < D; ++r)
+        for (int c = 0; c <= r; ++c) { P[(size_t)r * D + c] = (double)pk[(size_t)r * (r + 1) / 2 + c]; P[(size_t)c * D + r] = P[(size_t)r * D + c]; }
+      std::vector<double> Lc(P);
+      if (!host_chol(Lc, D)) return fb_fail(FB_E_ARG, "full-covariance Gaussian %d is not positive definite", k);
+      double logdet_inv = 0.0;
+      for (int d = 0; d < D; ++d) logdet_inv += 2.0 * log(Lc[(size_t)d * D + d]);
+      // mean = covar * means_invcovars ; covar diag via solves with unit vectors
+      for (int d = 0; d < D; ++d) mean[d] = (double)sy->fg_means_invcovars[(size_t)k * D + d];
+      double quad = 0.0;
+      {
+        std::vector<double> t(mean);
+        host_chol_solve(Lc, D, t.data());
+        for (int d = 0; d < D; ++d) quad += (double)sy->fg_means_invcovars[(size_t)k * D + d] * t[d];
+        mean = t;
+      }
+      const double w = (double)sy->fg_weights[k];
+      fg_gc[k] = (float)(log(w) - 0.5 * (D * LOG2PI - logdet_inv + quad));
+      double gc = log(w) - 0.5 * D * LOG2PI;
+      for (int d = 0; d < D; ++d) {
+        for (int q = 0; q < D; ++q) col[q] = q == d ? 1.0 : 0.0;
+        host_chol_solve(Lc, D, col.data());
+        const float ivf = (float)(1.0 / col[d]);
+        const float mivf = (float)(mean[d] * (1.0 / col[d]));
+        dg_iv[(size_t)k * D + d] = ivf;
+        dg_miv[(size_t)k * D + d] = mivf;
+        gc += 0.5 * log((double)ivf) - 0.5 * (double)mivf * (double)mivf / (double)ivf;
+      }
+      dg_gc[k] = (float)gc;
+    }
+  }
+  FBCHK(fb_load_gmm(e, 1, C, D, dg_gc.data(), dg_miv.data(), dg_iv.data()));
+  // ---- full UBM + packed-index tables
+  {
+    const size_t n_gc = C, n_mic = (size_t)C * D, n_P = (size_t)C * triD;
+    FBCHK(e->iv_fg.ensure(sizeof(float) * (n_gc + n_mic + n_P)));
+    float *base = e->iv_fg.as<float>();
+    HIPCHK(hipMemcpy(base, fg_gc.data(), sizeof(float) * n_gc, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(base + n_gc, sy->fg_means_invcovars, sizeof(float) * n_mic, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(base + n_gc + n_mic, sy->fg_inv_covars, sizeof(float) * n_P, hipMemcpyHostToDevice));
+    std::vector<unsigned char> tr(2 * (size_t)triD);
+    for (int r = 0, idx = 0; r < D; ++r)
+      for (int c = 0; c <= r; ++c, ++idx) { tr[idx] = (unsigned char)r; tr[triD + idx] = (unsigned char)c; }
+    FBCHK(e->iv_tri.ensure(tr.size()));
+    HIPCHK(hipMemcpy(e->iv_tri.p, tr.data(), tr.size(), hipMemcpyHostToDevice));
+    e->iv.fg_gconsts = base; e->iv.fg_mic = base + n_gc; e->iv.fg_P = base + n_gc + n_mic;
+    e->iv.tri_r = e->iv_tri.as<unsigned char>(); e->iv.tri_c = e->iv.tri_r + triD;
+  }
+  // ---- extractor: Sigma^-1 M and U derived on the device (IvectorExtractor::ComputeDerivedVars)
+  {
+    DevBuf dM, dS;
+    const size_t nM = (size_t)C * D * R;
+    FBCHK(dM.ensure(sizeof(double) * nM));
+    FBCHK(dS.ensure(sizeof(double) * (size_t)C * triD));
+    FBCHK(e->iv_sim.ensure(sizeof(double) * nM));
+    FBCHK(e->iv_u.ensure(sizeof(double) * (size_t)C * triR));
+    HIPCHK(hipMemcpy(dM.p, sy->ie_M, sizeof(double) * nM, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dS.p, sy->ie_sigma_inv, sizeof(double) * (size_t)C * triD, hipMemcpyHostToDevice));
+    fb_launch_iv_derive(e->stream, C, D, R, dM.as<double>(), dS.as<double>(), e->iv_sim.as<double>(), e->iv_u.as<double>());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    dM.release();
+    dS.release();
+    e->iv.sim = e->iv_sim.as<double>();
+    e->iv.u = e->iv_u.as<double>();
+  }
+  // ---- back-end tables
+  {
+    const int lc = sy->lda_cols;
+    std::vector<double> host;
+    const size_t o_mean = 0; host.resize(R);
+    for (int r = 0; r < R; ++r) host[o_mean + r] = (double)sy->mean_vec[r];
+    const size_t o_lda = host.size(); host.resize(o_lda + (size_t)lc * L);
+    for (int l = 0; l < L; ++l) for (int c = 0; c < lc; ++c) host[o_lda + (size_t)c * L + l] = (double)sy->lda[(size_t)l * lc + c];
+    const size_t o_pm = host.size(); host.resize(o_pm + L);
+    for (int l = 0; l < L; ++l) host[o_pm + l] = sy->plda_mean[l];
+    const size_t o_pt = host.size(); host.resize(o_pt + (size_t)L * L);
+    for (int l = 0; l < L; ++l) for (int m = 0; m < L; ++m) host[o_pt + (size_t)m * L + l] = sy->plda_transform[(size_t)l * L + m];
+    const size_t o_psi = host.size(); host.resize(o_psi + L);
+    for (int l = 0; l < L; ++l) host[o_psi + l] = sy->plda_psi[l];
+    const size_t o_tr = host.size(); host.resize(o_tr + (size_t)S * L);
+    for (int sp = 0; sp < S; ++sp) host_backend(sy, sy->enrolled + (size_t)sp * R, &host[o_tr + (size_t)sp * L]);
+    FBCHK(e->iv_backend.ensure(sizeof(double) * host.size()));
+    HIPCHK(hipMemcpy(e->iv_backend.p, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+    const double *b = e->iv_backend.as<double>();
+    e->iv.mean_vec = b + o_mean; e->iv.ldaT = b + o_lda; e->iv.plda_mean = b + o_pm; e->iv.pldaT = b + o_pt;
+    e->iv.plda_psi = b + o_psi; e->iv.train = b + o_tr;
+  }
+  FbIvDev &iv = e->iv;
+  iv.C = C; iv.Cpad = e->gmm.n_tiles * 32; iv.D = D; iv.R = R; iv.L = L; iv.S = S; iv.lda_cols = sy->lda_cols;
+  iv.nsel = sy->num_gselect; iv.triD = triD; iv.triR = triR; iv.min_post = (float)sy->min_post;
+  iv.prior_offset = sy->prior_offset;
+  e->kind = 1;
+  e->n_out = S;
+  e->task = task;
+  e->h_zmean.assign(sy->z_mean, sy->z_mean + S);
+  e->h_zstd.assign(sy->z_std, sy->z_std + S);
+  FBCHK(e->zmean.ensure(sizeof(double) * S));
+  FBCHK(e->zstd.ensure(sizeof(double) * S));
+  HIPCHK(hipMemcpy(e->zmean.p, e->h_zmean.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->zstd.p, e->h_zstd.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+  // split of the (C*D)-long contraction: enough workgroups to stream Sigma^-1 M at HBM rate
+  const int64_t Q = (int64_t)C * D;
+  e->iv_kchunks = (int)(Q / 512 > 256 ? 256 : (Q / 512 < 1 ? 1 : Q / 512));
+  return FB_OK;
+}
+
+extern "C" int fb_debug_ivectors(fb_engine *e, int B, double *ivecs) {
+  if (!e || !ivecs || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (e->kind != 1 || e->last_B < B) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(ivecs, e->iv_ivec.p, sizeof(double) * (size_t)B * e->iv.R, hipMemcpyDeviceToHost));
   return FB_OK;
 }
 
@@ -603,7 +852,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
                     p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
                     e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>());
   FBCHK(run_scoring(e, B, e->h_frame_off[B]));
-  fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->gmm.M, p->task, p->attack_type,
+  fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->n_out, p->task, e->kind, p->attack_type,
                  e->zmean.as<double>(), e->zstd.as<double>(), p->threshold, p->adver_thresh, p->target,
                  p->true_label, e->dist_part.as<double>(), with_dist ? ndp : 0, e->scores.as<double>(),
                  e->loss.as<double>(), e->nes_out.as<FbNesDev>());
@@ -783,7 +1032,7 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
     }
     if (n_iters >= max_total_iters) { rc = fb_fail(FB_E_LIMIT, "max_total_iters %d reached", max_total_iters); break; }
     if (thr_changed) {
-      fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->gmm.M, q.task, q.attack_type,
+      fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->n_out, q.task, e->kind, q.attack_type,
                      e->zmean.as<double>(), e->zstd.as<double>(), q.threshold, q.adver_thresh, q.target,
                      q.true_label, e->dist_part.as<double>(), 0, e->scores.as<double>(), e->loss.as<double>(),
                      e->nes_out.as<FbNesDev>());

@@ -47,7 +47,8 @@ struct FbNesDev {  // device control/result block of one NES iteration
   double score0[62];
 };
 // scores + loss + summary (single block).  raw[B][M] -> scores[B][S] -> loss[B].
-void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task,
+// znorm_all != 0 (i-vector systems): S = M and scores = (raw - z_mean)/z_std for every task.
+void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,
                     int attack_type, const double *z_mean, const double *z_std, double threshold,
                     double adver_thresh, int target, int true_label, const double *dist_part,
                     int n_dist_part, double *scores, double *loss, FbNesDev *out);
@@ -86,6 +87,39 @@ struct FbGmmDev {
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);
+// single model (g.M == 1): ll[row][n_tiles*32] = every component log-likelihood (gmm-gselect input)
+void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
+                        int rows_cap, int n_chunks, float *ll);
 // raw[b][m] = mean over voiced rows of logsumexp (merging the chunk partials)
 void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                             int rows_cap, int n_chunks, const int *row_off, int B, double *raw);
+
+// ---- i-vector / PLDA ------------------------------------------------------------
+struct FbIvDev {
+  int C, Cpad, D, R, L, S, lda_cols, nsel, triD, triR;
+  float min_post;
+  double prior_offset;
+  const float *fg_gconsts;      // [C]
+  const float *fg_mic;          // [C][D]   means_invcovars
+  const float *fg_P;            // [C][triD] inv_covars, packed lower-triangular
+  const unsigned char *tri_r, *tri_c;  // [triD] row / column of packed element e
+  const double *sim;            // [C*D][R] Sigma^-1 M
+  const double *u;              // [C][triR]
+  const double *mean_vec;       // [R]
+  const double *ldaT;           // [lda_cols][L]
+  const double *plda_mean;      // [L]
+  const double *pldaT;          // [L][L] transposed PLDA transform
+  const double *plda_psi;       // [L]
+  const double *train;          // [S][L] enrolled i-vectors in PLDA space
+};
+void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, const double *sinv_packed,
+                         double *sim, double *u);
+void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
+                              const int *n_rows_ptr, int rows_cap, int *sel, float *post);
+void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *sel,
+                        const float *post, int B, double *gamma, double *X);
+void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma, const double *X, int B,
+                           int n_kchunks, double *linp, double *quad);
+void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
+                        int B, double *Aall, double *ivec, int *fail);
+void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr);

@@ -31,7 +31,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FB_GMM_NEG (-3.0e38f)
 
-template <int KH>
+// DUMP = true: single-model variant that stores every component log-likelihood ll[row][comp]
+// (leading dimension n_tiles*32) instead of reducing them -- the gmm-gselect stage of the
+// i-vector path (ivector_kernels.hip) takes the top-n per frame from it.
+template <int KH, bool DUMP>
 __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restrict__ feats,
                                                 const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
                                                 int rows_cap, float *__restrict__ part_m,
@@ -141,6 +144,15 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
         v[4 * rr + 2] = acc[4 * rr + 2] + gq.z;
         v[4 * rr + 3] = acc[4 * rr + 3] + gq.w;
       }
+      if constexpr (DUMP) {
+        if (row < n_rows) {
+          const int tile = tile0 + it / g.n_items;
+          float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(v[4 * rr], v[4 * rr + 1], v[4 * rr + 2], v[4 * rr + 3]);
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tm = fmaxf(tm, v[r]);
       const float m_old = st_m[model * 256 + tid], s_old = st_s[model * 256 + tid];
@@ -150,12 +162,14 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
       for (int r = 0; r < 16; ++r) ssum += __expf(v[r] - m_new);
       st_m[model * 256 + tid] = m_new;
       st_s[model * 256 + tid] = ssum;
+      }
     }
 #pragma unroll
     for (int s = 0; s < NST; ++s) reinterpret_cast<float4 *>(nxt)[min(tid + 256 * s, IMG4 - 1)] = stage[s];
     __syncthreads();
   }
 
+  if constexpr (DUMP) return;
   // ---- merge the two lane halves (components 4h..) and publish the chunk partial
   for (int m = 0; m < g.M; ++m) {
     const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
@@ -179,8 +193,27 @@ template <int KH>
 static void launch_gmm_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                          int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
   dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
-  hipLaunchKernelGGL(k_gmm<KH>, grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr, tpc,
-                     rows_cap, part_m, part_s);
+  hipLaunchKernelGGL((k_gmm<KH, false>), grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr,
+                     tpc, rows_cap, part_m, part_s);
+}
+template <int KH>
+static void launch_gmm_dump_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                              int rows_cap, int n_chunks, int tpc, float *ll) {
+  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
+  hipLaunchKernelGGL((k_gmm<KH, true>), grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr,
+                     tpc, rows_cap, ll, (float *)nullptr);
+}
+void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                        int rows_cap, int n_chunks, float *ll) {
+  if (rows_cap <= 0) return;
+  const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  switch (g.KH) {
+    case 20: launch_gmm_dump_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
+    case 32: launch_gmm_dump_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
+    case 36: launch_gmm_dump_t<36>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
+    case 40: launch_gmm_dump_t<40>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
+    default: break;
+  }
 }
 
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,

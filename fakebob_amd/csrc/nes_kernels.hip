@@ -189,14 +189,14 @@ __device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
 }
 
 __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, const int *__restrict__ tv,
-                                              int B, int M, int task, int attack_type,
+                                              int B, int M, int task, int znorm_all, int attack_type,
                                               const double *__restrict__ z_mean,
                                               const double *__restrict__ z_std, double threshold,
                                               double adver_thresh, int target, int true_label,
                                               const double *__restrict__ dist_part, int n_dist_part,
                                               double *__restrict__ scores, double *__restrict__ loss,
                                               FbNesDev *__restrict__ out) {
-  const int S = (task == FB_TASK_CSI) ? M : M - 1;
+  const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
   __shared__ int s_err;
   if (threadIdx.x == 0) s_err = 0;
   __syncthreads();
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
     if (tv && tv[b] <= 0) atomicMax(&s_err, b + 1);
     const double *r = raw + (size_t)b * M;
     double *sc = scores + (size_t)b * S;
-    if (task == FB_TASK_CSI) {
-      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r[m], z_mean[m]), z_std[m]);  // gmm_ubm_CSI.py:93
+    if (task == FB_TASK_CSI || znorm_all) {
+      // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
+      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r[m], z_mean[m]), z_std[m]);
     } else {
       for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r[1 + m], r[0]);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
     }
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
   }
 }
 
-void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task,
+void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,
                     int attack_type, const double *z_mean, const double *z_std, double threshold,
                     double adver_thresh, int target, int true_label, const double *dist_part,
                     int n_dist_part, double *scores, double *loss, FbNesDev *out) {
-  hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, attack_type, z_mean, z_std,
+  hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, znorm_all, attack_type, z_mean, z_std,
                      threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out);
 }
 

@@ -69,6 +69,30 @@ class Engine(object):
         self.n_models = M
         self.task = "OSI"
 
+    def load_ivector(self, system, task="OSI"):
+        """system: models.IvectorSystem"""
+        sy = N.IvectorSystem()
+        sy.C, sy.D, sy.R, sy.L, sy.S = system.C, system.D, system.R, system.L, system.S
+        sy.lda_cols = system.lda.shape[1]
+        sy.num_gselect = system.num_gselect
+        sy.min_post = system.min_post
+        sy.prior_offset = system.prior_offset
+        keep = []
+        for name in ("fg_weights", "fg_means_invcovars", "fg_inv_covars", "ie_M", "ie_sigma_inv", "mean_vec",
+                     "lda", "plda_mean", "plda_transform", "plda_psi", "enrolled", "z_mean", "z_std"):
+            a = getattr(system, name)
+            keep.append(a)
+            setattr(sy, name, a.ctypes.data)
+        N.check(self._L.fb_load_ivector(self._h, C.byref(sy), C.c_int(N.TASK[task])))
+        self.n_models = system.S
+        self.task = task
+        self.kind = "iv"
+
+    def debug_ivectors(self, B, R):
+        out = np.empty((B, R), np.float64)
+        N.check(self._L.fb_debug_ivectors(self._h, C.c_int(B), N.ptr(out)))
+        return out
+
     def set_system(self, task, z_mean=None, z_std=None):
         zm = None if z_mean is None else np.ascontiguousarray(z_mean, np.float64)
         zs = None if z_std is None else np.ascontiguousarray(z_std, np.float64)

@@ -123,3 +123,90 @@ def synthetic_gmm_system(n_speakers=5, C=2048, D=72, seed_ubm=2001, seed_spk=210
         m = DiagGmm.from_internal(w, (mu_s / var).astype(np.float32), ubm.inv_vars)
         spk.append(m)
     return ubm, spk
+
+
+# ------------------------------------------------------------ i-vector / PLDA
+def tri_pack(A):
+    """(..., n, n) symmetric -> Kaldi SpMatrix packed lower-triangular (..., n(n+1)/2)."""
+    n = A.shape[-1]
+    r, c = np.tril_indices(n)
+    return np.ascontiguousarray(A[..., r, c])
+
+
+def tri_unpack(p, n):
+    r, c = np.tril_indices(n)
+    A = np.zeros(p.shape[:-1] + (n, n), p.dtype)
+    A[..., r, c] = p
+    A[..., c, r] = p
+    return A
+
+
+class IvectorSystem(object):
+    """Everything sid/extract_ivectors.sh + ivector-plda-scoring read from pre-models/ plus the
+    enrolled i-vectors (ivector_PLDA_kaldiHelper.py:197-213, 251-280), in Kaldi's internal forms:
+      full UBM     weights [C], means_invcovars [C,D], inv_covars packed [C, D(D+1)/2]   (float32)
+      extractor    M [C,D,R], Sigma_inv packed [C, D(D+1)/2], prior_offset               (float64)
+      back-end     mean_vec [R], lda [L, R or R+1] (float32); plda mean [L], transform [L,L], psi [L]
+      enrolled     raw i-vectors [S,R] (float32), z-norm mean/std [S]
+    """
+
+    def __init__(self, fg_weights, fg_means_invcovars, fg_inv_covars, ie_M, ie_sigma_inv, prior_offset,
+                 mean_vec, lda, plda_mean, plda_transform, plda_psi, enrolled, z_mean=None, z_std=None,
+                 num_gselect=20, min_post=0.025):
+        f32, f64 = np.float32, np.float64
+        self.fg_weights = np.ascontiguousarray(fg_weights, f32)
+        self.fg_means_invcovars = np.ascontiguousarray(fg_means_invcovars, f32)
+        self.fg_inv_covars = np.ascontiguousarray(fg_inv_covars, f32)
+        self.ie_M = np.ascontiguousarray(ie_M, f64)
+        self.ie_sigma_inv = np.ascontiguousarray(ie_sigma_inv, f64)
+        self.prior_offset = float(prior_offset)
+        self.mean_vec = np.ascontiguousarray(mean_vec, f32)
+        self.lda = np.ascontiguousarray(lda, f32)
+        self.plda_mean = np.ascontiguousarray(plda_mean, f64)
+        self.plda_transform = np.ascontiguousarray(plda_transform, f64)
+        self.plda_psi = np.ascontiguousarray(plda_psi, f64)
+        self.enrolled = np.ascontiguousarray(np.atleast_2d(enrolled), f32)
+        S = self.enrolled.shape[0]
+        self.z_mean = np.ascontiguousarray(np.zeros(S) if z_mean is None else z_mean, f64)
+        self.z_std = np.ascontiguousarray(np.ones(S) if z_std is None else z_std, f64)
+        self.num_gselect = int(num_gselect)
+        self.min_post = float(min_post)
+        self.C, self.D, self.R = self.ie_M.shape
+        self.L = self.lda.shape[0]
+        self.S = S
+        assert self.fg_inv_covars.shape == (self.C, self.D * (self.D + 1) // 2)
+        assert self.ie_sigma_inv.shape == self.fg_inv_covars.shape
+        assert self.lda.shape[1] in (self.R, self.R + 1) and self.enrolled.shape[1] == self.R
+
+    def with_enrolled(self, enrolled, z_mean=None, z_std=None):
+        return IvectorSystem(self.fg_weights, self.fg_means_invcovars, self.fg_inv_covars, self.ie_M,
+                             self.ie_sigma_inv, self.prior_offset, self.mean_vec, self.lda, self.plda_mean,
+                             self.plda_transform, self.plda_psi, enrolled, z_mean, z_std, self.num_gselect,
+                             self.min_post)
+
+
+def synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=1, seed=3001, prior_offset=10.0):
+    """SURVEY.md 8(d): Sigma_k = A A^T / D + diag(sigma_k^2), A ~ N(0, 0.3^2); M_k ~ N(0, 0.05^2);
+    prior offset 10; mean.vec = 0; LDA = first L rows of a random orthogonal R x R; PLDA
+    psi_i = 8 * 0.97^i, mean 0, transform I.  The UBM weights / means / diagonal variances are the
+    synthetic diagonal UBM's.  Enrolled i-vectors ~ N(0, I) (replace them with engine-extracted
+    ones via with_enrolled())."""
+    w, mu, var = synthetic_ubm_moments(C, D, 2001)
+    rng = np.random.default_rng(seed)
+    inv_covars = np.empty((C, D * (D + 1) // 2), np.float64)
+    mic = np.empty((C, D), np.float64)
+    for k in range(C):
+        A = rng.normal(0.0, 0.3, size=(D, D))
+        Sig = A @ A.T / D + np.diag(var[k])
+        P = np.linalg.inv(Sig)
+        P = 0.5 * (P + P.T)
+        inv_covars[k] = tri_pack(P)
+        mic[k] = P @ mu[k]
+    M = rng.normal(0.0, 0.05, size=(C, D, R))
+    Q, _ = np.linalg.qr(rng.normal(size=(R, R)))
+    lda = Q[:L]
+    psi = 8.0 * 0.97 ** np.arange(L)
+    enrolled = rng.normal(size=(n_speakers, R))
+    f32 = inv_covars.astype(np.float32)
+    return IvectorSystem(w, mic, f32, M, f32.astype(np.float64), prior_offset, np.zeros(R), lda, np.zeros(L),
+                         np.eye(L), psi, enrolled)

@@ -114,6 +114,35 @@ int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *cfg);
 int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gconsts,
                 const float *means_invvars, const float *inv_vars);
 
+/* i-vector / PLDA system: everything `sid/extract_ivectors.sh` + `ivector-plda-scoring` read
+ * from pre-models/ (final.ubm, final.ie, mean.vec, transform.mat, plda) plus the enrolled
+ * i-vectors the wrappers list in ivector.scp (ivector_PLDA_OSI.py:59-60,
+ * ivector_PLDA_kaldiHelper.py:197-213,251-280).  Derived variables (diagonalised UBM for
+ * gmm-gselect, Sigma^-1 M, U, PLDA-space enrolled vectors) are computed by the engine. */
+typedef struct {
+  int C, D, R, L, S;                /* Gaussians, feature dim, i-vector dim, LDA dim, speakers */
+  int lda_cols;                     /* R, or R+1 when transform.mat carries an offset column */
+  int num_gselect;                  /* 20 */
+  double min_post;                  /* 0.025 */
+  double prior_offset;              /* IvectorExtractor::prior_offset_ */
+  const float *fg_weights;          /* [C]          FullGmm */
+  const float *fg_means_invcovars;  /* [C*D] */
+  const float *fg_inv_covars;       /* [C*D(D+1)/2] packed lower-triangular (SpMatrix) */
+  const double *ie_M;               /* [C][D][R]    IvectorExtractor::M_ */
+  const double *ie_sigma_inv;       /* [C][D(D+1)/2] IvectorExtractor::Sigma_inv_ (packed) */
+  const float *mean_vec;            /* [R]          mean.vec */
+  const float *lda;                 /* [L][lda_cols] transform.mat */
+  const double *plda_mean;          /* [L] */
+  const double *plda_transform;     /* [L][L] */
+  const double *plda_psi;           /* [L] */
+  const float *enrolled;            /* [S][R] enrolment i-vectors as stored by ivector-extract */
+  const double *z_mean, *z_std;     /* [S] z-norm statistics of the speaker-model pickles */
+} fb_ivector_system;
+
+/* Loads an i-vector/PLDA system; scores are PLDA LLRs [B*S]; fb_system_scores / the NES
+ * kernels apply (llr - z_mean) / z_std for every task (ivector_PLDA_OSI.py:119). */
+int fb_load_ivector(fb_engine *e, const fb_ivector_system *sys, int task);
+
 /* How raw per-model log-likelihoods become system scores:
  *  OSI / SV: model 0 is the UBM, S = M-1, score = raw[1+s] - raw[0]
  *  CSI     : S = M, score = (raw - z_mean) / z_std                          */
@@ -169,6 +198,8 @@ int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int 
 /* compacted voiced CMVN'd features of one utterance: feats[Tv*dim] */
 int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
                    int *Tv, int *T);
+/* i-vectors [B*R] (float64, prior offset removed) of the last scored batch */
+int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
 /* counters since engine creation */
 int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames,
              int64_t *voiced_frames, int64_t *nes_iters);

@@ -753,3 +753,241 @@ int fbo_gmm_system_score(void *ctx, const double *audios, int64_t N, int B, doub
   free(wav); free(off); free(raw);
   return rc;
 }
+
+/* ======================================================== i-vector / PLDA */
+/* [EXT] sid/extract_ivectors.sh: gmm-gselect --n=20 | fgmm-global-gselect-to-post
+ * --min-post=0.025 | scale-post 1.0 | ivector-extract  (SURVEY.md A.9). */
+typedef struct { float v; int k; } fbo_pair;
+static int pair_desc(const void *a, const void *b) {
+  const fbo_pair *x = (const fbo_pair *)a, *y = (const fbo_pair *)b;
+  if (x->v > y->v) return -1;
+  if (x->v < y->v) return 1;
+  return (x->k > y->k) ? -1 : (x->k < y->k ? 1 : 0); /* std::greater<pair<float,int>> */
+}
+
+void fbo_iv_stats(const fbo_iv_system *s, const float *feats, int Tv, double *gamma, double *X) {
+  const int C = s->C, D = s->D, n = s->num_gselect < C ? s->num_gselect : C;
+  const int tri = D * (D + 1) / 2;
+  fbo_pair *pr = (fbo_pair *)malloc(sizeof(fbo_pair) * C);
+  double *xd = (double *)malloc(sizeof(double) * D), *xq = (double *)malloc(sizeof(double) * D);
+  double *ll = (double *)malloc(sizeof(double) * n);
+  float *post = (float *)malloc(sizeof(float) * n);
+  memset(gamma, 0, sizeof(double) * C);
+  memset(X, 0, sizeof(double) * (size_t)C * D);
+  const float min_post = (float)s->min_post;
+  for (int t = 0; t < Tv; ++t) {
+    const float *f = feats + (size_t)t * D;
+    for (int d = 0; d < D; ++d) { xd[d] = (double)f[d]; xq[d] = (double)(float)(f[d] * f[d]); }
+    /* gmm-gselect on the diagonalised UBM (float32 log-likelihoods like Kaldi) */
+    for (int k = 0; k < C; ++k) {
+      const float *m = s->dg_means_invvars + (size_t)k * D, *v = s->dg_inv_vars + (size_t)k * D;
+      double a = 0.0, b = 0.0;
+      for (int d = 0; d < D; ++d) { a += (double)m[d] * xd[d]; b += (double)v[d] * xq[d]; }
+      pr[k].v = (float)((double)s->dg_gconsts[k] + a - 0.5 * b);
+      pr[k].k = k;
+    }
+    qsort(pr, C, sizeof(fbo_pair), pair_desc);
+    /* fgmm-global-gselect-to-post: full-covariance log-likelihoods of the selected Gaussians */
+    double mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+      const int k = pr[j].k;
+      const float *mic = s->fg_means_invcovars + (size_t)k * D;
+      const float *P = s->fg_inv_covars + (size_t)k * tri;
+      double lin = 0.0, quad = 0.0;
+      for (int r = 0; r < D; ++r) {
+        lin += (double)mic[r] * xd[r];
+        const float *row = P + (size_t)r * (r + 1) / 2;
+        double acc = 0.0;
+        for (int c = 0; c < r; ++c) acc += (double)row[c] * xd[c];
+        quad += xd[r] * (2.0 * acc + (double)row[r] * xd[r]);
+      }
+      ll[j] = (double)(float)((double)s->fg_gconsts[k] + lin - 0.5 * quad);
+      if (ll[j] > mx) mx = ll[j];
+    }
+    double sum = 0.0;
+    for (int j = 0; j < n; ++j) { ll[j] = exp(ll[j] - mx); sum += ll[j]; }
+    int jmax = 0;
+    for (int j = 0; j < n; ++j) { post[j] = (float)(ll[j] / sum); if (post[j] > post[jmax]) jmax = j; }
+    if (min_post != 0.0f) {
+      double s2 = 0.0;
+      for (int j = 0; j < n; ++j) { if (post[j] < min_post) post[j] = 0.0f; s2 += (double)post[j]; }
+      if (s2 == 0.0) post[jmax] = 1.0f;
+      else for (int j = 0; j < n; ++j) post[j] = (float)((double)post[j] / s2);
+    }
+    for (int j = 0; j < n; ++j) {
+      if (post[j] == 0.0f) continue;
+      const int k = pr[j].k;
+      const double w = (double)post[j];
+      gamma[k] += w;
+      double *xk = X + (size_t)k * D;
+      for (int d = 0; d < D; ++d) xk[d] += w * xd[d];
+    }
+  }
+  free(pr); free(xd); free(xq); free(ll); free(post);
+}
+
+/* Cholesky solve of a symmetric positive definite system, A overwritten */
+static int chol_solve(double *A, double *b, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0)) return -1;
+    d = sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = v / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
+    b[i] = v / A[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = b[i];
+    for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k];
+    b[i] = v / A[(size_t)i * n + i];
+  }
+  return 0;
+}
+
+/* IvectorExtractor::GetIvectorDistribution without weight projections:
+ * linear = sum_k (Sigma_k^-1 M_k)^T X_k, quadratic = sum_k gamma_k U_k; prior: linear[0] +=
+ * prior_offset, quadratic += I; ivec = quadratic^-1 linear; ivec[0] -= prior_offset. */
+int fbo_iv_extract(const fbo_iv_system *s, const double *gamma, const double *X, double *ivec) {
+  const int C = s->C, D = s->D, R = s->R, tri = R * (R + 1) / 2;
+  double *lin = (double *)calloc(R, sizeof(double));
+  double *qp = (double *)calloc(tri, sizeof(double));
+  for (int k = 0; k < C; ++k) {
+    if (gamma[k] == 0.0) continue;
+    const double *sm = s->sigma_inv_m + (size_t)k * D * R;
+    const double *xk = X + (size_t)k * D;
+    for (int d = 0; d < D; ++d) {
+      const double xv = xk[d];
+      const double *row = sm + (size_t)d * R;
+      for (int r = 0; r < R; ++r) lin[r] += row[r] * xv;
+    }
+    const double g = gamma[k];
+    const double *uk = s->u + (size_t)k * tri;
+    for (int i = 0; i < tri; ++i) qp[i] += g * uk[i];
+  }
+  lin[0] += s->prior_offset;
+  double *A = (double *)malloc(sizeof(double) * (size_t)R * R);
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c <= r; ++c) {
+      double v = qp[(size_t)r * (r + 1) / 2 + c] + (r == c ? 1.0 : 0.0);
+      A[(size_t)r * R + c] = v;
+      A[(size_t)c * R + r] = v;
+    }
+  int rc = chol_solve(A, lin, R);
+  for (int r = 0; r < R; ++r) ivec[r] = lin[r];
+  ivec[0] -= s->prior_offset;
+  free(lin); free(qp); free(A);
+  return rc;
+}
+
+/* ivector-subtract-global-mean | transform-vec | ivector-normalize-length, then
+ * Plda::TransformIvector with normalize_length=true, simple_length_norm=false, n=1 (A.10) */
+void fbo_iv_backend(const fbo_iv_system *s, const double *ivec_in, double *y) {
+  const int R = s->R, L = s->L;
+  /* ivector-extract writes a float vector */
+  double *x = (double *)malloc(sizeof(double) * R), *z = (double *)malloc(sizeof(double) * L);
+  for (int r = 0; r < R; ++r) x[r] = (double)(float)ivec_in[r] - s->mean_vec[r];
+  double nrm = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double *row = s->lda + (size_t)l * s->lda_cols;
+    double acc = s->lda_cols == R + 1 ? row[R] : 0.0;
+    for (int r = 0; r < R; ++r) acc += row[r] * x[r];
+    z[l] = acc;
+    nrm += acc * acc;
+  }
+  nrm = sqrt(nrm);
+  const double ratio = nrm / sqrt((double)L);
+  if (ratio != 0.0) for (int l = 0; l < L; ++l) z[l] /= ratio;
+  double dot = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double *row = s->plda_transform + (size_t)l * L;
+    double acc = 0.0;
+    for (int m = 0; m < L; ++m) acc += row[m] * (z[m] - s->plda_mean[m]);
+    y[l] = acc;
+    dot += acc * acc / (s->plda_psi[l] + 1.0);
+  }
+  const double nf = sqrt((double)L / dot);
+  for (int l = 0; l < L; ++l) y[l] *= nf;
+  free(x); free(z);
+}
+
+double fbo_plda_llr(const fbo_iv_system *s, const double *train, const double *y) {
+  const int L = s->L;
+  double given = 0.0, without = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double psi = s->plda_psi[l];
+    const double mean = psi / (psi + 1.0) * train[l];
+    const double var = 1.0 + psi / (psi + 1.0);
+    const double d = y[l] - mean;
+    given += log(var) + d * d / var;
+    without += log(psi + 1.0) + y[l] * y[l] / (psi + 1.0);
+  }
+  const double M_LOG_2PI_ = 1.8378770664093454835606594728112;
+  given = -0.5 * (given + M_LOG_2PI_ * L);
+  without = -0.5 * (without + M_LOG_2PI_ * L);
+  return given - without;
+}
+
+int fbo_iv_score_batch(const fbo_iv_system *s, const int16_t *wav, const int64_t *off, int B,
+                       double *llr, double *ivecs_out, int *tv_out) {
+  int err = 0;
+  const int D = s->D, C = s->C, R = s->R, L = s->L, S = s->S;
+  if (fbo_feat_dim(&s->cfg) != D) return -1000000;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(s->nthreads > 0 ? s->nthreads : 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = off[b + 1] - off[b];
+    const int T = fbo_num_frames(&s->cfg, n);
+    float *feats = (float *)malloc(sizeof(float) * (size_t)(T > 0 ? T : 1) * D);
+    int Tt = 0;
+    const int tv = fbo_frontend(&s->cfg, wav + off[b], n, feats, &Tt);
+    if (tv_out) tv_out[b] = tv;
+    if (tv <= 0) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      { if (err == 0 || -(b + 1) > err) err = -(b + 1); }
+      for (int j = 0; j < S; ++j) llr[(size_t)b * S + j] = NAN;
+    } else {
+      double *gamma = (double *)malloc(sizeof(double) * C), *X = (double *)malloc(sizeof(double) * (size_t)C * D);
+      double *iv = (double *)malloc(sizeof(double) * R), *y = (double *)malloc(sizeof(double) * L);
+      fbo_iv_stats(s, feats, tv, gamma, X);
+      if (fbo_iv_extract(s, gamma, X, iv) != 0) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        { err = -2000000; }
+      }
+      if (ivecs_out) memcpy(ivecs_out + (size_t)b * R, iv, sizeof(double) * R);
+      fbo_iv_backend(s, iv, y);
+      for (int j = 0; j < S; ++j) llr[(size_t)b * S + j] = fbo_plda_llr(s, s->train + (size_t)j * L, y);
+      free(gamma); free(X); free(iv); free(y);
+    }
+    free(feats);
+  }
+  return err;
+}
+
+int fbo_iv_system_score(void *ctx, const double *audios, int64_t N, int B, double *scores) {
+  const fbo_iv_system *s = (const fbo_iv_system *)ctx;
+  int16_t *wav = (int16_t *)malloc(sizeof(int16_t) * (size_t)N * B);
+  int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (B + 1));
+  fbo_quantize(audios, N * B, 16, wav);
+  for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+  int rc = fbo_iv_score_batch(s, wav, off, B, scores, NULL, NULL);
+  if (rc == 0)
+    for (int b = 0; b < B; ++b)
+      for (int j = 0; j < s->S; ++j)
+        scores[(size_t)b * s->S + j] = (scores[(size_t)b * s->S + j] - s->z_mean[j]) / s->z_std[j];
+  free(wav); free(off);
+  return rc;
+}

@@ -174,6 +174,47 @@ typedef struct {
 } fbo_gmm_system;
 int fbo_gmm_system_score(void *ctx, const double *audios, int64_t N, int B, double *scores);
 
+/* ---- i-vector / PLDA back-end ([EXT] SURVEY.md A.9, A.10; reference command lines
+ * ivector_PLDA_kaldiHelper.py:197-213, 251-280) ---- */
+typedef struct {
+  int C, D, R, L, S;          /* Gaussians, feat dim, i-vector dim, LDA dim, enrolled speakers */
+  int num_gselect;            /* 20 */
+  double min_post;            /* 0.025 */
+  /* diagonalised UBM for gmm-gselect (fgmm-global-to-gmm) */
+  const float *dg_gconsts, *dg_means_invvars, *dg_inv_vars;
+  /* full-covariance UBM (Kaldi FullGmm internal form; inv_covars packed lower-triangular) */
+  const float *fg_gconsts, *fg_means_invcovars, *fg_inv_covars;
+  /* i-vector extractor derived variables (float64 like Kaldi) */
+  const double *sigma_inv_m;  /* [C][D][R] */
+  const double *u;            /* [C][R(R+1)/2] packed lower-triangular */
+  double prior_offset;
+  /* back-end */
+  const double *mean_vec;     /* [R] */
+  const double *lda;          /* [L][R] or [L][R+1] when lda_cols == R+1 (offset column) */
+  int lda_cols;
+  const double *plda_mean;    /* [L] */
+  const double *plda_transform; /* [L][L] */
+  const double *plda_psi;     /* [L] */
+  const double *train;        /* [S][L] enrolled i-vectors after the full back-end transform */
+  const double *z_mean, *z_std; /* [S] wrapper z-norm (ivector_PLDA_OSI.py:119) */
+  fbo_frontend_cfg cfg;
+  int nthreads;
+} fbo_iv_system;
+
+/* zeroth/first order statistics of one utterance: gamma[C], X[C*D] (float64) */
+void fbo_iv_stats(const fbo_iv_system *s, const float *feats, int Tv, double *gamma, double *X);
+/* i-vector (with the prior offset already subtracted) from the statistics: ivec[R] */
+int fbo_iv_extract(const fbo_iv_system *s, const double *gamma, const double *X, double *ivec);
+/* raw i-vector -> PLDA space (subtract mean, LDA, length norm, PLDA transform + norm): y[L] */
+void fbo_iv_backend(const fbo_iv_system *s, const double *ivec, double *y);
+/* PLDA log-likelihood ratio of test y against enrolled train (n=1) */
+double fbo_plda_llr(const fbo_iv_system *s, const double *train, const double *y);
+/* ivector_PLDA_kaldiHelper.score: llr[B*S]; ivecs_out (nullable) [B*R]; tv_out nullable */
+int fbo_iv_score_batch(const fbo_iv_system *s, const int16_t *wav, const int64_t *off, int B,
+                       double *llr, double *ivecs_out, int *tv_out);
+/* fbo_score_fn: z-normalised scores (iv_OSI / iv_CSI / iv_SV .score) */
+int fbo_iv_system_score(void *ctx, const double *audios, int64_t N, int B, double *scores);
+
 #ifdef __cplusplus
 }
 #endif

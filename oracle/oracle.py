@@ -75,6 +75,7 @@ def lib():
         _lib = C.CDLL(_LIB)
         _lib.fbo_diag_gmm_loglikes.restype = C.c_double
         _lib.fbo_np_sum.restype = C.c_double
+        _lib.fbo_plda_llr.restype = C.c_double
     return _lib
 
 
@@ -310,3 +311,120 @@ def estimate_threshold(p, model_threshold, fn, ctx, audio, noise_all=None, max_t
     if rc:
         raise RuntimeError("oracle estimate_threshold rc=%d" % rc)
     return sc.value, ni.value, no.value, tf.value, adv_f
+
+
+# ---------------------------------------------------------------- i-vector / PLDA
+class IvSystem(C.Structure):
+    """fbo_iv_system"""
+    _fields_ = [
+        ("C", C.c_int), ("D", C.c_int), ("R", C.c_int), ("L", C.c_int), ("S", C.c_int),
+        ("num_gselect", C.c_int), ("min_post", C.c_double),
+        ("dg_gconsts", C.c_void_p), ("dg_means_invvars", C.c_void_p), ("dg_inv_vars", C.c_void_p),
+        ("fg_gconsts", C.c_void_p), ("fg_means_invcovars", C.c_void_p), ("fg_inv_covars", C.c_void_p),
+        ("sigma_inv_m", C.c_void_p), ("u", C.c_void_p), ("prior_offset", C.c_double),
+        ("mean_vec", C.c_void_p), ("lda", C.c_void_p), ("lda_cols", C.c_int),
+        ("plda_mean", C.c_void_p), ("plda_transform", C.c_void_p), ("plda_psi", C.c_void_p),
+        ("train", C.c_void_p), ("z_mean", C.c_void_p), ("z_std", C.c_void_p),
+        ("cfg", FrontendCfg), ("nthreads", C.c_int),
+    ]
+
+
+class IvSystemCtx(object):
+    """The oracle's own iv_OSI/iv_CSI/iv_SV.score.  Derived variables (fgmm-global-to-gmm,
+    FullGmm gconsts, Sigma^-1 M, U, PLDA-space enrolled vectors) are computed here with numpy,
+    independently of the engine's C++/HIP derivations."""
+
+    def __init__(self, cfg, sysm, nthreads=1):
+        f32, f64 = np.float32, np.float64
+        Cn, D, R, L, S = sysm.C, sysm.D, sysm.R, sysm.L, sysm.S
+        r, c = np.tril_indices(D)
+        P = np.zeros((Cn, D, D), f64)
+        P[:, r, c] = sysm.fg_inv_covars.astype(f64)
+        P[:, c, r] = sysm.fg_inv_covars.astype(f64)
+        covar = np.linalg.inv(P)
+        mic = sysm.fg_means_invcovars.astype(f64)
+        mean = np.einsum("kde,ke->kd", covar, mic)
+        var = np.einsum("kdd->kd", covar)
+        w = sysm.fg_weights.astype(f64)
+        self.dg_iv = np.ascontiguousarray((1.0 / var).astype(f32))
+        self.dg_miv = np.ascontiguousarray((mean * (1.0 / var)).astype(f32))
+        iv64, miv64 = self.dg_iv.astype(f64), self.dg_miv.astype(f64)
+        self.dg_gc = np.ascontiguousarray((np.log(w) - 0.5 * D * np.log(2 * np.pi) + 0.5 * np.log(iv64).sum(1)
+                                           - 0.5 * (miv64 * miv64 / iv64).sum(1)).astype(f32))
+        _, logdet = np.linalg.slogdet(P)
+        self.fg_gc = np.ascontiguousarray((np.log(w) - 0.5 * (D * np.log(2 * np.pi) - logdet
+                                                               + np.einsum("kd,kd->k", mic, mean))).astype(f32))
+        self.fg_mic = sysm.fg_means_invcovars
+        self.fg_P = sysm.fg_inv_covars
+        Sinv = np.zeros((Cn, D, D), f64)
+        Sinv[:, r, c] = sysm.ie_sigma_inv
+        Sinv[:, c, r] = sysm.ie_sigma_inv
+        self.sim = np.ascontiguousarray(np.einsum("kde,ker->kdr", Sinv, sysm.ie_M))
+        rr, cc = np.tril_indices(R)
+        U = np.einsum("kdi,kdj->kij", sysm.ie_M, self.sim)
+        self.u = np.ascontiguousarray(U[:, rr, cc])
+        self.mean_vec = np.ascontiguousarray(sysm.mean_vec.astype(f64))
+        self.lda = np.ascontiguousarray(sysm.lda.astype(f64))
+        self.plda_mean, self.plda_tr, self.plda_psi = sysm.plda_mean, sysm.plda_transform, sysm.plda_psi
+        self.zm, self.zs = sysm.z_mean, sysm.z_std
+        self.train = np.zeros((S, L), f64)
+        s = IvSystem()
+        s.C, s.D, s.R, s.L, s.S = Cn, D, R, L, S
+        s.num_gselect, s.min_post = sysm.num_gselect, sysm.min_post
+        s.dg_gconsts, s.dg_means_invvars, s.dg_inv_vars = self.dg_gc.ctypes.data, self.dg_miv.ctypes.data, self.dg_iv.ctypes.data
+        s.fg_gconsts, s.fg_means_invcovars, s.fg_inv_covars = self.fg_gc.ctypes.data, self.fg_mic.ctypes.data, self.fg_P.ctypes.data
+        s.sigma_inv_m, s.u, s.prior_offset = self.sim.ctypes.data, self.u.ctypes.data, sysm.prior_offset
+        s.mean_vec, s.lda, s.lda_cols = self.mean_vec.ctypes.data, self.lda.ctypes.data, self.lda.shape[1]
+        s.plda_mean, s.plda_transform, s.plda_psi = self.plda_mean.ctypes.data, self.plda_tr.ctypes.data, self.plda_psi.ctypes.data
+        s.train, s.z_mean, s.z_std = self.train.ctypes.data, self.zm.ctypes.data, self.zs.ctypes.data
+        s.cfg = cfg
+        s.nthreads = nthreads
+        self.s = s
+        self.S, self.R, self.L = S, R, L
+        for i in range(S):  # enrolled i-vectors through the same back-end (n = 1)
+            self.train[i] = self.backend(sysm.enrolled[i].astype(f64))
+        self.fn = C.cast(lib().fbo_iv_system_score, SCORE_FN)
+        self.ctx = C.cast(C.pointer(s), C.c_void_p)
+
+    def backend(self, ivec):
+        ivec = np.ascontiguousarray(ivec, np.float64)
+        y = np.empty(self.L, np.float64)
+        lib().fbo_iv_backend(C.byref(self.s), _p(ivec), _p(y))
+        return y
+
+    def stats(self, feats):
+        feats = np.ascontiguousarray(feats, np.float32)
+        g = np.empty(self.s.C, np.float64)
+        X = np.empty((self.s.C, self.s.D), np.float64)
+        lib().fbo_iv_stats(C.byref(self.s), _p(feats), C.c_int(feats.shape[0]), _p(g), _p(X))
+        return g, X
+
+    def extract(self, gamma, X):
+        iv = np.empty(self.R, np.float64)
+        rc = lib().fbo_iv_extract(C.byref(self.s), _p(np.ascontiguousarray(gamma)), _p(np.ascontiguousarray(X)), _p(iv))
+        if rc:
+            raise RuntimeError("oracle: i-vector system not positive definite")
+        return iv
+
+    def score_batch(self, wavs):
+        """list of int16 arrays -> (llr[B,S], ivectors[B,R], tv[B])"""
+        B = len(wavs)
+        off = np.zeros(B + 1, np.int64)
+        off[1:] = np.cumsum([len(w) for w in wavs])
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(w, np.int16) for w in wavs]))
+        llr = np.empty((B, self.S), np.float64)
+        ivs = np.empty((B, self.R), np.float64)
+        tv = np.empty(B, np.int32)
+        rc = lib().fbo_iv_score_batch(C.byref(self.s), _p(cat), _p(off), C.c_int(B), _p(llr), _p(ivs), _p(tv))
+        if rc:
+            raise RuntimeError("oracle iv score rc=%d" % rc)
+        return llr, ivs, tv
+
+    def score(self, audios):
+        a = np.ascontiguousarray(np.asarray(audios, np.float64).T)
+        B, N = a.shape
+        out = np.empty((B, self.S), np.float64)
+        rc = lib().fbo_iv_system_score(self.ctx, _p(a), C.c_int64(N), C.c_int(B), _p(out))
+        if rc:
+            raise RuntimeError("oracle iv system score rc=%d" % rc)
+        return out
