@@ -173,6 +173,142 @@ def write_diag_gmm(path, gmm, weights, binary=True):
         wf.write(out.getvalue())
 
 
+# ------------------------------------------------------------ i-vector model files
+def _read_file(path_or_bytes):
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        return bytes(path_or_bytes)
+    with open(path_or_bytes, "rb") as r:
+        return r.read()
+
+
+def _sp(rd):
+    """SpMatrix: binary "FP"/"DP" + int32 rows + packed lower-triangular data; text = full rows."""
+    if rd.binary:
+        t = rd.token()
+        if t not in ("FP", "DP"):
+            raise ValueError("kaldi_io: expected FP/DP, got %r" % t)
+        dt = np.dtype("<f4") if t == "FP" else np.dtype("<f8")
+        n = rd.int32()
+        cnt = n * (n + 1) // 2
+        v = np.frombuffer(rd.b, dt, cnt, rd.i).astype(np.float64)
+        rd.i += cnt * dt.itemsize
+        return v, n
+    m = rd.matrix()
+    n = m.shape[0]
+    r, c = np.tril_indices(n)
+    return np.array([m[i][j] for i, j in zip(r, c)], np.float64), n
+
+
+def _f64(rd):
+    if rd.binary:
+        sz = rd.b[rd.i]
+        fmt = {4: "<f", 8: "<d"}[sz]
+        v = struct.unpack_from(fmt, rd.b, rd.i + 1)[0]
+        rd.i += 1 + sz
+        return v
+    return float(rd.token())
+
+
+def read_vector(path):
+    rd = _Reader(_read_file(path))
+    return rd.vector()
+
+
+def read_matrix(path):
+    rd = _Reader(_read_file(path))
+    return rd.matrix()
+
+
+def read_full_gmm(path):
+    """final.ubm -> (weights [C], means_invcovars [C,D], inv_covars packed [C, D(D+1)/2])."""
+    rd = _Reader(_read_file(path))
+    rd.expect("<FullGMM>")
+    w = mic = None
+    covs = []
+    while True:
+        t = rd.token()
+        if t == "</FullGMM>":
+            break
+        if t == "<GCONSTS>":
+            rd.vector()
+        elif t == "<WEIGHTS>":
+            w = rd.vector()
+        elif t == "<MEANS_INVCOVARS>":
+            mic = rd.matrix()
+        elif t == "<INV_COVARS>":
+            for _ in range(len(w)):
+                covs.append(_sp(rd)[0])
+        else:
+            raise ValueError("kaldi_io: unexpected token %r in FullGmm" % t)
+    return w, mic, np.stack(covs)
+
+
+def read_ivector_extractor(path):
+    """final.ie -> (M [C,D,R], Sigma_inv packed [C, D(D+1)/2], prior_offset).  Extractors with
+    weight projections (<w> non-empty) are rejected: the voxceleb recipe trains without them."""
+    rd = _Reader(_read_file(path))
+    rd.expect("<IvectorExtractor>")
+    rd.expect("<w>")
+    wmat = rd.matrix()
+    rd.expect("<w_vec>")
+    rd.vector()
+    if wmat.size:
+        raise ValueError("kaldi_io: i-vector extractors with weight projections are unsupported")
+    rd.expect("<M>")
+    n = rd.int32()
+    M = np.stack([rd.matrix() for _ in range(n)])
+    rd.expect("<SigmaInv>")
+    S = np.stack([_sp(rd)[0] for _ in range(n)])
+    rd.expect("<IvectorOffset>")
+    off = _f64(rd)
+    rd.expect("</IvectorExtractor>")
+    return M, S, off
+
+
+def read_plda(path):
+    rd = _Reader(_read_file(path))
+    rd.expect("<Plda>")
+    mean = rd.vector()
+    tr = rd.matrix()
+    psi = rd.vector()
+    rd.expect("</Plda>")
+    return mean, tr, psi
+
+
+def read_ivector_location(loc):
+    """identity_location of a speaker-model pickle: an array, or Kaldi's `file:offset` scp form
+    pointing into a text/binary vector ark (build_spk_models.py:146-150)."""
+    if isinstance(loc, np.ndarray):
+        return loc.astype(np.float32)
+    path, _, off = str(loc).rpartition(":")
+    if not path or not off.isdigit():
+        path, off = str(loc), "0"
+    with open(path, "rb") as r:
+        r.seek(int(off))
+        data = r.read(1 << 20)
+    if data[:2] == b"\x00B":
+        return _Reader(data).vector().astype(np.float32)
+    end = data.index(b"]")
+    txt = data[:end].decode("ascii")
+    txt = txt[txt.index("[") + 1:]
+    return np.array(txt.split(), np.float32)
+
+
+def load_ivector_pre_models(pre_model_dir):
+    """pre-models/{final.ubm, final.ie, mean.vec, transform.mat, plda} -> dict of arrays."""
+    def p(name):
+        f = os.path.join(pre_model_dir, name)
+        if not os.path.isfile(f):
+            raise FileNotFoundError("i-vector system needs %s (README.md:71-81 of the reference)" % f)
+        return f
+    w, mic, covs = read_full_gmm(p("final.ubm"))
+    M, S, off = read_ivector_extractor(p("final.ie"))
+    mean, tr, psi = read_plda(p("plda"))
+    return dict(fg_weights=w, fg_means_invcovars=mic, fg_inv_covars=covs, ie_M=M, ie_sigma_inv=S,
+                prior_offset=off, mean_vec=read_vector(p("mean.vec")), lda=read_matrix(p("transform.mat")),
+                plda_mean=mean, plda_transform=tr, plda_psi=psi)
+
+
 def load_gmm_any(loc):
     """identity_location / ubm argument of the wrappers -> DiagGmm.  Accepts a DiagGmm, a Kaldi
     model file, or an .npz with gconsts / means_invvars / inv_vars."""

@@ -145,3 +145,134 @@ class gmm_SV(_GmmSystem):
         else:
             decisions = 1 if score >= self.threshold else -1
         return decisions, score
+
+
+# ------------------------------------------------------------------ i-vector / PLDA
+class _IvSystem(object):
+    task = None
+
+    def _setup(self, group_id, model_list, pre_model_dir, engine, system):
+        from .models import IvectorSystem
+        self.pre_model_dir = os.path.abspath(pre_model_dir)
+        self.group_id = os.path.abspath(group_id)
+        self.n_speakers = len(model_list)
+        spk_ids = [m[0] for m in model_list]
+        utt_ids = [m[1] for m in model_list]
+        locs = [m[2] for m in model_list]
+        zm = np.array([m[3] for m in model_list], np.float64)
+        zs = np.array([m[4] for m in model_list], np.float64)
+        # speakers are re-ordered by sorted spk_id string (ivector_PLDA_OSI.py:56-57,65-82): label
+        # indices therefore differ from the GMM wrappers' command-line order
+        if len(model_list) > 1:
+            order = []
+            for sid in sorted(spk_ids):
+                order.append(int(np.argwhere(np.array(spk_ids) == sid).flatten()[0]))
+            spk_ids = sorted(spk_ids)
+            utt_ids = [utt_ids[i] for i in order]
+            locs = [locs[i] for i in order]
+            zm, zs = zm[order], zs[order]
+        self.spk_ids, self.utt_ids, self.identity_locations = spk_ids, utt_ids, locs
+        self.z_norm_means, self.z_norm_stds = zm, zs
+        self._engine = engine if engine is not None else Engine(default_device())
+        from .kaldi_io import load_ivector_pre_models, read_ivector_location
+        enrolled = np.stack([read_ivector_location(x) for x in locs])
+        if system is None:
+            conf = os.path.join(self.pre_model_dir, "conf")
+            if os.path.isdir(conf):
+                from .config import frontend_from_kaldi_conf
+                over = frontend_from_kaldi_conf(self.pre_model_dir)
+                if over:
+                    self._engine.set_frontend(**over)
+            d = load_ivector_pre_models(self.pre_model_dir)
+            system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
+        else:
+            system = system.with_enrolled(enrolled, zm, zs)
+        self._engine.load_ivector(system, self.task)
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def _llr(self, audios, bits_per_sample):
+        raw, _tv = self._engine.score_raw(_to_audio_list(audios), bits_per_sample=bits_per_sample)
+        return raw
+
+
+class iv_OSI(_IvSystem):
+    """ivector_PLDA_OSI.py:16-143"""
+    task = "OSI"
+
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None):
+        self.threshold = threshold
+        self._setup(group_id, model_list, pre_model_dir, engine, system)
+
+    def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds   # :119
+        if self.n_speakers == 1:
+            return s[:, 0]                     # one enrolled speaker: the helper returns (B,) (:293-296)
+        return s if s.shape[0] > 1 else s[0]   # the helper returns (S,) for a single utterance (:282-296)
+
+    def make_decisions(self, audios, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        score_array = self.score(audios, fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
+        if score_array.ndim == 1:
+            score_array = score_array[np.newaxis, :]
+        max_score = np.max(score_array, axis=1)
+        decisions = np.argmax(score_array, axis=1)
+        for i, sc in enumerate(max_score):
+            if sc < self.threshold:
+                decisions[i] = -1
+        decisions = list(decisions)
+        if len(decisions) == 1:
+            return decisions[0], score_array.flatten()
+        return decisions, score_array
+
+
+class iv_CSI(_IvSystem):
+    """ivector_PLDA_CSI.py:18-135"""
+    task = "CSI"
+
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, system=None):
+        self._setup(group_id, model_list, pre_model_dir, engine, system)
+
+    def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds
+        if self.n_speakers == 1:
+            return s[:, 0]
+        return s if s.shape[0] > 1 else s[0]
+
+    def make_decisions(self, audios, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        score_array = self.score(audios, fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
+        if score_array.ndim == 1:
+            score_array = score_array[np.newaxis, :]
+        decisions = list(np.argmax(score_array, axis=1))
+        if len(decisions) == 1:
+            return decisions[0], score_array.flatten()
+        return decisions, score_array
+
+
+class iv_SV(_IvSystem):
+    """ivector_PLDA_SV.py:20-110"""
+    task = "SV"
+
+    def __init__(self, spk_id, model, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None):
+        self.threshold = threshold
+        self._setup(spk_id, [model], pre_model_dir, engine, system)
+        self.spk_id = self.group_id
+        self.utt_id = model[1]
+        self.identity_location = model[2]
+        self.z_norm_mean, self.z_norm_std = model[3], model[4]
+
+    def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        s = (self._llr(audio_list, bits_per_sample)[:, 0] - self.z_norm_mean) / self.z_norm_std   # :85
+        return s if s.size > 1 else s[0]   # (B,) or scalar (:87)
+
+    def make_decisions(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        scores = self.score(audio_list, fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
+        if isinstance(scores, np.ndarray):
+            decisions = [1 if s >= self.threshold else -1 for s in scores]
+        else:
+            decisions = 1 if scores >= self.threshold else -1
+        return decisions, scores
+
+    def make_decisions_value(self, score):
+        return -1 if score < self.threshold else 1

@@ -84,6 +84,9 @@ class FakeEngine(object):
     def set_system(self, task, zm=None, zs=None):
         self.task, self.zm, self.zs = task, zm, zs
 
+    def load_ivector(self, system, task):
+        self.system, self.task, self.n_models = system, task, system.S
+
     @property
     def n_speakers(self):
         return self.n_models if self.task == "CSI" else self.n_models - 1
@@ -193,6 +196,99 @@ def test_g6_g7_gmm_postprocessing_and_decisions(gold, tmp_path):
     csi.engine.ret = z["g6_raw_csi"][:1]
     dec, sc = csi.make_decisions(np.zeros(8))
     assert dec == meta["g7_csi_b1_dec"] and np.array_equal(sc, z["g7_csi_b1_sc"])
+
+
+def test_iv_wrappers_reorder_speakers_and_match_goldens(gold, tmp_path):
+    """ivector_PLDA_{OSI,CSI,SV}.py: speakers sorted by spk_id string, z-norm, decisions."""
+    from fakebob_amd.models import synthetic_ivector_system
+    from fakebob_amd.systems import iv_CSI, iv_OSI, iv_SV
+    meta, z = gold
+    base = synthetic_ivector_system(C=8, D=72, R=10, L=4, n_speakers=1)
+    rng = np.random.default_rng(0)
+    ml = [[m[0], m[1], rng.normal(size=10).astype(np.float32), m[3], m[4]] for m in meta["spk_models"]]
+    osi = iv_OSI(str(tmp_path / "io"), ml, pre_model_dir=str(tmp_path), threshold=1.0, engine=FakeEngine(), system=base)
+    csi = iv_CSI(str(tmp_path / "ic"), ml, pre_model_dir=str(tmp_path), engine=FakeEngine(), system=base)
+    sv = iv_SV(str(tmp_path / "is"), ml[1], pre_model_dir=str(tmp_path), threshold=1.0, engine=FakeEngine(), system=base)
+    assert osi.spk_ids == meta["iv_spk_ids"] and osi.utt_ids == meta["iv_utt_ids"]   # ['1580','2830','61']
+    assert list(osi.z_norm_means) == meta["iv_z_means"] and list(osi.z_norm_stds) == meta["iv_z_stds"]
+    # the engine received the enrolled vectors in the same (sorted) order
+    want = np.stack([ml[i][2] for i in (0, 2, 1)])
+    assert np.array_equal(osi.engine.system.enrolled, want)
+    assert list(osi.engine.system.z_mean) == meta["iv_z_means"]
+    x = np.zeros((8, 4))
+    raw = z["g6_raw_iv"]
+    osi.engine.ret = raw
+    assert np.array_equal(osi.score(x), z["g6_iv_osi_scores"])
+    dec, _ = osi.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_iv_osi_dec"])
+    osi.engine.ret = raw[:1]
+    dec, sc = osi.make_decisions(np.zeros(8))
+    assert dec == meta["g7_iv_osi_b1_dec"] and np.array_equal(sc, z["g7_iv_osi_b1_sc"])
+    csi.engine.ret = raw
+    assert np.array_equal(csi.score(x), z["g6_iv_csi_scores"])
+    dec, _ = csi.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_iv_csi_dec"])
+    sv.engine.ret = raw[:, :1]
+    assert np.array_equal(sv.score(x), z["g6_iv_sv_scores"])
+    dec, _ = sv.make_decisions(x)
+    assert np.array_equal(np.array(dec), z["g7_iv_sv_dec"])
+    sv.engine.ret = raw[:1, :1]
+    r = sv.score(np.zeros(8))
+    assert np.ndim(r) == 0 and float(r) == float(z["g6_iv_sv_b1"])
+    assert [sv.make_decisions_value(v) for v in (0.99, 1.0, 1.01)] == meta["g7_iv_sv_value"]
+
+
+def test_kaldi_ivector_file_readers(tmp_path):
+    """Round trip through hand-built Kaldi binary files ([EXT] formats; no real files offline)."""
+    import struct
+    from fakebob_amd import kaldi_io as K
+    rng = np.random.default_rng(1)
+
+    def tok(s):
+        return s.encode() + b" "
+
+    def i32(v):
+        return b"\x04" + struct.pack("<i", v)
+
+    def vec(v, d=False):
+        return tok("DV" if d else "FV") + i32(v.size) + np.asarray(v, "<f8" if d else "<f4").tobytes()
+
+    def mat(m, d=False):
+        return tok("DM" if d else "FM") + i32(m.shape[0]) + i32(m.shape[1]) + np.ascontiguousarray(m, "<f8" if d else "<f4").tobytes()
+
+    def sp(p, n, d=False):
+        return tok("DP" if d else "FP") + i32(n) + np.asarray(p, "<f8" if d else "<f4").tobytes()
+    C, D, R = 3, 4, 5
+    tri = D * (D + 1) // 2
+    w = rng.random(C).astype(np.float32)
+    mic = rng.normal(size=(C, D)).astype(np.float32)
+    covs = rng.normal(size=(C, tri)).astype(np.float32)
+    ubm = b"\x00B" + tok("<FullGMM>") + tok("<GCONSTS>") + vec(np.zeros(C)) + tok("<WEIGHTS>") + vec(w) + \
+        tok("<MEANS_INVCOVARS>") + mat(mic) + tok("<INV_COVARS>") + b"".join(sp(covs[k], D) for k in range(C)) + tok("</FullGMM>")
+    (tmp_path / "final.ubm").write_bytes(ubm)
+    M = rng.normal(size=(C, D, R))
+    S = rng.normal(size=(C, tri))
+    ie = b"\x00B" + tok("<IvectorExtractor>") + tok("<w>") + mat(np.zeros((0, 0)), True) + tok("<w_vec>") + vec(np.zeros(C), True) + \
+        tok("<M>") + i32(C) + b"".join(mat(M[k], True) for k in range(C)) + tok("<SigmaInv>") + \
+        b"".join(sp(S[k], D, True) for k in range(C)) + tok("<IvectorOffset>") + b"\x08" + struct.pack("<d", 12.5) + tok("</IvectorExtractor>")
+    (tmp_path / "final.ie").write_bytes(ie)
+    pm, pt, psi = rng.normal(size=3), rng.normal(size=(3, 3)), rng.random(3)
+    (tmp_path / "plda").write_bytes(b"\x00B" + tok("<Plda>") + vec(pm, True) + mat(pt, True) + vec(psi, True) + tok("</Plda>"))
+    (tmp_path / "mean.vec").write_bytes(b"\x00B" + vec(np.arange(R, dtype=np.float32)))
+    (tmp_path / "transform.mat").write_text(" [\n  1 2 3 4 5 0.5\n  6 7 8 9 10 -0.5 ]\n")
+    d = K.load_ivector_pre_models(str(tmp_path))
+    assert np.array_equal(d["fg_weights"], w) and np.array_equal(d["fg_means_invcovars"], mic)
+    assert np.array_equal(d["fg_inv_covars"], covs)
+    assert np.array_equal(d["ie_M"], M) and np.array_equal(d["ie_sigma_inv"], S) and d["prior_offset"] == 12.5
+    assert np.array_equal(d["plda_mean"], pm) and np.array_equal(d["plda_transform"], pt) and np.array_equal(d["plda_psi"], psi)
+    assert np.array_equal(d["mean_vec"], np.arange(R)) and d["lda"].shape == (2, 6)
+    # ivector.scp style `file:offset` into a text ark (build_spk_models.py:146-150)
+    ark = tmp_path / "ivector.1.ark"
+    ark.write_text("spk-utt  [ 0.5 -1.25 3 ]\nother  [ 1 2 ]\n")
+    assert np.array_equal(K.read_ivector_location("%s:%d" % (ark, 8)), np.array([0.5, -1.25, 3], np.float32))
+    assert np.array_equal(K.read_ivector_location("%s:%d" % (ark, 32)), np.array([1, 2], np.float32))
+    with pytest.raises(FileNotFoundError):
+        K.load_ivector_pre_models(str(tmp_path / "nope"))
 
 
 # ------------------------------------------------------------- file readers
