@@ -54,25 +54,26 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch  # device sync + torch.distributed (RCCL); imported before the HIP library
+    from fakebob_amd import parallel
+    rank, local_rank, world = parallel.dist_env()
+    dev_index = 0 if args.same_device else local_rank
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(dev_index)
+        dist = parallel.init_process_group(args.dist_backend)
     from fakebob_amd.engine import Engine, nes_params
     from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
 
     ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
     models = [ubm] + spk
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     eng.load_gmm(models)
     eng.set_system("OSI")
     audio = synthetic_audio(rank, N_SAMPLES)  # utterance `rank`
@@ -92,14 +93,17 @@ def main():
     ms_dev, ms_gmm, rows = eng.bench_nes(p, audio, 0, args.steps, time_gmm=True)
     barrier()
     dt = time.perf_counter() - t0
+    total_steps = args.steps
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # final counter reduction (mirrors success_cnt / total_cnt, attackMain.py:312,411)
-        cnt = torch.tensor([args.steps, args.steps * (SPD + 1), rows], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    its = world * args.steps / dt
+        # final counter reduction (mirrors success_cnt / total_cnt, attackMain.py:312,411): the only
+        # data the ranks ever exchange
+        total_steps, total_scored, _ = parallel.reduce_counters([args.steps, args.steps * (SPD + 1), rows], dist)
+        assert total_steps == world * args.steps
+    its = total_steps / dt
     out = None
     if rank == 0:
         gmm_ms_avg = ms_gmm / args.steps
@@ -117,11 +121,19 @@ def main():
                                    "N=48000 (3 s @ 16 kHz), 1 utterance per GPU",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
-            "roofline": {"kernel": "k_gmm<36> (diag-GMM log-likelihood + logsumexp, f32 MFMA)",
+            # `achieved` uses the ALGORITHMIC flops of SURVEY.md 8(d): (S+1)*C*4D per voiced frame (two
+            # length-D dot products per component per model, as Kaldi evaluates them).  The kernel
+            # shares the quadratic term across the 6 models (mean-only MAP adaptation), so it EXECUTES
+            # (1 + M)/(2M) = 7/12 of those flops on the matrix cores: `executed_*` is the honest
+            # hardware utilisation, `frac` may therefore exceed 1.
+            "roofline": {"kernel": "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "avg_launch_ms": gmm_ms_avg,
                          "algorithmic_flops_per_launch": flops_launch,
+                         "executed_flops_per_launch": flops_launch * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
+                         "executed_tflops": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
+                         "executed_frac": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)) / PEAK_F32_MFMA_TFLOPS,
                          "gmm_share_of_step": ms_gmm / ms_dev if ms_dev > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
