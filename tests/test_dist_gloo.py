@@ -43,7 +43,8 @@ WORKER = textwrap.dedent('''
         return (1 if item %% 3 else -1), item + 1, 51 * (item + 1)
     g = P.run_sharded(list(range(11)), attack, estimate, dist)
     assert (len(calls) == 1) == (rank == 0)         # only rank 0 estimates
-    print(json.dumps({"rank": rank, "g": g[:4], "local": g[4]}))
+    with open(sys.argv[1] + "/rank%d.json" % rank, "w") as w:     # per-rank file: stdout of two ranks interleaves
+        json.dump({"rank": rank, "g": g[:4], "local": g[4]}, w)
     dist.barrier()
     dist.destroy_process_group()
 ''') % ROOT
@@ -53,13 +54,12 @@ def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), str(tmp_path)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:]
     import json
-    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(rows) == 2
+    rows = [json.load(open(str(tmp_path / ("rank%d.json" % k)))) for k in range(2)]
     items = list(range(11))
     want = [sum(1 for i in items if i % 3), 11, sum(i + 1 for i in items), 51 * sum(i + 1 for i in items)]
     for row in rows:
