@@ -43,7 +43,7 @@ WORKER = textwrap.dedent('''
         return (1 if item %% 3 else -1), item + 1, 51 * (item + 1)
     g = P.run_sharded(list(range(11)), attack, estimate, dist)
     assert (len(calls) == 1) == (rank == 0)         # only rank 0 estimates
-    with open(sys.argv[1] + "/rank%d.json" % rank, "w") as w:     # per-rank file: stdout of two ranks interleaves
+    with open(sys.argv[1] + "/rank%%d.json" %% rank, "w") as w:     # per-rank file: stdout of two ranks interleaves
         json.dump({"rank": rank, "g": g[:4], "local": g[4]}, w)
     dist.barrier()
     dist.destroy_process_group()
