@@ -10,6 +10,13 @@ clip, with the early-stop *test* evaluated but not taken so that exactly K steps
 Synthetic audio and seeded synthetic models: no dataset / Kaldi models exist
 offline.
 
+Attacks in flight: attacks on different utterances are independent (attackMain.py:324-409), so each
+GPU runs --streams K of them concurrently, one engine (= HIP stream + device state) each, driven from K
+host threads (ctypes releases the GIL).  Kernels of different attacks then overlap on the chip --
+the float64 VALU front-end of one attack runs beside the MFMA GMM kernel of another -- which is what
+fills the gaps a single launch chain leaves.  One "step" = one NES iteration of each of the K attacks
+in flight; `value` counts all of them.
+
 Multi-GPU: utterances are independent (attackMain.py:324-409), so each rank attacks its own
 utterance ("weak" scaling, no data-path collective); RCCL is used only for the barrier, the
 max-over-ranks time and the final counter reduction.
@@ -53,6 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=3, help="attacks in flight per GPU (one engine/stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
     ap.add_argument("--same-device", action="store_true",
@@ -71,15 +79,31 @@ def main():
     from fakebob_amd.engine import Engine, nes_params
     from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
 
+    import threading
+    K = max(1, args.streams)
     ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
     models = [ubm] + spk
-    eng = Engine(dev_index)
-    eng.load_gmm(models)
-    eng.set_system("OSI")
-    audio = synthetic_audio(rank, N_SAMPLES)  # utterance `rank`
     kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_lr=0.001, min_lr=1e-6, momentum=0.9,
               plateau_length=5, plateau_drop=2.0, adver_thresh=0.0, max_iter=1000, target=0, threshold=0.2277)
-    p = nes_params("OSI", "targeted", seed=42, stream=rank, **kw)
+    engs, auds, prms = [], [], []
+    for k in range(K):
+        e = Engine(dev_index)
+        e.load_gmm(models)
+        e.set_system("OSI")
+        engs.append(e)
+        utt = rank * K + k                                  # a different utterance per attack
+        auds.append(synthetic_audio(utt, N_SAMPLES))
+        prms.append(nes_params("OSI", "targeted", seed=42, stream=utt, **kw))
+    audio = auds[0]
+    results = [None] * K
+
+    def run(k, n, timed):
+        results[k] = engs[k].bench_nes(prms[k], auds[k], 0, n, time_gmm=timed)
+
+    def run_all(n, timed):
+        ths = [threading.Thread(target=run, args=(k, n, timed)) for k in range(K)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
 
     def barrier():
         if dist is not None:
@@ -87,13 +111,16 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup > 0:
-        eng.bench_nes(p, audio, 0, args.warmup)
+        run_all(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    ms_dev, ms_gmm, rows = eng.bench_nes(p, audio, 0, args.steps, time_gmm=True)
+    run_all(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
-    total_steps = args.steps
+    ms_dev = sum(r[0] for r in results) / K
+    ms_gmm = sum(r[1] for r in results) / K                 # per attack: sum over its timed launches
+    rows = int(sum(r[2] for r in results) / K)
+    total_steps = args.steps * K
     if dist is not None:
         tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
@@ -101,8 +128,8 @@ def main():
         dt = float(t.item())
         # final counter reduction (mirrors success_cnt / total_cnt, attackMain.py:312,411): the only
         # data the ranks ever exchange
-        total_steps, total_scored, _ = parallel.reduce_counters([args.steps, args.steps * (SPD + 1), rows], dist)
-        assert total_steps == world * args.steps
+        total_steps, total_scored, _ = parallel.reduce_counters([args.steps * K, args.steps * K * (SPD + 1), rows], dist)
+        assert total_steps == world * args.steps * K
     its = total_steps / dt
     out = None
     if rank == 0:
@@ -118,7 +145,9 @@ def main():
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS,
             "config": {"workload": "GMM-UBM OSI targeted, 5 speakers+UBM, C=2048, D=72, spd=50, "
-                                   "N=48000 (3 s @ 16 kHz), 1 utterance per GPU",
+                                   "N=48000 (3 s @ 16 kHz), %d attacks in flight per GPU "
+                                   "(1 step = 1 NES iteration of each)" % K,
+                       "attacks_in_flight_per_gpu": K,
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
             # `achieved` uses the ALGORITHMIC flops of SURVEY.md 8(d): (S+1)*C*4D per voiced frame (two
@@ -134,8 +163,14 @@ def main():
                          "executed_flops_per_launch": flops_launch * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
                          "executed_tflops": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
                          "executed_frac": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)) / PEAK_F32_MFMA_TFLOPS,
-                         "gmm_share_of_step": ms_gmm / ms_dev if ms_dev > 0 else None},
+                         "gmm_share_of_stream_time": ms_gmm / ms_dev if ms_dev > 0 else None,
+                         "note": "launch durations are HIP-event times on each attack's own stream; with "
+                                 "several attacks in flight they include time shared with other attacks' "
+                                 "kernels (solo launch: see solo_launch_ms)"},
         }
+        solo_ms, solo_rows = engs[0].bench_gmm_kernel(20)   # same kernel, same data, chip to itself
+        out["roofline"]["solo_launch_ms"] = solo_ms
+        out["roofline"]["solo_achieved"] = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows / (solo_ms * 1e-3) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             ckw = dict(kw)
             out["cpu_baseline"] = cpu_baseline(audio, models, ckw)
@@ -145,7 +180,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engs:
+        e.close()
 
 
 if __name__ == "__main__":
