@@ -55,6 +55,57 @@ def cpu_baseline(audio, models, params_kw):
                       "CPU oracle single thread, %.1f s" % dt}
 
 
+def bench_ivector(args, torch):
+    """BASELINE.json configs[2]: i-vector-PLDA SV targeted attack, spd=50, C=2048, D=72, R=400, LDA 200
+    (the T-matrix contraction path).  Not the headline metric: run with --arch iv."""
+    from fakebob_amd.engine import Engine, nes_params
+    from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+    t0 = time.perf_counter()
+    sy = synthetic_ivector_system(C=C_GAUSS, D=D_FEAT, R=400, L=200, n_speakers=1)
+    sy = sy.with_enrolled(sy.enrolled, [-40.0], [10.0])
+    eng = Engine(0)
+    eng.load_ivector(sy, "SV")
+    t_load = time.perf_counter() - t0
+    audio = synthetic_audio(0, N_SAMPLES)
+    kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_iter=1000, threshold=1.0)
+    p = nes_params("SV", "targeted", seed=42, stream=0, **kw)
+    eng.bench_nes(p, audio, 0, max(1, args.warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_dev, ms_con, rows = eng.bench_nes(p, audio, 0, args.steps, time_gmm=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = args.steps / dt
+    tri = 400 * 401 // 2
+    bytes_stream = 8.0 * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)       # Sigma^-1 M + U, float64, read once
+    con_ms = ms_con / args.steps
+    out = {"metric": "NES iterations/sec (i-vector-PLDA SV, samples_per_draw=50, 3 s@16 kHz)", "value": its,
+           "unit": "NES iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64 (extractor/PLDA), f32 MFMA (gselect)", "data": "synthetic",
+           "vs_readme_nominal": its / 0.083,
+           "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
+                                  "1 attack in flight", "voiced_rows_per_iter": rows, "model_load_s": t_load},
+           "roofline": {"kernel": "k_iv_lin + k_iv_quad (T-matrix contraction, float64)", "bound": "hbm",
+                        "achieved": bytes_stream / (con_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": bytes_stream / (con_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                        "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_stream,
+                        "flops_per_launch": 2.0 * (SPD + 1) * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        import numpy as np
+        ctx = O.IvSystemCtx(O.default_cfg(), sy, nthreads=1)
+        wavs = [(synthetic_audio(u, N_SAMPLES) * 32768).astype(np.int16) for u in range(8)]
+        t0 = time.perf_counter()
+        ctx.score_batch(wavs)
+        t8 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / (t8 * (SPD + 1) / 8.0), "unit": "NES iterations/s", "cores": 1,
+                               "kind": "port", "sample": "8 of the 51 utterances of one NES batch scored by the CPU "
+                               "oracle (1 thread, %.1f s), scaled to 51" % t8}
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,12 +113,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=3, help="attacks in flight per GPU (one engine/stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arch", default="gmm", choices=["gmm", "iv"], help="gmm = headline (configs[1]); iv = configs[2]")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
     args = ap.parse_args()
 
     import torch  # device sync + torch.distributed (RCCL); imported before the HIP library
+    if args.arch == "iv":
+        return bench_ivector(args, torch)
     from fakebob_amd import parallel
     rank, local_rank, world = parallel.dist_env()
     dev_index = 0 if args.same_device else local_rank
@@ -168,6 +222,13 @@ def main():
                                  "several attacks in flight they include time shared with other attacks' "
                                  "kernels (solo launch: see solo_launch_ms)"},
         }
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable in-process)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as r:
+                tr = json.load(r)["kernels"]["k_gmm<36, false>"]
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
+        except Exception:
+            pass
         solo_ms, solo_rows = engs[0].bench_gmm_kernel(20)   # same kernel, same data, chip to itself
         out["roofline"]["solo_launch_ms"] = solo_ms
         out["roofline"]["solo_achieved"] = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows / (solo_ms * 1e-3) / 1e12
