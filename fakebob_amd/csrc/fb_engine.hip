@@ -92,8 +92,9 @@ struct fb_engine {
   int n_out = 0;  // columns of `raw`: models (GMM) or enrolled speakers (i-vector)
   FbIvDev iv;
   DevBuf iv_fg, iv_tri, iv_sim, iv_u, iv_backend;
-  DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_ivec, iv_fail;
+  DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_linv, iv_ivec, iv_fail, iv_active, iv_bws, iv_pairs, iv_llf;
   int iv_kchunks = 96;
+  int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
   // system
   int task = FB_TASK_OSI;
   DevBuf zmean, zstd;
@@ -147,7 +148,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_ivec, &e->iv_fail};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -486,27 +487,43 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(e->iv_ll.ensure(sizeof(float) * (size_t)total_frames * iv.Cpad));
     FBCHK(e->iv_sel.ensure(sizeof(int) * (size_t)total_frames * iv.nsel));
     FBCHK(e->iv_post.ensure(sizeof(float) * (size_t)total_frames * iv.nsel));
-    FBCHK(e->iv_gamma.ensure(sizeof(double) * (size_t)B * iv.C));
-    FBCHK(e->iv_X.ensure(sizeof(double) * (size_t)B * Q));
+    FBCHK(e->iv_bws.ensure(sizeof(int) * (size_t)(4 * iv.C + 8)));
+    FBCHK(e->iv_pairs.ensure(sizeof(int) * (size_t)total_frames * iv.nsel));
+    FBCHK(e->iv_llf.ensure(sizeof(float) * (size_t)total_frames * iv.nsel));
+    const int Bpad = (B + 31) / 32 * 32;
+    {
+      const size_t cg = e->iv_gamma.cap, cx = e->iv_X.cap;
+      FBCHK(e->iv_gamma.ensure(sizeof(double) * (size_t)Bpad * iv.C));
+      FBCHK(e->iv_X.ensure(sizeof(double) * (size_t)Bpad * Q));
+      if (Bpad != e->iv_Bpad || cg != e->iv_gamma.cap || cx != e->iv_X.cap) {  // zero the padding columns once
+        HIPCHK(hipMemsetAsync(e->iv_gamma.p, 0, sizeof(double) * (size_t)Bpad * iv.C, s));
+        HIPCHK(hipMemsetAsync(e->iv_X.p, 0, sizeof(double) * (size_t)Bpad * Q, s));
+        e->iv_Bpad = Bpad;
+      }
+    }
     FBCHK(e->iv_linp.ensure(sizeof(double) * (size_t)e->iv_kchunks * B * iv.R));
     FBCHK(e->iv_quad.ensure(sizeof(double) * (size_t)B * iv.triR));
     FBCHK(e->iv_A.ensure(sizeof(double) * (size_t)B * iv.R * iv.R));
+    FBCHK(e->iv_linv.ensure(sizeof(double) * (size_t)B * ((iv.R + 31) / 32) * 1024));
     FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
     FBCHK(e->iv_fail.ensure(sizeof(int)));
+    FBCHK(e->iv_active.ensure(sizeof(int) * (size_t)(iv.C + 1)));
     HIPCHK(hipMemsetAsync(e->iv_fail.p, 0, sizeof(int), s));
     fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                        e->iv_ll.as<float>());
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
-                             total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>());
+                             total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
+                             e->iv_pairs.as<int>(), e->iv_llf.as<float>());
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_sel.as<int>(),
-                       e->iv_post.as<float>(), B, e->iv_gamma.as<double>(), e->iv_X.as<double>());
+                       e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
     // bench timing of the T-matrix contraction (k_iv_lin + k_iv_quad): the HBM-streaming kernels
     if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
-    fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, e->iv_kchunks,
-                          e->iv_linp.as<double>(), e->iv_quad.as<double>());
+    fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
+                          e->iv_active.as<int>(), e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(),
+                          e->iv_quad.as<double>());
     if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
     fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
-                       e->iv_A.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+                       e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
   }
   HIPCHK(hipGetLastError());
@@ -784,7 +801,8 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
   HIPCHK(hipMemcpy(e->zstd.p, e->h_zstd.data(), sizeof(double) * S, hipMemcpyHostToDevice));
   // split of the (C*D)-long contraction: enough workgroups to stream Sigma^-1 M at HBM rate
   const int64_t Q = (int64_t)C * D;
-  e->iv_kchunks = (int)(Q / 512 > 256 ? 256 : (Q / 512 < 1 ? 1 : Q / 512));
+  (void)Q;
+  e->iv_kchunks = C / 8 > 128 ? 128 : (C / 8 < 1 ? 1 : C / 8);  // chunks of the active-component list
   return FB_OK;
 }
 

@@ -17,6 +17,7 @@
 //   k_iv_solve          blocked Cholesky + triangular solves of the B (R x R) systems
 //   k_iv_backend        mean subtraction, LDA, length norm, PLDA transform, LLR vs enrolled
 #include <float.h>
+#include <stdlib.h>
 
 #include "fb_device.h"
 #include "fb_kernels.h"
@@ -63,26 +64,34 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 }
 
 // ------------------------------------------------ gselect + posteriors (K8/K9)
-// One wave per voiced frame.  LDS per wave: the Cpad log-likelihoods of the frame + its D features.
-__global__ __launch_bounds__(256) void k_iv_select_post(FbIvDev iv, const float *__restrict__ ll,
-                                                        const float *__restrict__ feats,
-                                                        const int *__restrict__ n_rows_ptr,
-                                                        int *__restrict__ sel, float *__restrict__ post) {
+// Gathering 20 packed 72x72 precision matrices (10.5 KB each) per frame from L2/MALL is what a
+// frame-major kernel spends its time on (3.3 GB per NES batch, measured 1.5 ms).  The work is
+// therefore transposed: frames are bucketed by selected component, one workgroup owns one
+// component (its matrix lives in registers) and walks the frames that selected it.
+//   k_iv_select        wave = frame: top-n of the diagonal log-likelihoods (+ bucket histogram)
+//   k_iv_bucket_scan   bucket offsets and the (component, 128-entry chunk) work list
+//   k_iv_bucket_fill   (frame, slot) pairs into their bucket
+//   k_iv_fullcov       workgroup = (component, chunk): full-covariance log-likelihood of each pair
+//   k_iv_post          wave = frame: softmax over the n values, min-post pruning, renormalisation
+// Values are independent of the (atomic) bucket order: each pair writes its own output slot.
+#define FB_IV_CH 128  // bucket entries per workgroup
+
+__global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
+                                                   const int *__restrict__ n_rows_ptr, int *__restrict__ sel,
+                                                   int *__restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n_rows = *n_rows_ptr;
   const int row = blockIdx.x * 4 + w;
   if (row >= n_rows) return;  // whole wave exits; no block-level barriers below
-  const int Cpad = iv.Cpad, D = iv.D, nsel = iv.nsel;
-  float *vals = smf + (size_t)w * (Cpad + 128);
-  float *xs = vals + Cpad;
+  const int Cpad = iv.Cpad, nsel = iv.nsel;
+  float *vals = smf + (size_t)w * Cpad;
   const float *lr = ll + (size_t)row * Cpad;
   for (int i = lane; i < Cpad; i += 64) vals[i] = (i < iv.C) ? lr[i] : -FLT_MAX;
-  for (int i = lane; i < D; i += 64) xs[i] = feats[(size_t)row * D + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // ---- top-nsel, descending by (value, index) like std::greater<pair<float,int>>
+  // top-nsel, descending by (value, index) like std::greater<pair<float,int>>
   int my_k = -1;  // lane j < nsel keeps the j-th selected component
   for (int s = 0; s < nsel; ++s) {
     float bv = -FLT_MAX;
@@ -103,34 +112,134 @@ __global__ __launch_bounds__(256) void k_iv_select_post(FbIvDev iv, const float 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // ---- full-covariance log-likelihoods of the selected components
-  const int triD = iv.triD;
-  double my_ll = -INFINITY;
-  for (int s = 0; s < nsel; ++s) {
-    const int k = __shfl(my_k, s, 64);
-    double acc = 0.0;
-    if (k >= 0 && k < iv.C) {
-      const float *P = iv.fg_P + (size_t)k * triD;
-      const float *mic = iv.fg_mic + (size_t)k * D;
-      for (int e = lane; e < triD; e += 64) {
-        const int r = iv.tri_r[e], c = iv.tri_c[e];
-        const double xr = (double)xs[r], xc = (double)xs[c];
-        const double t = (double)P[e] * xr * xc;
-        acc -= (r == c) ? 0.5 * t : t;
-      }
-      for (int d = lane; d < D; d += 64) acc = fma((double)mic[d], (double)xs[d], acc);
-    }
-    acc = fb_wave_sum(acc);
-    if (lane == s) my_ll = (k >= 0 && k < iv.C) ? (double)(float)((double)iv.fg_gconsts[k] + acc) : -INFINITY;
+  if (lane < nsel) {
+    sel[(size_t)row * nsel + lane] = my_k;
+    if (my_k >= 0 && my_k < iv.C) atomicAdd(&hist[my_k], 1);
   }
-  // ---- softmax over the nsel lanes, min-post pruning, renormalisation
-  const double mx = fb_wave_max(lane < nsel ? my_ll : -INFINITY);
-  double ex = (lane < nsel && my_ll > -INFINITY) ? exp(my_ll - mx) : 0.0;
+}
+
+// bstart[C+1] = exclusive scan of hist; wstart[C+1] = exclusive scan of ceil(hist/CH); cursor = 0
+__global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, const int *__restrict__ hist,
+                                                         int *__restrict__ bstart, int *__restrict__ wstart,
+                                                         int *__restrict__ cursor) {
+  __shared__ int sa[1024], sb[1024];
+  const int per = (C + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(C, lo + per);
+  int a = 0, bsum = 0;
+  for (int k = lo; k < hi; ++k) { a += hist[k]; bsum += (hist[k] + FB_IV_CH - 1) / FB_IV_CH; }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = bsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ra = 0, rb = 0;
+    for (int i = 0; i < 1024; ++i) { const int va = sa[i], vb = sb[i]; sa[i] = ra; sb[i] = rb; ra += va; rb += vb; }
+    bstart[C] = ra;
+    wstart[C] = rb;
+  }
+  __syncthreads();
+  int ra = sa[threadIdx.x], rb = sb[threadIdx.x];
+  for (int k = lo; k < hi; ++k) {
+    bstart[k] = ra;
+    wstart[k] = rb;
+    cursor[k] = 0;
+    ra += hist[k];
+    rb += (hist[k] + FB_IV_CH - 1) / FB_IV_CH;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_iv_bucket_fill(FbIvDev iv, const int *__restrict__ n_rows_ptr,
+                                                        const int *__restrict__ sel, const int *__restrict__ bstart,
+                                                        int *__restrict__ cursor, int *__restrict__ pairs) {
+  const int n = *n_rows_ptr * iv.nsel;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = sel[i];
+  if (k < 0 || k >= iv.C) return;
+  pairs[bstart[k] + atomicAdd(&cursor[k], 1)] = i;
+}
+
+// TRI64 = ceil(D(D+1)/2 / 64): 42 for D = 72 (the recipe), 52 covers D <= 80
+template <int TRI64>
+__global__ __launch_bounds__(256) void k_iv_fullcov(FbIvDev iv, const float *__restrict__ feats,
+                                                    const int *__restrict__ bstart, const int *__restrict__ wstart,
+                                                    const int *__restrict__ pairs, float *__restrict__ llf) {
+  __shared__ float xs[4][128];
+  const int n_work = wstart[iv.C];
+  const int wi = blockIdx.x;
+  if (wi >= n_work) return;
+  // component owning work item wi: largest k with wstart[k] <= wi
+  int lo = 0, hi = iv.C;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (wstart[mid] <= wi) lo = mid; else hi = mid;
+  }
+  const int k = lo;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int D = iv.D, triD = iv.triD, nsel = iv.nsel;
+  const int e0 = bstart[k] + (wi - wstart[k]) * FB_IV_CH;
+  const int e1 = min(bstart[k + 1], e0 + FB_IV_CH);
+  // this lane's entries of the packed precision matrix, with the 1/2 of the diagonal folded in
+  float pk[TRI64];
+  unsigned short rc[TRI64];
+  const float *P = iv.fg_P + (size_t)k * triD;
+#pragma unroll
+  for (int i = 0; i < TRI64; ++i) {
+    const int e = lane + 64 * i;
+    const int ec = min(e, triD - 1);
+    const int r = iv.tri_r[ec], c = iv.tri_c[ec];
+    float v = (e < triD) ? P[ec] : 0.0f;
+    if (r == c) v *= 0.5f;
+    pk[i] = v;
+    rc[i] = (unsigned short)(r | (c << 8));
+  }
+  const float *mic = iv.fg_mic + (size_t)k * D;
+  const double m0 = lane < D ? (double)mic[lane] : 0.0, m1 = lane + 64 < D ? (double)mic[lane + 64] : 0.0;
+  const double gck = (double)iv.fg_gconsts[k];
+  float *x = xs[w];
+  for (int e = e0 + w; e < e1; e += 4) {
+    const int pr = pairs[e];
+    const int row = pr / nsel;
+    for (int i = lane; i < D; i += 64) x[i] = feats[(size_t)row * D + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < TRI64; ++i) {
+      const double xr = (double)x[rc[i] & 0xff], xc = (double)x[rc[i] >> 8];
+      acc = fma(-(double)pk[i], xr * xc, acc);
+    }
+    if (lane < D) acc = fma(m0, (double)x[lane], acc);
+    if (lane + 64 < D) acc = fma(m1, (double)x[lane + 64], acc);
+    acc = fb_wave_sum(acc);
+    if (lane == 0) llf[pr] = (float)(gck + acc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// softmax over the nsel full-covariance log-likelihoods of a frame + min-post pruning: lane = slot
+__global__ __launch_bounds__(256) void k_iv_post(FbIvDev iv, const int *__restrict__ n_rows_ptr,
+                                                 const int *__restrict__ sel, const float *__restrict__ llf,
+                                                 float *__restrict__ post) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= *n_rows_ptr) return;
+  const int nsel = iv.nsel;
+  int k = -1;
+  double my_ll = -INFINITY;
+  if (lane < nsel) {
+    k = sel[(size_t)row * nsel + lane];
+    if (k >= 0 && k < iv.C) my_ll = (double)llf[(size_t)row * nsel + lane];
+  }
+  const double mx = fb_wave_max(my_ll);
+  const double ex = (my_ll > -INFINITY) ? exp(my_ll - mx) : 0.0;
   const double sum = fb_wave_sum(ex);
   float p = (lane < nsel) ? (float)(ex / sum) : 0.0f;
   const float min_post = iv.min_post;
   if (min_post != 0.0f) {
-    // first lane holding the maximum posterior (Vector::Max(&index) semantics: first max)
+    // first slot holding the maximum posterior (Vector::Max(&index) semantics: first max)
     float pm = p;
     int pi = lane < nsel ? lane : 64;
 #pragma unroll
@@ -144,17 +253,28 @@ __global__ __launch_bounds__(256) void k_iv_select_post(FbIvDev iv, const float 
     if (s2 == 0.0) p = (lane == pi) ? 1.0f : 0.0f;
     else p = (float)((double)p / s2);
   }
-  if (lane < nsel) {
-    sel[(size_t)row * nsel + lane] = my_k;
-    post[(size_t)row * nsel + lane] = p;
-  }
+  if (lane < nsel) post[(size_t)row * nsel + lane] = p;
 }
+
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
-                              const int *n_rows_ptr, int rows_cap, int *sel, float *post) {
+                              const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
+                              int *pairs, float *llf) {
   if (rows_cap <= 0) return;
-  size_t shm = sizeof(float) * 4 * (size_t)(iv.Cpad + 128);
-  hipLaunchKernelGGL(k_iv_select_post, dim3((rows_cap + 3) / 4), dim3(256), shm, s, iv, ll, feats, n_rows_ptr, sel,
-                     post);
+  const int C = iv.C;
+  int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *cursor = wstart + (C + 1);
+  (void)hipMemsetAsync(hist, 0, sizeof(int) * C, s);
+  hipLaunchKernelGGL(k_iv_select, dim3((rows_cap + 3) / 4), dim3(256), sizeof(float) * 4 * (size_t)iv.Cpad, s, iv,
+                     ll, n_rows_ptr, sel, hist);
+  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, cursor);
+  const int n_pairs_cap = rows_cap * iv.nsel;
+  hipLaunchKernelGGL(k_iv_bucket_fill, dim3((n_pairs_cap + 255) / 256), dim3(256), 0, s, iv, n_rows_ptr, sel, bstart,
+                     cursor, pairs);
+  const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
+  if (iv.triD <= 42 * 64)
+    hipLaunchKernelGGL((k_iv_fullcov<42>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);
+  else
+    hipLaunchKernelGGL((k_iv_fullcov<52>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);
+  hipLaunchKernelGGL(k_iv_post, dim3((rows_cap + 3) / 4), dim3(256), 0, s, iv, n_rows_ptr, sel, llf, post);
 }
 
 // ------------------------------------------------------- statistics (K10a)
@@ -162,8 +282,8 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
 #define FB_IV_DMAX4 20  // D <= 80
 __global__ __launch_bounds__(256) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
                                                   const int *__restrict__ row_off, const int *__restrict__ sel,
-                                                  const float *__restrict__ post, double *__restrict__ gamma,
-                                                  double *__restrict__ X) {
+                                                  const float *__restrict__ post, int Bpad,
+                                                  double *__restrict__ gammaT, double *__restrict__ XT) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   const int b = blockIdx.x, k0 = blockIdx.y * 64;
   const int D = iv.D, nsel = iv.nsel;
@@ -203,243 +323,325 @@ __global__ __launch_bounds__(256) void k_iv_stats(FbIvDev iv, const float *__res
     }
     __syncthreads();
   }
+  // outputs are utterance-minor ([k][Bpad], [k*D+d][Bpad]) so that the contraction kernels can fetch
+  // the per-utterance coefficients of one row with scalar loads
   const int k = k0 + c;
   if (k < iv.C) {
-    if (dg == 0) gamma[(size_t)b * iv.C + k] = gam;
+    if (dg == 0) gammaT[(size_t)k * Bpad + b] = gam;
 #pragma unroll
     for (int i = 0; i < FB_IV_DMAX4; ++i) {
       const int d = dg + 4 * i;
-      if (d < D) X[((size_t)b * iv.C + k) * D + d] = acc[i];
+      if (d < D) XT[((size_t)k * D + d) * Bpad + b] = acc[i];
     }
   }
 }
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *sel,
-                        const float *post, int B, double *gamma, double *X) {
+                        const float *post, int B, int Bpad, double *gammaT, double *XT) {
   size_t shm = sizeof(float) * (64 * 64 + 64 * (size_t)iv.D);
-  hipLaunchKernelGGL(k_iv_stats, dim3(B, (iv.C + 63) / 64), dim3(256), shm, s, iv, feats, row_off, sel, post, gamma,
-                     X);
+  hipLaunchKernelGGL(k_iv_stats, dim3(B, (iv.C + 63) / 64), dim3(256), shm, s, iv, feats, row_off, sel, post, Bpad,
+                     gammaT, XT);
 }
 
 // ---------------------------------------------- T-matrix contraction (K10b)
-// lin partials: grid (n_kchunks, ceil(B/BT)); thread = one i-vector dimension r.
+// Components that no utterance of the batch gave any posterior mass contribute nothing to lin / quad
+// (Kaldi's GetIvectorDistMean skips gamma == 0 as well).  After gselect(20) + min-post pruning only a
+// few hundred of the C Gaussians are touched by a 3-s utterance, and the 51 utterances of an NES batch
+// are noisy copies of one utterance, so the contraction streams only the active rows of Sigma^-1 M / U.
+__global__ __launch_bounds__(1024) void k_iv_active(int C, int Bpad, const double *__restrict__ gammaT,
+                                                    int *__restrict__ active, int *__restrict__ n_active) {
+  __shared__ int s_cnt[17];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < C; k0 += 1024) {  // ascending k: deterministic list order
+    const int k = k0 + threadIdx.x;
+    int any = 0;
+    if (k < C) {
+      const double *g = gammaT + (size_t)k * Bpad;
+      for (int b = 0; b < Bpad; ++b) any |= (g[b] != 0.0);
+    }
+    const unsigned long long bal = __ballot(any);
+    if (lane == 0) s_cnt[w] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int i = 0; i < w; ++i) off += s_cnt[i];
+    if (any) active[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += s_cnt[i]; s_base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_active = s_base;
+}
+
+// Both kernels stream float64 parameter rows exactly once per pass (coalesced, one column per thread)
+// and keep BT utterances of accumulators in VGPRs.  The per-utterance coefficients of the current row
+// (gammaT[k][*] / XT[q][*], contiguous, zero-padded to Bpad) are wave-uniform: they are fetched with
+// scalar loads and enter v_fmac_f64 as SGPR operands -- no LDS, no barriers.
 #define FB_IV_BT 32
-__global__ __launch_bounds__(512) void k_iv_lin(FbIvDev iv, const double *__restrict__ X, int B, int rows_per_chunk,
-                                                double *__restrict__ linp) {
-  extern __shared__ __attribute__((aligned(16))) double smd[];  // [BT][32]
-  const int R = iv.R;
-  const int64_t Q = (int64_t)iv.C * iv.D;
-  const int64_t q0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t q1 = min(Q, q0 + rows_per_chunk);
+__global__ __launch_bounds__(512) void k_iv_lin(FbIvDev iv, const double *__restrict__ XT,
+                                                const int *__restrict__ active, const int *__restrict__ n_active,
+                                                int B, int Bpad, int n_kchunks, double *__restrict__ linp) {
+  const int R = iv.R, D = iv.D;
+  const int na = *n_active;
+  const int per = (na + n_kchunks - 1) / n_kchunks;  // active components per chunk
+  const int a0 = blockIdx.x * per, a1 = min(na, a0 + per);
   const int b0 = blockIdx.y * FB_IV_BT;
-  const int nb = min(FB_IV_BT, B - b0);
   const int r = threadIdx.x;
+  if (r >= R) return;
   double acc[FB_IV_BT];
 #pragma unroll
   for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
-  for (int64_t qb = q0; qb < q1; qb += 32) {
-    const int nq = (int)min((int64_t)32, q1 - qb);
-    __syncthreads();
-    for (int i = threadIdx.x; i < FB_IV_BT * 32; i += blockDim.x) {
-      const int bb = i >> 5, qq = i & 31;
-      smd[i] = (bb < nb && qq < nq) ? X[(size_t)(b0 + bb) * Q + qb + qq] : 0.0;
-    }
-    __syncthreads();
-    if (r < R) {
-      for (int qq = 0; qq < nq; ++qq) {
-        const double v = iv.sim[(size_t)(qb + qq) * R + r];
+  for (int ai = a0; ai < a1; ++ai) {
+    const int k = active[ai];
+    const double *sim = iv.sim + (size_t)k * D * R + r;
+    const double *xk = XT + (size_t)k * D * Bpad + b0;
+#pragma unroll 2
+    for (int d = 0; d < D; ++d) {
+      const double v = sim[(size_t)d * R];
+      const double *xr = xk + (size_t)d * Bpad;  // uniform address -> s_load
 #pragma unroll
-        for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(smd[bb * 32 + qq], v, acc[bb]);
-      }
+      for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(xr[bb], v, acc[bb]);
     }
   }
-  if (r < R)
-    for (int bb = 0; bb < nb; ++bb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
+  const int nb = min(FB_IV_BT, B - b0);
+  for (int bb = 0; bb < nb; ++bb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
 }
-// quad[b][e] = sum_k gamma[b][k] U[k][e]; thread = one packed element e; BT utterances per pass
-template <int BT>
-__global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__restrict__ gamma, int B,
-                                                 double *__restrict__ quad) {
-  __shared__ double sg[BT * 64];
-  const int triR = iv.triR, C = iv.C;
+// quad[b][e] = sum_k gamma[b][k] U[k][e]; thread = one packed element e
+__global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__restrict__ gammaT,
+                                                 const int *__restrict__ active, const int *__restrict__ n_active,
+                                                 int B, int Bpad, double *__restrict__ quad) {
+  const int triR = iv.triR;
+  const int na = *n_active;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = blockIdx.y * BT;
-  const int nb = min(BT, B - b0);
-  double acc[BT];
+  const int b0 = blockIdx.y * FB_IV_BT;
+  if (e >= triR) return;
+  double acc[FB_IV_BT];
 #pragma unroll
-  for (int i = 0; i < BT; ++i) acc[i] = 0.0;
-  for (int kb = 0; kb < C; kb += 64) {
-    const int nk = min(64, C - kb);
-    __syncthreads();
-    for (int i = threadIdx.x; i < BT * 64; i += 256) {
-      const int bb = i >> 6, kk = i & 63;
-      sg[i] = (bb < nb && kk < nk) ? gamma[(size_t)(b0 + bb) * C + kb + kk] : 0.0;
-    }
-    __syncthreads();
-    if (e < triR) {
-      for (int kk = 0; kk < nk; ++kk) {
-        const double uv = iv.u[(size_t)(kb + kk) * triR + e];
+  for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
+  const double *up = iv.u + e;
+#pragma unroll 2
+  for (int ai = 0; ai < na; ++ai) {
+    const int k = active[ai];
+    const double uv = up[(size_t)k * triR];
+    const double *gr = gammaT + (size_t)k * Bpad + b0;  // uniform address -> s_load
 #pragma unroll
-        for (int bb = 0; bb < BT; ++bb) acc[bb] = fma(sg[bb * 64 + kk], uv, acc[bb]);
-      }
-    }
+    for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(gr[bb], uv, acc[bb]);
   }
-  if (e < triR)
-    for (int bb = 0; bb < nb; ++bb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
+  const int nb = min(FB_IV_BT, B - b0);
+  for (int bb = 0; bb < nb; ++bb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
 }
-void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma, const double *X, int B,
-                           int n_kchunks, double *linp, double *quad) {
-  const int64_t Q = (int64_t)iv.C * iv.D;
-  int rpc = (int)((Q + n_kchunks - 1) / n_kchunks);
-  rpc = (rpc + 31) / 32 * 32;
+void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
+                           int Bpad, int n_kchunks, int *active, int *n_active, double *linp, double *quad) {
   const int threads = (iv.R + 63) / 64 * 64;
-  hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, (B + FB_IV_BT - 1) / FB_IV_BT), dim3(threads),
-                     sizeof(double) * FB_IV_BT * 32, s, iv, X, B, rpc, linp);
-  if (B > 16)
-    hipLaunchKernelGGL((k_iv_quad<64>), dim3((iv.triR + 255) / 256, (B + 63) / 64), dim3(256), 0, s, iv, gamma, B, quad);
-  else
-    hipLaunchKernelGGL((k_iv_quad<16>), dim3((iv.triR + 255) / 256, (B + 15) / 16), dim3(256), 0, s, iv, gamma, B, quad);
+  const int btiles = (B + FB_IV_BT - 1) / FB_IV_BT;
+  hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, Bpad, gammaT, active, n_active);
+  hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, btiles), dim3(threads), 0, s, iv, XT, active, n_active, B, Bpad,
+                     n_kchunks, linp);
+  hipLaunchKernelGGL(k_iv_quad, dim3((iv.triR + 255) / 256, btiles), dim3(256), 0, s, iv, gammaT, active, n_active,
+                     B, Bpad, quad);
 }
 
 // --------------------------------------------------------- solve (K10c)
-// One workgroup per utterance: A = I + unpack(quad), rhs = sum of lin partials (+ prior offset);
-// right-looking blocked Cholesky (panel 32) in global scratch (L2 resident), then the two
-// triangular solves; ivec = solution with the prior offset removed from component 0.
+// One workgroup per utterance: A = I + unpack(quad), rhs = sum of lin partials (+ prior offset).
+// Right-looking blocked Cholesky (panel 32) in global scratch (L2 resident).  Everything serial is kept
+// out of LDS-latency chains: the 32x32 diagonal block is factored by one wave in registers (lane =
+// row, pivots/columns broadcast with v_readlane), its inverse is formed with lane = column, and both the
+// panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain mat-vec /
+// mat-mat products.  ivec = solution with the prior offset removed from component 0.
 #define FB_IV_NB 32
+__device__ __forceinline__ double fb_readlane_f64(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(1024) void k_iv_solve(FbIvDev iv, const double *__restrict__ quad,
                                                    const double *__restrict__ linp, int n_kchunks, int B,
-                                                   double *__restrict__ Aall, double *__restrict__ ivec,
-                                                   int *__restrict__ fail) {
+                                                   double *__restrict__ Aall, double *__restrict__ LinvAll,
+                                                   double *__restrict__ ivec, int *__restrict__ fail) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
+  constexpr int LD = FB_IV_NB + 1;
   const int R = iv.R, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  const int npanel = (R + FB_IV_NB - 1) / FB_IV_NB;
   double *A = Aall + (size_t)b * R * R;
-  double *rhs = smd;                 // [R]
-  double *Dg = rhs + ((R + 1) & ~1); // [NB][NB+1]
-  double *Lp = Dg + FB_IV_NB * (FB_IV_NB + 1);  // [R][NB+1] panel below the diagonal block
+  double *Lg = LinvAll + (size_t)b * npanel * FB_IV_NB * FB_IV_NB;
+  double *rhs = smd;                  // [R]
+  double *Dg = rhs + ((R + 1) & ~1);  // [NB][LD]  L11
+  double *Di = Dg + FB_IV_NB * LD;    // [NB][LD]  L11^-1
+  double *Lp = Di + FB_IV_NB * LD;    // [R+4][LD] panel below the diagonal block
   const double *qb = quad + (size_t)b * iv.triR;
-  for (int i = tid; i < R * R; i += nt) {
-    const int r = i / R, c = i - r * R;
-    A[i] = (c <= r) ? qb[(size_t)r * (r + 1) / 2 + c] + (r == c ? 1.0 : 0.0) : 0.0;
+  // ---- unpack the lower triangle (+ I): wave w walks rows w, w+nw, ...; lanes walk columns
+  for (int r = wv; r < R; r += nw) {
+    const double *qr = qb + (size_t)r * (r + 1) / 2;
+    for (int c = lane; c < R; c += 64) A[(size_t)r * R + c] = (c <= r) ? qr[c] + (r == c ? 1.0 : 0.0) : 0.0;
   }
-  for (int r = tid; r < R; r += nt) {
-    double acc = 0.0;
-    for (int ch = 0; ch < n_kchunks; ++ch) acc += linp[((size_t)ch * B + b) * R + r];
-    rhs[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
+  {  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order
+    double *part = Lp;
+    for (int idx = tid; idx < 8 * R; idx += nt) {
+      const int sl = idx / R, r = idx - sl * R;
+      double acc = 0.0;
+      for (int ch = sl; ch < n_kchunks; ch += 8) acc += linp[((size_t)ch * B + b) * R + r];
+      part[sl * R + r] = acc;
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += nt) {
+      double acc = 0.0;
+      for (int sl = 0; sl < 8; ++sl) acc += part[sl * R + r];
+      rhs[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
+    }
   }
   __syncthreads();
-  for (int j0 = 0; j0 < R; j0 += FB_IV_NB) {
+  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
     const int nb = min(FB_IV_NB, R - j0);
-    // (a) diagonal block -> LDS, factor with one wave
-    for (int i = tid; i < nb * nb; i += nt) {
-      const int r = i / nb, c = i - r * nb;
-      Dg[r * (FB_IV_NB + 1) + c] = (c <= r) ? A[(size_t)(j0 + r) * R + j0 + c] : 0.0;
+    // (a) diagonal block -> LDS (identity beyond nb so the fixed-size register code stays valid)
+    for (int i = tid; i < FB_IV_NB * FB_IV_NB; i += nt) {
+      const int r = i / FB_IV_NB, c = i - r * FB_IV_NB;
+      double v = (r == c) ? 1.0 : 0.0;
+      if (r < nb && c < nb) v = (c <= r) ? A[(size_t)(j0 + r) * R + j0 + c] : 0.0;
+      Dg[r * LD + c] = v;
     }
     __syncthreads();
-    if (tid < 64) {
-      for (int c = 0; c < nb; ++c) {
-        const double d = Dg[c * (FB_IV_NB + 1) + c];
-        if (!(d > 0.0) && tid == 0) atomicMax(fail, b + 1);
-        const double piv = sqrt(d > 0.0 ? d : 1.0);
-        for (int r = c + tid; r < nb; r += 64) {
-          const double v = (r == c) ? piv : Dg[r * (FB_IV_NB + 1) + c] / piv;
-          Dg[r * (FB_IV_NB + 1) + c] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = tid; i < (nb - c - 1) * (nb - c - 1); i += 64) {
-          const int rr = c + 1 + i / (nb - c - 1), cc = c + 1 + i % (nb - c - 1);
-          if (cc <= rr) Dg[rr * (FB_IV_NB + 1) + cc] -= Dg[rr * (FB_IV_NB + 1) + c] * Dg[cc * (FB_IV_NB + 1) + c];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < nb * nb; i += nt) {
-      const int r = i / nb, c = i - r * nb;
-      if (c <= r) A[(size_t)(j0 + r) * R + j0 + c] = Dg[r * (FB_IV_NB + 1) + c];
-    }
-    // (b) panel below: L21 = A21 * L11^-T, one row per thread
-    const int m = R - j0 - nb;
-    for (int i = tid; i < m; i += nt) {
-      double x[FB_IV_NB];
-      const double *arow = A + (size_t)(j0 + nb + i) * R + j0;
+    if (wv == 0) {
+      // factor: lane r (< 32) holds row r
+      double row[FB_IV_NB];
+      const int rr = lane & 31;
 #pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) x[c] = (c < nb) ? arow[c] : 0.0;
+      for (int c = 0; c < FB_IV_NB; ++c) row[c] = Dg[rr * LD + c];
+      bool bad = false;
 #pragma unroll
       for (int c = 0; c < FB_IV_NB; ++c) {
-        if (c < nb) {
-          double v = x[c];
+        const double d = fb_readlane_f64(row[c], c);
+        bad |= !(d > 0.0);
+        const double piv = sqrt(d > 0.0 ? d : 1.0);
+        const double l = (rr == c) ? piv : row[c] / piv;
+        row[c] = (rr >= c) ? l : 0.0;
 #pragma unroll
-          for (int q = 0; q < FB_IV_NB; ++q)
-            if (q < c) v -= x[q] * Dg[c * (FB_IV_NB + 1) + q];
-          x[c] = v / Dg[c * (FB_IV_NB + 1) + c];
+        for (int cc = c + 1; cc < FB_IV_NB; ++cc) row[cc] = fma(-l, fb_readlane_f64(l, cc), row[cc]);
+      }
+      if (bad && lane == 0) atomicMax(fail, b + 1);
+      if (lane < FB_IV_NB) {
+#pragma unroll
+        for (int c = 0; c < FB_IV_NB; ++c) Dg[rr * LD + c] = row[c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
+      double li[FB_IV_NB];
+#pragma unroll
+      for (int r = 0; r < FB_IV_NB; ++r) {
+        double sacc = (r == rr) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < r; ++q) sacc = fma(-Dg[r * LD + q], li[q], sacc);
+        li[r] = sacc / Dg[r * LD + r];
+      }
+      if (lane < FB_IV_NB) {
+#pragma unroll
+        for (int r = 0; r < FB_IV_NB; ++r) {
+          Di[r * LD + rr] = li[r];
+          Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = li[r];
         }
       }
-      double *lrow = Lp + (size_t)i * (FB_IV_NB + 1);
-      double *wrow = A + (size_t)(j0 + nb + i) * R + j0;
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c)
-        if (c < nb) { lrow[c] = x[c]; wrow[c] = x[c]; }
     }
     __syncthreads();
-    // (c) trailing update A22 -= L21 L21^T (lower triangle), 2x2 register tiles
-    const int mt = (m + 1) / 2;
-    for (int i = tid; i < mt * mt; i += nt) {
-      const int tr = i / mt, tc = i - tr * mt;
-      if (tc > tr) continue;
-      const int r0 = 2 * tr, c0 = 2 * tc;
-      const double *l0 = Lp + (size_t)r0 * (FB_IV_NB + 1), *l1 = l0 + (FB_IV_NB + 1);
-      const double *k0 = Lp + (size_t)c0 * (FB_IV_NB + 1), *k1 = k0 + (FB_IV_NB + 1);
-      const bool r1ok = r0 + 1 < m, c1ok = c0 + 1 < m;
-      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-      for (int q = 0; q < nb; ++q) {
-        const double a0 = l0[q], a1 = r1ok ? l1[q] : 0.0, b0 = k0[q], b1 = c1ok ? k1[q] : 0.0;
-        s00 = fma(a0, b0, s00); s01 = fma(a0, b1, s01); s10 = fma(a1, b0, s10); s11 = fma(a1, b1, s11);
+    for (int i = tid; i < nb * nb; i += nt) {
+      const int r = i / nb, c = i - r * nb;
+      if (c <= r) A[(size_t)(j0 + r) * R + j0 + c] = Dg[r * LD + c];
+    }
+    // (b) panel below: X = A21 * L11^-T, one row per thread, independent dot products
+    const int m = R - j0 - nb;
+    for (int i = tid; i < m; i += nt) {
+      double a[FB_IV_NB];
+      double *arow = A + (size_t)(j0 + nb + i) * R + j0;
+#pragma unroll
+      for (int c = 0; c < FB_IV_NB; ++c) a[c] = (c < nb) ? arow[c] : 0.0;
+      double *lrow = Lp + (size_t)i * LD;
+#pragma unroll
+      for (int c = 0; c < FB_IV_NB; ++c) {
+        double x = 0.0;
+#pragma unroll
+        for (int q = 0; q <= c; ++q) x = fma(a[q], Di[c * LD + q], x);
+        lrow[c] = x;
+        if (c < nb) arow[c] = x;
       }
-      double *a = A + (size_t)(j0 + nb + r0) * R + j0 + nb + c0;
-      a[0] -= s00;
-      if (c1ok && c0 + 1 <= r0) a[1] -= s01;
-      if (r1ok) {
-        a[R] -= s10;
-        if (c1ok) a[R + 1] -= s11;
+    }
+    // zero the padding rows of the panel so the 4x4 tiles below need no bounds checks
+    for (int i = m * LD + tid; i < ((m + 3) & ~3) * LD; i += nt) Lp[i] = 0.0;
+    __syncthreads();
+    // (c) trailing update A22 -= L21 L21^T (lower triangle), 4x4 register tiles from the LDS panel
+    const int mt = (m + 3) / 4;
+    const int ntile = mt * (mt + 1) / 2;
+    for (int i = tid; i < ntile; i += nt) {
+      int tr = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
+      while ((tr + 1) * (tr + 2) / 2 <= i) ++tr;
+      while (tr * (tr + 1) / 2 > i) --tr;
+      const int tc = i - tr * (tr + 1) / 2;
+      const int r0 = 4 * tr, c0 = 4 * tc;
+      const double *lr = Lp + (size_t)r0 * LD, *lc = Lp + (size_t)c0 * LD;
+      double sacc[4][4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) sacc[x][y] = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < FB_IV_NB; ++q) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { av[x] = lr[x * LD + q]; bv[x] = lc[x * LD + q]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) sacc[x][y] = fma(av[x], bv[y], sacc[x][y]);
       }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int rr2 = r0 + x, cc2 = c0 + y;
+          if (rr2 < m && cc2 <= rr2) A[(size_t)(j0 + nb + rr2) * R + j0 + nb + cc2] -= sacc[x][y];
+        }
     }
     __syncthreads();
   }
-  // ---- forward substitution L y = rhs, then L^T x = y (column oriented, panel by panel)
-  for (int j0 = 0; j0 < R; j0 += FB_IV_NB) {
+  // ---- L y = rhs then L^T x = y, panel by panel, with the stored panel inverses
+  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
     const int nb = min(FB_IV_NB, R - j0);
-    if (tid == 0) {
-      for (int c = 0; c < nb; ++c) {
-        double v = rhs[j0 + c];
-        for (int q = 0; q < c; ++q) v -= A[(size_t)(j0 + c) * R + j0 + q] * rhs[j0 + q];
-        rhs[j0 + c] = v / A[(size_t)(j0 + c) * R + j0 + c];
-      }
+    if (tid < FB_IV_NB) {
+      double y = 0.0;
+      if (tid < nb)
+        for (int q = 0; q <= tid; ++q) y = fma(Lg[((size_t)pi * FB_IV_NB + tid) * FB_IV_NB + q], rhs[j0 + q], y);
+      __builtin_amdgcn_wave_barrier();
+      if (tid < nb) Dg[tid] = y;
     }
+    __syncthreads();
+    if (tid < nb) rhs[j0 + tid] = Dg[tid];
     __syncthreads();
     for (int i = j0 + nb + tid; i < R; i += nt) {
       double v = rhs[i];
       const double *arow = A + (size_t)i * R + j0;
-      for (int q = 0; q < nb; ++q) v -= arow[q] * rhs[j0 + q];
+#pragma unroll 8
+      for (int q = 0; q < nb; ++q) v = fma(-arow[q], rhs[j0 + q], v);
       rhs[i] = v;
     }
     __syncthreads();
   }
-  for (int j1 = R; j1 > 0; j1 -= FB_IV_NB) {
-    const int j0 = max(0, j1 - FB_IV_NB), nb = j1 - j0;
-    if (tid == 0) {
-      for (int c = nb - 1; c >= 0; --c) {
-        double v = rhs[j0 + c];
-        for (int q = c + 1; q < nb; ++q) v -= A[(size_t)(j0 + q) * R + j0 + c] * rhs[j0 + q];
-        rhs[j0 + c] = v / A[(size_t)(j0 + c) * R + j0 + c];
-      }
+  for (int pi = npanel - 1; pi >= 0; --pi) {
+    const int j0 = pi * FB_IV_NB, nb = min(FB_IV_NB, R - j0);
+    if (tid < FB_IV_NB) {
+      double x = 0.0;
+      if (tid < nb)
+        for (int q = tid; q < nb; ++q) x = fma(Lg[((size_t)pi * FB_IV_NB + q) * FB_IV_NB + tid], rhs[j0 + q], x);
+      if (tid < nb) Dg[tid] = x;
     }
+    __syncthreads();
+    if (tid < nb) rhs[j0 + tid] = Dg[tid];
     __syncthreads();
     for (int i = tid; i < j0; i += nt) {
       double v = rhs[i];
-      for (int q = 0; q < nb; ++q) v -= A[(size_t)(j0 + q) * R + i] * rhs[j0 + q];
+#pragma unroll 8
+      for (int q = 0; q < nb; ++q) v = fma(-A[(size_t)(j0 + q) * R + i], rhs[j0 + q], v);
       rhs[i] = v;
     }
     __syncthreads();
@@ -447,10 +649,15 @@ __global__ __launch_bounds__(1024) void k_iv_solve(FbIvDev iv, const double *__r
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
 void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                        int B, double *Aall, double *ivec, int *fail) {
+                        int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
   const int R = iv.R;
-  size_t shm = sizeof(double) * (((R + 1) & ~1) + FB_IV_NB * (FB_IV_NB + 1) + (size_t)R * (FB_IV_NB + 1));
-  hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(1024), shm, s, iv, quad, linp, n_kchunks, B, Aall, ivec, fail);
+  size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + (size_t)(R + 4) * (FB_IV_NB + 1));
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(1024), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
 }
 
 // ------------------------------------------------------ back-end (K11/K12)
