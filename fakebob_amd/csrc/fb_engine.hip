@@ -806,6 +806,15 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
   return FB_OK;
 }
 
+extern "C" int fb_debug_iv_active(fb_engine *e, int *n_active) {
+  if (!e || !n_active) return fb_fail(FB_E_ARG, "bad argument");
+  if (e->kind != 1 || e->last_B <= 0) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(n_active, e->iv_active.as<int>() + e->iv.C, sizeof(int), hipMemcpyDeviceToHost));
+  return FB_OK;
+}
+
 extern "C" int fb_debug_ivectors(fb_engine *e, int B, double *ivecs) {
   if (!e || !ivecs || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (e->kind != 1 || e->last_B < B) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");

@@ -93,6 +93,11 @@ class Engine(object):
         N.check(self._L.fb_debug_ivectors(self._h, C.c_int(B), N.ptr(out)))
         return out
 
+    def debug_iv_active(self):
+        n = C.c_int()
+        N.check(self._L.fb_debug_iv_active(self._h, C.byref(n)))
+        return n.value
+
     def set_system(self, task, z_mean=None, z_std=None):
         zm = None if z_mean is None else np.ascontiguousarray(z_mean, np.float64)
         zs = None if z_std is None else np.ascontiguousarray(z_std, np.float64)

@@ -200,6 +200,9 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
                    int *Tv, int *T);
 /* i-vectors [B*R] (float64, prior offset removed) of the last scored batch */
 int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
+/* number of UBM components that received posterior mass in the last i-vector batch (only their
+ * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
+int fb_debug_iv_active(fb_engine *e, int *n_active);
 /* counters since engine creation */
 int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames,
              int64_t *voiced_frames, int64_t *nes_iters);
