@@ -85,7 +85,7 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_images, gmm_items;
+  DevBuf gmm_images, gmm_items, gmm_images_bx;
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
@@ -143,7 +143,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
@@ -356,12 +356,61 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   HIPCHK(hipStreamSynchronize(e->stream));
   FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
   HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
+  // bf16x3 images (k_gmm_bx3): exact 3-way truncation split of every parameter, gconst in the K padding
+  const int NK = (D + 3 + 15) / 16;
+  const char *mode_env = getenv("FB_GMM_MODE");
+  const int mode = (mode_env && strcmp(mode_env, "f32") == 0) ? FB_GMM_MODE_F32 : FB_GMM_MODE_BX3;
+  if (mode == FB_GMM_MODE_BX3) {
+    const size_t per_item = (size_t)3 * NK * 64 * 8;  // bf16 values
+    std::vector<uint16_t> bx((size_t)n_tiles * n_items * per_item, 0);
+    auto split3 = [](float v, uint16_t out[3]) {
+      for (int s = 0; s < 3; ++s) {
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        u &= 0xffff0000u;
+        float t;
+        memcpy(&t, &u, 4);
+        out[s] = (uint16_t)(u >> 16);
+        v -= t;  // exact
+      }
+    };
+    for (int t = 0; t < n_tiles; ++t)
+      for (int it = 0; it < n_items; ++it) {
+        uint16_t *im = &bx[((size_t)t * n_items + it) * per_item];
+        const int im_model = item_model[it];
+        for (int cc = 0; cc < 32; ++cc) {
+          const int c = t * 32 + cc;
+          for (int k = 0; k < 16 * NK; ++k) {
+            float v = 0.0f;
+            if (k < D) {
+              if (c < C)
+                v = im_model < 0 ? -0.5f * iv[((size_t)group_rep[-1 - im_model] * C + c) * D + k]
+                                 : miv[((size_t)im_model * C + c) * D + k];
+            }
+            uint16_t sp[3] = {0, 0, 0};
+            if (k < D) {
+              split3(v, sp);
+            } else if (k < D + 3 && im_model >= 0) {  // gconst term k-D against 1.0 in the frame operand
+              uint16_t gs[3];
+              split3(c < C ? gconsts[(size_t)im_model * C + c] : -1.0e30f, gs);
+              sp[0] = gs[k - D];
+            }
+            const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
+            for (int s = 0; s < 3; ++s) im[(((size_t)s * NK + ch) * 64 + lane) * 8 + i] = sp[s];
+          }
+        }
+      }
+    FBCHK(e->gmm_images_bx.ensure(sizeof(uint16_t) * bx.size()));
+    HIPCHK(hipMemcpy(e->gmm_images_bx.p, bx.data(), sizeof(uint16_t) * bx.size(), hipMemcpyHostToDevice));
+  }
   std::vector<int> im_dev(item_model);
   FBCHK(e->gmm_items.ensure(sizeof(int) * im_dev.size()));
   HIPCHK(hipMemcpy(e->gmm_items.p, im_dev.data(), sizeof(int) * im_dev.size(), hipMemcpyHostToDevice));
   FbGmmDev &g = e->gmm;
   g.M = M; g.C = C; g.D = D; g.KH = KH; g.n_tiles = n_tiles; g.n_items = n_items; g.img_floats = IMGF;
   g.images = e->gmm_images.as<float>();
+  g.mode = mode; g.NK = NK;
+  g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
   g.item_model = e->gmm_items.as<int>();
   e->n_groups = G;
   e->have_gmm = true;
@@ -438,7 +487,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
 static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   const int strips = (rows_cap + 127) / 128;
   const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
-  const int target = ev ? atoi(ev) : 1024;
+  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_BX3 ? 512 : 1024);
   int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;

@@ -83,7 +83,12 @@ struct FbGmmDev {
   int img_floats;                     // floats per tile image
   const float *images;                // [n_tiles][n_items][img_floats]
   const int *item_model;              // [n_items]: -1 = quadratic (Q) item, else model index
+  // bf16x3 variant (k_gmm_bx3): K padded to 16*NK >= D + 3, images [n_tiles][n_items][3][NK][64] x 16 B
+  int mode, NK;
+  const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
 };
+#define FB_GMM_MODE_F32 0
+#define FB_GMM_MODE_BX3 1
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

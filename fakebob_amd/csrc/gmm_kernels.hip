@@ -184,6 +184,214 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gmm_bx3: the same computation on the bf16 matrix pipe (16x the f32 MFMA rate) WITHOUT giving up
+// f32 accuracy.  Every f32 operand is split exactly into three bf16 terms (v = v1 + v2 + v3, 8
+// significant bits each, by truncation -- the three terms carry all 24 bits, nothing is rounded), and
+// a product a*b is accumulated in f32 from the six partial products of order <= 2^-16:
+//     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1        (dropped: a2b3, a3b2, a3b3 <= 2^-24 |ab|)
+// Each bf16 x bf16 product is exact in the f32 accumulator, so the result differs from an f32 fma
+// chain by the order of f32 additions plus a term below one f32 ulp per product -- the same class of
+// difference as between two f32 BLAS implementations (measured against the float64 oracle: §5 of
+// DESIGN.md).  K = D is padded to 16*NK; three padding positions carry gconst (its three bf16 terms
+// in A's first image against 1.0 in the frame operand), so the epilogue has no separate add.
+//   6 * NK MFMAs of 32 cycles per (32 components x 32 frames x item) instead of KH of 64 cycles:
+//   960 vs 2304 cycles for D = 72.
+// Image of one item in global memory == its LDS image: [3 splits][NK chunks][64 lanes][8 bf16], i.e.
+// every A fragment is one conflict-free, fully contiguous ds_read_b128 per wave.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned fb_pack_hi(float lo, float hi) {  // {lo[31:16], hi[31:16]}
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+// v[8] -> three packed bf16x8 fragments (exact truncation split)
+__device__ __forceinline__ void fb_split3_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2, u32x4 &f3) {
+  float a[8], b[8], c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
+    const float r = __fsub_rn(v[i], a[i]);
+    b[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    c[i] = __fsub_rn(r, b[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f1[i] = fb_pack_hi(a[2 * i], a[2 * i + 1]);
+    f2[i] = fb_pack_hi(b[2 * i], b[2 * i + 1]);
+    f3[i] = fb_pack_hi(c[2 * i], c[2 * i + 1]);
+  }
+}
+
+#define FB_BX_MFMA(A, B, ACC) \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
+
+template <int NK>
+__device__ __forceinline__ f32x16 fb_bx_item(const u32x4 *__restrict__ cur4, int lane, const u32x4 (&b1)[NK],
+                                             const u32x4 (&b2)[NK], const u32x4 (&b3)[NK], f32x16 acc) {
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    const u32x4 a1 = cur4[(0 * NK + c) * 64 + lane];
+    const u32x4 a2 = cur4[(1 * NK + c) * 64 + lane];
+    const u32x4 a3 = cur4[(2 * NK + c) * 64 + lane];
+    FB_BX_MFMA(a3, b1[c], acc);
+    FB_BX_MFMA(a1, b3[c], acc);
+    FB_BX_MFMA(a2, b2[c], acc);
+    FB_BX_MFMA(a2, b1[c], acc);
+    FB_BX_MFMA(a1, b2[c], acc);
+    FB_BX_MFMA(a1, b1[c], acc);
+  }
+  return acc;
+}
+
+template <int NK, bool DUMP>
+__global__ __launch_bounds__(256, 2) void k_gmm_bx3(FbGmmDev g, const float *__restrict__ feats,
+                                                    const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                    int rows_cap, float *__restrict__ part_m,
+                                                    float *__restrict__ part_s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 3 * NK * 64;  // 16-byte units per item
+  constexpr int NST = (IMG4 + 255) / 256;
+  const int n_rows = *n_rows_ptr;
+  const int strip0 = blockIdx.x * 128;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int row = strip0 + w * 32 + j;
+  u32x4 *slot0 = reinterpret_cast<u32x4 *>(lds), *slot1 = slot0 + IMG4;
+  float *st_m = lds + 2 * IMG4 * 4;        // [M][256]
+  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
+
+  // ---- frame fragments: chunk c of this lane = dims 16c + 8h + i, i < 8, split into 3 bf16 terms;
+  //      bx = x (with 1.0 at the three gconst positions D..D+2), bq = fl(x*x)
+  u32x4 bx1[NK], bx2[NK], bx3[NK], bq1[NK], bq2[NK], bq3[NK];
+  {
+    const bool ok = row < n_rows;
+    const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      const int d0 = 16 * c + 8 * h;
+      float v[8], q[8];
+      if ((g.D & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d = d0 + 4 * u;
+          const float4 t = *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
+          const bool in = ok && d < g.D;
+          v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
+          v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(v[i], v[i]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = d0 + i;
+        if (d >= g.D && d < g.D + 3) v[i] = 1.0f;
+      }
+      fb_split3_frag(v, bx1[c], bx2[c], bx3[c]);
+      fb_split3_frag(q, bq1[c], bq2[c], bq3[c]);
+    }
+  }
+  for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
+
+  const int tile0 = blockIdx.y * tiles_per_chunk;
+  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
+  const int total_items = (tile1 - tile0) * g.n_items;
+  const u32x4 *gimg = g.images_bx + (size_t)tile0 * g.n_items * IMG4;
+
+  u32x4 stage[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    const int q = min(tid + 256 * s, IMG4 - 1);
+    slot0[q] = gimg[q];
+  }
+  __syncthreads();
+
+  f32x16 accq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accq[r] = 0.0f;
+
+  for (int it = 0; it < total_items; ++it) {
+    u32x4 *cur = (it & 1) ? slot1 : slot0;
+    u32x4 *nxt = (it & 1) ? slot0 : slot1;
+    {
+      const u32x4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
+    }
+    const int item = it % g.n_items;
+    const int model = g.item_model[item];
+    if (model < 0) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      accq = fb_bx_item<NK>(cur, lane, bq1, bq2, bq3, acc);
+    } else {
+      const f32x16 v = fb_bx_item<NK>(cur, lane, bx1, bx2, bx3, accq);
+      if constexpr (DUMP) {
+        if (row < n_rows) {
+          const int tile = tile0 + it / g.n_items;
+          float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(v[4 * rr], v[4 * rr + 1], v[4 * rr + 2], v[4 * rr + 3]);
+        }
+      } else {
+        float tm = FB_GMM_NEG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, v[r]);
+        const float m_old = st_m[model * 256 + tid], s_old = st_s[model * 256 + tid];
+        const float m_new = fmaxf(m_old, tm);
+        float ssum = s_old * __expf(m_old - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum += __expf(v[r] - m_new);
+        st_m[model * 256 + tid] = m_new;
+        st_s[model * 256 + tid] = ssum;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) nxt[min(tid + 256 * s, IMG4 - 1)] = stage[s];
+    __syncthreads();
+  }
+
+  if constexpr (DUMP) return;
+  for (int m = 0; m < g.M; ++m) {
+    const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
+    const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
+    const float mx = fmaxf(mm, m2);
+    const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
+    if (h == 0 && row < n_rows) {
+      const size_t o = ((size_t)blockIdx.y * g.M + m) * rows_cap + row;
+      part_m[o] = mx;
+      part_s[o] = sx;
+    }
+  }
+}
+
+template <int NK, bool DUMP>
+static void launch_gmm_bx_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                            int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
+  const size_t ldsb = (size_t)2 * 3 * NK * 64 * 16 + (size_t)2 * g.M * 256 * sizeof(float);
+  hipLaunchKernelGGL((k_gmm_bx3<NK, DUMP>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap,
+                     part_m, part_s);
+}
+template <bool DUMP>
+static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                          int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  switch (g.NK) {
+    case 3: launch_gmm_bx_t<3, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 4: launch_gmm_bx_t<4, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 5: launch_gmm_bx_t<5, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 6: launch_gmm_bx_t<6, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    default: break;  // fb_load_gmm only produces the NK values above
+  }
+}
+
 static int fb_gmm_lds_bytes(const FbGmmDev &g) {
   const int imgf = 32 * (2 * g.KH + 4) + 32;
   return (2 * imgf + 2 * g.M * 256) * (int)sizeof(float);
@@ -207,6 +415,7 @@ void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, co
                         int rows_cap, int n_chunks, float *ll) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr); return; }
   switch (g.KH) {
     case 20: launch_gmm_dump_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
     case 32: launch_gmm_dump_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
@@ -220,6 +429,7 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
                    int rows_cap, int n_chunks, float *part_m, float *part_s) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   switch (g.KH) {
     case 20: launch_gmm_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     case 32: launch_gmm_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
