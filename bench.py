@@ -133,6 +133,36 @@ def bench_ivector(args, torch):
         e.close()
 
 
+GMM_BX3 = os.environ.get("FB_GMM_MODE", "bx3") != "f32"
+GMM_TRAFFIC_KEY = "k_gmm_bx3<5, false>" if GMM_BX3 else "k_gmm<36, false>"
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (MI355X_MICROARCH.md)
+# bf16 32x32x16 chain on random operands, this chip, scratch/bx_probe.hip: the clock drops to ~1.6 GHz
+# under a saturated bf16 matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
+BF16_MFMA_POWER_LIMITED_TFLOPS = 1660.0
+
+
+def _gmm_roofline(achieved, flops_launch, gmm_ms_avg):
+    M = S_SPK + 1
+    shared = (1 + M) / (2.0 * M)
+    r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": gmm_ms_avg,
+         "algorithmic_flops_per_launch": flops_launch}
+    if GMM_BX3:
+        nk = (D_FEAT + 3 + 15) // 16
+        ex = flops_launch * shared * 6 * (16.0 * nk / D_FEAT)
+        ex_t = ex / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
+        r.update({"kernel": "k_gmm_bx3<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as an exact "
+                            "3-way bf16 split, 6 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate)",
+                  "executed_flops_per_launch": ex, "executed_tflops": ex_t, "executed_pipe": "bf16 MFMA",
+                  "executed_frac": ex_t / PEAK_BF16_MFMA_TFLOPS,
+                  "executed_frac_of_power_limited_ceiling": ex_t / BF16_MFMA_POWER_LIMITED_TFLOPS})
+    else:
+        r.update({"kernel": "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)",
+                  "executed_flops_per_launch": flops_launch * shared, "executed_tflops": achieved * shared,
+                  "executed_pipe": "f32 MFMA", "executed_frac": achieved * shared / PEAK_F32_MFMA_TFLOPS})
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,7 +251,7 @@ def main():
             "metric": "NES iterations/sec (and scored-utts/sec) at samples_per_draw=50, 3 s@16 kHz",
             "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (MFMA f32 GMM; f64 front-end/NES)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)" if GMM_BX3 else "f32 (MFMA f32 GMM; f64 front-end/NES)",
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS,
@@ -232,26 +262,22 @@ def main():
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
             # `achieved` uses the ALGORITHMIC flops of SURVEY.md 8(d): (S+1)*C*4D per voiced frame (two
-            # length-D dot products per component per model, as Kaldi evaluates them).  The kernel
-            # shares the quadratic term across the 6 models (mean-only MAP adaptation), so it EXECUTES
-            # (1 + M)/(2M) = 7/12 of those flops on the matrix cores: `executed_*` is the honest
-            # hardware utilisation, `frac` may therefore exceed 1.
-            "roofline": {"kernel": "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": gmm_ms_avg,
-                         "algorithmic_flops_per_launch": flops_launch,
-                         "executed_flops_per_launch": flops_launch * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
-                         "executed_tflops": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)),
-                         "executed_frac": achieved * (1 + S_SPK + 1) / (2 * (S_SPK + 1)) / PEAK_F32_MFMA_TFLOPS,
-                         "gmm_share_of_stream_time": ms_gmm / ms_dev if ms_dev > 0 else None,
-                         "note": "launch durations are HIP-event times on each attack's own stream; with "
-                                 "several attacks in flight they include time shared with other attacks' "
-                                 "kernels (solo launch: see solo_launch_ms)"},
+            # length-D dot products per component per model, as Kaldi evaluates them in float32).  The
+            # kernel (a) shares the quadratic term across the 6 models (mean-only MAP adaptation):
+            # (1 + M)/(2M) = 7/12 of those products are executed, and (b) by default evaluates each
+            # f32 product on the bf16 matrix pipe as 6 exact partial products of a 3-way bf16 split
+            # (k_gmm_bx3, f32-equivalent accuracy; FB_GMM_MODE=f32 selects the plain f32-MFMA kernel).
+            # `peak` is the MFMA peak of the path's arithmetic type (f32: 157.3 TF) so `frac` can
+            # exceed 1; `executed_*` give the honest utilisation of the pipe the instructions run on.
+            "roofline": dict(_gmm_roofline(achieved, flops_launch, gmm_ms_avg),
+                             gmm_share_of_stream_time=ms_gmm / ms_dev if ms_dev > 0 else None,
+                             note="launch durations are HIP-event times on each attack's own stream; with "
+                                  "several attacks in flight they include time shared with other attacks' "
+                                  "kernels (solo launch: see solo_launch_ms)"),
         }
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable in-process)
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as r:
-                tr = json.load(r)["kernels"]["k_gmm<36, false>"]
+                tr = json.load(r)["kernels"][GMM_TRAFFIC_KEY]
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
         except Exception:

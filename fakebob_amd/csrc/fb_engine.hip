@@ -356,7 +356,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   HIPCHK(hipStreamSynchronize(e->stream));
   FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
   HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
-  // bf16x3 images (k_gmm_bx3): exact 3-way truncation split of every parameter, gconst in the K padding
+  // bf16x3 images (k_gmm_bx3): exact 3-way bf16 split of every parameter, gconst in the K padding
   const int NK = (D + 3 + 15) / 16;
   const char *mode_env = getenv("FB_GMM_MODE");
   const int mode = (mode_env && strcmp(mode_env, "f32") == 0) ? FB_GMM_MODE_F32 : FB_GMM_MODE_BX3;
@@ -367,7 +367,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
       for (int s = 0; s < 3; ++s) {
         uint32_t u;
         memcpy(&u, &v, 4);
-        u &= 0xffff0000u;
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;  // round to nearest even, 8 significant bits
         float t;
         memcpy(&t, &u, 4);
         out[s] = (uint16_t)(u >> 16);

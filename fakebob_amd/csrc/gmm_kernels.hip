@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
 // ------------------------------------------------------------------------------------------------
 // k_gmm_bx3: the same computation on the bf16 matrix pipe (16x the f32 MFMA rate) WITHOUT giving up
 // f32 accuracy.  Every f32 operand is split exactly into three bf16 terms (v = v1 + v2 + v3, 8
-// significant bits each, by truncation -- the three terms carry all 24 bits, nothing is rounded), and
+// significant bits each, round-to-nearest residuals -- the three terms carry all 24 bits exactly), and
 // a product a*b is accumulated in f32 from the six partial products of order <= 2^-16:
 //     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1        (dropped: a2b3, a3b2, a3b3 <= 2^-24 |ab|)
 // Each bf16 x bf16 product is exact in the f32 accumulator, so the result differs from an f32 fma
@@ -205,14 +205,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned fb_pack_hi(float lo, float hi) {  // {lo[31:16], hi[31:16]}
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
-// v[8] -> three packed bf16x8 fragments (exact truncation split)
+// round-to-nearest-even to 8 significant bits (a bf16 value held in an f32 register)
+__device__ __forceinline__ float fb_bf16_rne(float v) {
+  const unsigned u = __float_as_uint(v);
+  return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+}
+// v[8] -> three packed bf16x8 fragments: v = a + b + c exactly (both residuals are exact in f32 and
+// the last one fits 8 bits); rounding to nearest keeps the residuals -- and with them the dropped
+// third-order products -- sign-symmetric, so the result carries no systematic bias.
 __device__ __forceinline__ void fb_split3_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2, u32x4 &f3) {
   float a[8], b[8], c[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    a[i] = __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
+    a[i] = fb_bf16_rne(v[i]);
     const float r = __fsub_rn(v[i], a[i]);
-    b[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    b[i] = fb_bf16_rne(r);
     c[i] = __fsub_rn(r, b[i]);
   }
 #pragma unroll

@@ -1,5 +1,6 @@
 #!/bin/bash
-for v in "-DFB_ABL_NOLOAD" "-DFB_ABL_NOLOAD -DFB_ABL_NOSTORE" "-DFB_ABL_NOLOAD -DFB_ABL_NOSTORE -DFB_ABL_NOEPI" "-DFB_ABL_NOLOAD -DFB_ABL_NOSTORE -DFB_ABL_NOEPI -DFB_ABL_NOBAR"; do
-  FB_EXTRA_HIPCC_FLAGS="$v" python fakebob_amd/build.py --force >/dev/null 2>&1
-  echo -n "variant [$v] "; python scratch/gmm_only.py 2>&1 | tail -1
+# ablation of k_gmm_bx3 on the GPU box
+for f in "" -DFB_ABL_NOEPI -DFB_ABL_NOLOAD -DFB_ABL_NOLDSREAD -DFB_ABL_NOBAR "-DFB_ABL_NOEPI -DFB_ABL_NOLOAD -DFB_ABL_NOLDSREAD -DFB_ABL_NOBAR"; do
+  FB_EXTRA_HIPCC_FLAGS="$f" python -c "from fakebob_amd import build; build.build(force=True)" >/dev/null 2>&1
+  echo "== $f"; python scratch/gmm_only.py
 done
