@@ -100,6 +100,8 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
+  DevBuf frame_rec;
+  std::vector<int32_t> h_frame_rec;
   DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
   std::vector<int> h_frame_off, h_chunk_off;
@@ -144,7 +146,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -470,6 +472,25 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
     e->h_chunk_off[b + 1] = e->h_chunk_off[b] + (T + 31) / 32;
     if (T > e->cfg.cmn_window) e->any_long = true;
   }
+  {  // per-frame records for k_mfcc_r4: {absolute start sample (int64), start within the utterance, n}
+    const int total = e->h_frame_off[B];
+    e->h_frame_rec.resize((size_t)4 * total);
+    const fb_frontend_cfg &c = e->cfg;
+    for (int b = 0; b < B; ++b) {
+      const int64_t n = off[b + 1] - off[b];
+      if (n > 0x7fffffffLL) return fb_fail(FB_E_LIMIT, "utterance %d longer than 2^31 samples", b);
+      for (int f = e->h_frame_off[b]; f < e->h_frame_off[b + 1]; ++f) {
+        const int64_t t = f - e->h_frame_off[b];
+        const int64_t start = c.snip_edges ? t * c.frame_shift : t * c.frame_shift + c.frame_shift / 2 - c.frame_length / 2;
+        const int64_t abs_start = off[b] + start;
+        memcpy(&e->h_frame_rec[(size_t)4 * f], &abs_start, 8);
+        e->h_frame_rec[(size_t)4 * f + 2] = (int32_t)start;
+        e->h_frame_rec[(size_t)4 * f + 3] = (int32_t)n;
+      }
+    }
+    FBCHK(e->frame_rec.ensure(sizeof(int32_t) * 4 * (size_t)(total > 0 ? total : 1)));
+    HIPCHK(hipMemcpyAsync(e->frame_rec.p, e->h_frame_rec.data(), sizeof(int32_t) * 4 * (size_t)total, hipMemcpyHostToDevice, e->stream));
+  }
   FBCHK(e->chunk_off.ensure(sizeof(int) * (B + 1)));
   HIPCHK(hipMemcpyAsync(e->chunk_off.p, e->h_chunk_off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, e->stream));
   FBCHK(e->wav_off.ensure(sizeof(int64_t) * (B + 1)));
@@ -512,8 +533,8 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   }
   FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * e->n_out));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), B, total_frames,
-                 e->mfcc.as<float>());
+  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
+                 e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>());
   fb_launch_rowscan(s, e->tv.as<int>(), B, e->row_off.as<int>());
   const int total_chunks = e->h_chunk_off[B];
@@ -1177,7 +1198,8 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)T * fe.dim));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), 1, T, e->mfcc.as<float>());
+  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), e->frame_rec.as<int32_t>(), 1, T,
+                 e->mfcc.as<float>());
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, e->vrank.as<int>(), e->tv.as<int>());
   fb_launch_rowscan(s, e->tv.as<int>(), 1, e->row_off.as<int>());
   const int total_chunks = e->h_chunk_off[1];

@@ -61,8 +61,11 @@ void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int hal
 
 // ---- front-end ------------------------------------------------------------
 // MFCC of every frame of a (ragged) batch.  wav_off[B+1], frame_off[B+1] device arrays.
+// frame_rec: [total_frames][4] int32 = {absolute start sample (int64 in two words), start within the
+// utterance, utterance length} (used by the P = 512 kernel instead of a search in frame_off)
 void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav,
-                    const int64_t *wav_off, const int *frame_off, int B, int total_frames, float *mfcc);
+                    const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
+                    int total_frames, float *mfcc);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                    int *vrank, int *tv);

@@ -217,14 +217,263 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
   }
 }
 
+// ---------------------------------------------------------- MFCC, P = 512 (the recipe's size)
+// Same arithmetic as k_mfcc, organised for latency: the complex FFT of size 256 runs as four radix-4
+// Stockham stages with one butterfly per lane (4 points per lane in registers), so a frame crosses the
+// LDS three times instead of eight and the first stage starts straight from the windowed samples in
+// registers.  The per-wave exchange buffer is padded by one 16-byte slot per 8 (the stride-4 stores
+// of the first stage would otherwise be 4-way bank-conflicted); power spectrum and log-mel energies
+// alias it.  The waves of a workgroup share the tables; workgroups are persistent and sized so every
+// wave gets the same number of frames.
+#ifndef FB_R4_WAVES
+#define FB_R4_WAVES 4
+#endif
+#ifndef FB_R4_OCC
+#define FB_R4_OCC 3
+#endif
+#define FB_R4_XSLOTS 288  // 256 + 256/8 padded complex slots
+
+struct MfccR4Lds {  // offsets in doubles
+  int tw, twf, win, melw, dct, lift, melidx, wave0, per_wave;
+};
+__host__ __device__ inline MfccR4Lds fb_mfcc_r4_layout(int L, int nb, int nc, int melw_n) {
+  MfccR4Lds o;
+  int off = 0;
+  o.tw = off; off += 2 * 256;                  // exp(-2 pi i m / 256), m < 256
+  o.twf = off; off += 2 * 257;                 // exp(-2 pi i k / 512), k <= 256
+  o.win = off; off += (L + 1) / 2;             // floats
+  o.melw = off; off += (melw_n + 1) / 2 + 1;
+  o.dct = off; off += (nc * nb + 1) / 2 + 1;
+  o.lift = off; off += (nc + 1) / 2 + 1;
+  o.melidx = off; off += (3 * nb + 1) / 2 + 1;
+  off = (off + 1) & ~1;
+  o.wave0 = off;
+  o.per_wave = 2 * FB_R4_XSLOTS;
+  return o;
+}
+
+__device__ __forceinline__ int fb_r4_phys(int idx) { return idx + (idx >> 3); }
+__device__ __forceinline__ double2 fb_cmul(double2 a, double2 w) {
+  return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+// forward 4-point DFT in place
+__device__ __forceinline__ void fb_dft4(double2 &v0, double2 &v1, double2 &v2, double2 &v3) {
+  const double2 a = make_double2(v0.x + v2.x, v0.y + v2.y), b = make_double2(v0.x - v2.x, v0.y - v2.y);
+  const double2 c = make_double2(v1.x + v3.x, v1.y + v3.y), d = make_double2(v1.x - v3.x, v1.y - v3.y);
+  v0 = make_double2(a.x + c.x, a.y + c.y);
+  v2 = make_double2(a.x - c.x, a.y - c.y);
+  v1 = make_double2(b.x + d.y, b.y - d.x);  // b - i d
+  v3 = make_double2(b.x - d.y, b.y + d.x);  // b + i d
+}
+
+__global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFrontendDev fe, int melw_n,
+                                                                       const int16_t *__restrict__ wav,
+                                                                       const int4 *__restrict__ frame_rec,
+                                                                       int total_frames,
+                                                                       float *__restrict__ mfcc) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NT = 64 * FB_R4_WAVES, Nc = 256;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int L = fe.L, nb = fe.nb, nc = fe.nc;
+  const MfccR4Lds lo = fb_mfcc_r4_layout(L, nb, nc, melw_n);
+  double2 *s_tw = reinterpret_cast<double2 *>(smem + lo.tw);
+  double2 *s_twf = reinterpret_cast<double2 *>(smem + lo.twf);
+  float *s_win = reinterpret_cast<float *>(smem + lo.win);
+  float *s_melw = reinterpret_cast<float *>(smem + lo.melw);
+  float *s_dct = reinterpret_cast<float *>(smem + lo.dct);
+  float *s_lift = reinterpret_cast<float *>(smem + lo.lift);
+  int *s_mfirst = reinterpret_cast<int *>(smem + lo.melidx), *s_mlen = s_mfirst + nb, *s_moff = s_mlen + nb;
+  double2 *X = reinterpret_cast<double2 *>(smem + lo.wave0 + (size_t)w * lo.per_wave);
+  for (int i = tid; i < Nc; i += NT) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
+  for (int i = tid; i <= Nc; i += NT) s_twf[i] = reinterpret_cast<const double2 *>(fe.tw_full)[i];
+  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
+  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
+  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
+  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
+  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
+  __syncthreads();
+
+  // The frame index is wave-uniform: it (and the frame record read through it) stays in scalar
+  // registers.  Lane l owns complex points p = l + 64 q <-> samples 2p, 2p+1 (and 2p-1 for the
+  // pre-emphasis); the raw samples of the NEXT frame are requested before the current one is
+  // processed, so their L2 latency is off the critical path.
+  auto load_raw = [&](int f, int (&r0)[4], int (&r1)[4], int (&rm)[4]) {
+    const int4 rec = frame_rec[f];
+    const int64_t abs_start = ((int64_t)(unsigned)rec.x) | ((int64_t)rec.y << 32);
+    const int start = rec.z, n = rec.w;
+    if (start >= 0 && start + L <= n) {  // interior frame (uniform branch): no reflection
+      // (loads are unconditional on clamped indices and selected afterwards: a predicated load is
+      //  followed by its own s_waitcnt and the twelve L2 latencies would add up)
+      const int16_t *fr = wav + abs_start;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s0 = 2 * (lane + 64 * q);
+        r0[q] = fr[min(s0, L - 1)];
+        r1[q] = fr[min(s0 + 1, L - 1)];
+        rm[q] = fr[min(max(s0 - 1, 0), L - 1)];
+      }
+    } else {
+      const int16_t *wv = wav + (abs_start - start);
+      auto sample = [&](int s) -> int {  // reflected at the utterance edges
+        int64_t k = (int64_t)start + s;
+        while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
+        return wv[k];
+      };
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const int s0 = 2 * (lane + 64 * q);
+        r0[q] = sample(min(s0, L - 1));
+        r1[q] = sample(min(s0 + 1, L - 1));
+        rm[q] = sample(min(max(s0 - 1, 0), L - 1));
+      }
+    }
+  };
+  const int w_s = __builtin_amdgcn_readfirstlane(w);
+  const int f_first = blockIdx.x * FB_R4_WAVES + w_s, f_step = gridDim.x * FB_R4_WAVES;
+  int n0[4], n1[4], nm[4];
+  if (f_first < total_frames) load_raw(f_first, n0, n1, nm);
+  for (int f = f_first; f < total_frames; f += f_step) {
+    double xm[4], x0[4], x1[4];
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s0 = 2 * (lane + 64 * q);
+      x0[q] = s0 < L ? (double)n0[q] : 0.0;
+      x1[q] = s0 + 1 < L ? (double)n1[q] : 0.0;
+      xm[q] = (s0 > 0 && s0 < L) ? (double)nm[q] : x0[q];  // Kaldi: sample 0 is pre-emphasised with itself
+      sum += x0[q] + x1[q];  // integers: exact in any order
+    }
+    if (f + f_step < total_frames) load_raw(f + f_step, n0, n1, nm);
+    sum = fb_wave_sum(sum);
+    const double mean = fe.remove_dc ? sum / (double)L : 0.0;
+    double en = 0.0, en2 = 0.0;
+    double2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s0 = 2 * (lane + 64 * q);
+      // branch-free: out-of-frame samples get weight 0 (x0/x1 are 0 there, but x - mean is not)
+      const double w0 = s0 < L ? (double)s_win[min(s0, L - 1)] : 0.0;
+      const double w1 = s0 + 1 < L ? (double)s_win[min(s0 + 1, L - 1)] : 0.0;
+      const double a = s0 < L ? x0[q] - mean : 0.0, pm = xm[q] - mean;
+      const double c = s0 + 1 < L ? x1[q] - mean : 0.0;
+      en = fma(a, a, en);
+      en = fma(c, c, en);
+      const double y0 = (a - fe.preemph * pm) * w0;
+      const double y1 = (c - fe.preemph * a) * w1;
+      en2 = fma(y0, y0, en2);
+      en2 = fma(y1, y1, en2);
+      v[q] = make_double2(y0, y1);
+    }
+    const double energy = fb_wave_sum(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
+
+    // ---- radix-4 Stockham, Ns = 1, 4, 16, 64; input of a stage: points lane + 64 r
+    fb_dft4(v[0], v[1], v[2], v[3]);  // Ns = 1: no twiddles
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[fb_r4_phys(4 * lane + r)] = v[r];
+    fb_wave_sync();
+#pragma unroll
+    for (int st = 1; st < 4; ++st) {
+      const int Ns = 1 << (2 * st), k = lane & (Ns - 1), tstep = Nc / (4 * Ns);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = X[fb_r4_phys(lane + 64 * r)];
+      v[1] = fb_cmul(v[1], s_tw[k * tstep]);
+      v[2] = fb_cmul(v[2], s_tw[2 * k * tstep]);
+      v[3] = fb_cmul(v[3], s_tw[3 * k * tstep]);
+      fb_dft4(v[0], v[1], v[2], v[3]);
+      fb_wave_sync();  // all reads of this stage are issued before its stores (LDS is in-order per wave)
+      const int base = 4 * lane - 3 * k;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[fb_r4_phys(base + r * Ns)] = v[r];
+      fb_wave_sync();
+    }
+    // ---- real-FFT unpack + power spectrum of bins k = lane + 64 i (i < 4) and bin 256 (lane 0)
+    double pwv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = lane + 64 * i;
+      const int kc = min(k, Nc);  // i == 4: only lane 0 holds a bin (k = 256); the others compute and drop
+      const double2 zk = X[fb_r4_phys(kc & (Nc - 1))];
+      const double2 zr = X[fb_r4_phys((Nc - kc) & (Nc - 1))];
+      const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);
+      const double dr = zk.x - zr.x, di = zk.y + zr.y;
+      const double orr = 0.5 * di, oi = -0.5 * dr;
+      const double2 wk = s_twf[kc];
+      const double xr = er + (wk.x * orr - wk.y * oi);
+      const double xi = ei + (wk.x * oi + wk.y * orr);
+      pwv[i] = xr * xr + xi * xi;
+    }
+    fb_wave_sync();
+    double *PW = reinterpret_cast<double *>(X);  // 257 doubles; LM behind it
+    double *LM = PW + 264;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = lane + 64 * i;
+      if (k <= Nc) PW[k] = pwv[i];
+    }
+    fb_wave_sync();
+    // ---- mel filterbank + log: two lanes per filter (nb <= 31: one pass); lane 63 takes the log of the
+    //      frame energy in the same call
+    {
+      const int m = lane >> 1, part = lane & 1;
+      double e = 0.0;
+      if (m < nb) {
+        const float *wm = s_melw + s_moff[m];
+        const int first = s_mfirst[m], len = s_mlen[m];
+        const int h0 = (len + 1) >> 1;
+        const int i0 = part ? h0 : 0, i1 = part ? len : h0;
+        for (int i = i0; i < i1; ++i) e = fma((double)wm[i], PW[first + i], e);
+      }
+      e += __shfl_xor(e, 1, 64);
+      if (lane == 63) e = energy;
+      if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
+      const double le = log(e);
+      if (m < nb && part == 0) LM[m] = le;
+      if (lane == 63) LM[nb] = le < fe.log_energy_floor ? fe.log_energy_floor : le;
+    }
+    fb_wave_sync();
+    // ---- DCT-II, lifter, C0 <- log energy: two lanes per coefficient
+    for (int c2 = lane; c2 < 2 * ((nc + 31) / 32) * 32; c2 += 64) {
+      const int c = c2 >> 1, part = c2 & 1;
+      double acc = 0.0;
+      if (c < nc) {
+        const float *dr = s_dct + c * nb;
+        const int h0 = (nb + 1) >> 1;
+        const int i0 = part ? h0 : 0, i1 = part ? nb : h0;
+        for (int m = i0; m < i1; ++m) acc = fma((double)dr[m], LM[m], acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      if (c < nc && part == 0) {
+        acc *= (double)s_lift[c];
+        float o = (float)acc;
+        if (c == 0 && fe.use_energy) o = (float)LM[nb];
+        mfcc[(size_t)f * nc + c] = o;
+      }
+    }
+    fb_wave_sync();
+  }
+}
+
 int fb_mfcc_layout_doubles(int P, int L, int nb, int nc, int melw_n) {
   const MfccLds lo = fb_mfcc_layout(P, L, nb, nc, melw_n);
   return lo.wave0 + 4 * lo.per_wave;
 }
 
 void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav,
-                    const int64_t *wav_off, const int *frame_off, int B, int total_frames, float *mfcc) {
+                    const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
+                    int total_frames, float *mfcc) {
   if (total_frames <= 0) return;
+  if (fe.P == 512 && fe.nb <= 31) {
+    const MfccR4Lds l4 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
+    const size_t shm4 = sizeof(double) * (size_t)(l4.wave0 + FB_R4_WAVES * l4.per_wave);
+    if (shm4 <= 64 * 1024) {
+      const int max_blocks = 256 * (4 * FB_R4_OCC / FB_R4_WAVES);  // FB_R4_OCC waves per SIMD
+      const int rounds = (total_frames + max_blocks * FB_R4_WAVES - 1) / (max_blocks * FB_R4_WAVES);
+      const int blocks = (total_frames + rounds * FB_R4_WAVES - 1) / (rounds * FB_R4_WAVES);
+      hipLaunchKernelGGL(k_mfcc_r4, dim3(blocks), dim3(64 * FB_R4_WAVES), shm4, s, fe, melw_n, wav,
+                         reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
+      return;
+    }
+  }
   const MfccLds lo = fb_mfcc_layout(fe.P, fe.L, fe.nb, fe.nc, melw_n);
   size_t shm = sizeof(double) * (size_t)(lo.wave0 + 4 * lo.per_wave);
   int blocks = (total_frames + 3) / 4;
