@@ -119,6 +119,42 @@ __device__ __forceinline__ double fb_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// DPP row/bank reductions (VALU data path, no LDS round trips): after the six steps lane 63 holds
+// the wave total, which is broadcast through a scalar register.  Summation order: pairs, quads,
+// half rows, rows (lanes of a 16-lane row), then rows 0+1 / 2+3, then halves -- fixed, so the
+// result is deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int fb_dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double fb_dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = fb_dpp_i32<CTRL, ROW_MASK>((int)(b & 0xffffffffll));
+  const int hi = fb_dpp_i32<CTRL, ROW_MASK>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int fb_wave_sum_i32_dpp(int v) {
+  v += fb_dpp_i32<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += fb_dpp_i32<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += fb_dpp_i32<0x141, 0xf>(v);  // row_half_mirror
+  v += fb_dpp_i32<0x140, 0xf>(v);  // row_mirror
+  v += fb_dpp_i32<0x142, 0xa>(v);  // row_bcast15 -> rows 1, 3
+  v += fb_dpp_i32<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double fb_wave_sum_dpp(double v) {
+  v += fb_dpp_f64<0xb1, 0xf>(v);
+  v += fb_dpp_f64<0x4e, 0xf>(v);
+  v += fb_dpp_f64<0x141, 0xf>(v);
+  v += fb_dpp_f64<0x140, 0xf>(v);
+  v += fb_dpp_f64<0x142, 0xa>(v);
+  v += fb_dpp_f64<0x143, 0xc>(v);
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double fb_wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }

@@ -332,39 +332,48 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
   const int f_first = blockIdx.x * FB_R4_WAVES + w_s, f_step = gridDim.x * FB_R4_WAVES;
   int n0[4], n1[4], nm[4];
   if (f_first < total_frames) load_raw(f_first, n0, n1, nm);
+  // loop-invariant per-lane constants: window weights (0 outside the frame) and 0/1 frame masks
+  double wq0[4], wq1[4], mq0[4], mq1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int s0 = 2 * (lane + 64 * q);
+    wq0[q] = s0 < L ? (double)s_win[min(s0, L - 1)] : 0.0;
+    wq1[q] = s0 + 1 < L ? (double)s_win[min(s0 + 1, L - 1)] : 0.0;
+    mq0[q] = s0 < L ? 1.0 : 0.0;
+    mq1[q] = s0 + 1 < L ? 1.0 : 0.0;
+  }
   for (int f = f_first; f < total_frames; f += f_step) {
+    // DC: the samples are integers, |sum| < 2^24: exact in int32 in any order
+    int isum = 0;
     double xm[4], x0[4], x1[4];
-    double sum = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int s0 = 2 * (lane + 64 * q);
-      x0[q] = s0 < L ? (double)n0[q] : 0.0;
-      x1[q] = s0 + 1 < L ? (double)n1[q] : 0.0;
-      xm[q] = (s0 > 0 && s0 < L) ? (double)nm[q] : x0[q];  // Kaldi: sample 0 is pre-emphasised with itself
-      sum += x0[q] + x1[q];  // integers: exact in any order
+      isum += (s0 < L ? n0[q] : 0) + (s0 + 1 < L ? n1[q] : 0);
+      x0[q] = (double)n0[q];
+      x1[q] = (double)n1[q];
+      xm[q] = (double)(s0 > 0 ? nm[q] : n0[q]);  // Kaldi: sample 0 is pre-emphasised with itself
     }
     if (f + f_step < total_frames) load_raw(f + f_step, n0, n1, nm);
-    sum = fb_wave_sum(sum);
-    const double mean = fe.remove_dc ? sum / (double)L : 0.0;
+    const double mean = fe.remove_dc ? (double)fb_wave_sum_i32_dpp(isum) / (double)L : 0.0;
     double en = 0.0, en2 = 0.0;
     double2 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int s0 = 2 * (lane + 64 * q);
-      // branch-free: out-of-frame samples get weight 0 (x0/x1 are 0 there, but x - mean is not)
-      const double w0 = s0 < L ? (double)s_win[min(s0, L - 1)] : 0.0;
-      const double w1 = s0 + 1 < L ? (double)s_win[min(s0 + 1, L - 1)] : 0.0;
-      const double a = s0 < L ? x0[q] - mean : 0.0, pm = xm[q] - mean;
-      const double c = s0 + 1 < L ? x1[q] - mean : 0.0;
+      // out-of-frame positions hold clamped samples: the masks zero them for the energy, the zero
+      // window weights for the FFT input
+      const double a = (x0[q] - mean) * mq0[q], c = (x1[q] - mean) * mq1[q], pm = xm[q] - mean;
       en = fma(a, a, en);
       en = fma(c, c, en);
-      const double y0 = (a - fe.preemph * pm) * w0;
-      const double y1 = (c - fe.preemph * a) * w1;
-      en2 = fma(y0, y0, en2);
-      en2 = fma(y1, y1, en2);
+      const double y0 = (a - fe.preemph * pm) * wq0[q];
+      const double y1 = (c - fe.preemph * a) * wq1[q];
       v[q] = make_double2(y0, y1);
     }
-    const double energy = fb_wave_sum(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
+    if (!fe.raw_energy) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { en2 = fma(v[q].x, v[q].x, en2); en2 = fma(v[q].y, v[q].y, en2); }
+    }
+    const double energy = fb_wave_sum_dpp(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
 
     // ---- radix-4 Stockham, Ns = 1, 4, 16, 64; input of a stage: points lane + 64 r
     fb_dft4(v[0], v[1], v[2], v[3]);  // Ns = 1: no twiddles

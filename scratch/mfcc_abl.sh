@@ -1,6 +1,6 @@
 #!/bin/bash
-for f in "" -DR4_ABL_NOLOG -DR4_ABL_NOMEL -DR4_ABL_NODCT -DR4_ABL_NOFFT "-DR4_ABL_NOLOG -DR4_ABL_NOMEL -DR4_ABL_NODCT -DR4_ABL_NOFFT"; do
-  FB_EXTRA_HIPCC_FLAGS="$f" python -c "from fakebob_amd import build; build.build(force=True)" 2>&1 | grep -i error
+for f in -DR4_ABL_EMPTY -DR4_ABL_HALF; do
+  FB_EXTRA_HIPCC_FLAGS="$f" python -c "from fakebob_amd import build; build.build(force=True)" 2>&1 | grep -i " error"
   cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$$ -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 3 --streams 1 --no-cpu-baseline > /dev/null 2>&1
   python - <<PY
 import csv,glob
