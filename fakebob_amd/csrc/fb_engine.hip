@@ -100,7 +100,8 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec;
+  DevBuf frame_rec, vad_counter;
+  int t_max = 0;
   std::vector<int32_t> h_frame_rec;
   DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
@@ -146,7 +147,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -463,6 +464,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
   e->h_frame_off[0] = 0;
   e->h_chunk_off[0] = 0;
   e->any_long = false;
+  e->t_max = 0;
   for (int b = 0; b < B; ++b) {
     const int64_t n = off[b + 1] - off[b];
     if (n <= 0) return fb_fail(FB_E_ARG, "utterance %d is empty", b);
@@ -471,6 +473,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
     e->h_frame_off[b + 1] = e->h_frame_off[b] + T;
     e->h_chunk_off[b + 1] = e->h_chunk_off[b] + (T + 31) / 32;
     if (T > e->cfg.cmn_window) e->any_long = true;
+    if (T > e->t_max) e->t_max = T;
   }
   {  // per-frame records for k_mfcc_r4: {absolute start sample (int64), start within the utterance, n}
     const int total = e->h_frame_off[B];
@@ -516,6 +519,30 @@ static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   return (g.n_tiles + tpc - 1) / tpc;
 }
 
+// mfcc -> VAD (+ row offsets) -> deltas -> CMVN -> voiced-row compaction
+static int run_post_mfcc(fb_engine *e, int B) {
+  const FbFrontendDev &fe = e->fe;
+  hipStream_t s = e->stream;
+  if (!e->vad_counter.p) {
+    FBCHK(e->vad_counter.ensure(sizeof(int)));
+    HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), s));
+  }
+  fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>(),
+                e->vad_counter.as<int>(), e->row_off.as<int>());
+  if (fb_launch_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(),
+                           e->row_off.as<int>(), B, e->t_max, e->feats.as<float>()))
+    return FB_OK;
+  const int total_frames = e->h_frame_off[B], total_chunks = e->h_chunk_off[B];
+  FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
+  FBCHK(e->chunk_sum.ensure(sizeof(double) * (size_t)total_chunks * fe.dim));
+  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(), B, total_chunks,
+                   e->dfeat.as<float>(), e->chunk_sum.as<double>());
+  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
+                 e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), B, total_chunks, e->any_long,
+                 e->feats.as<float>());
+  return FB_OK;
+}
+
 // wav (device) + offsets (device) -> raw[B][M] (device).  Purely asynchronous.
 static int run_scoring(fb_engine *e, int B, int total_frames) {
   const FbFrontendDev &fe = e->fe;
@@ -524,7 +551,6 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   FBCHK(e->vrank.ensure(sizeof(int) * (size_t)total_frames));
   FBCHK(e->tv.ensure(sizeof(int) * (size_t)B));
   FBCHK(e->row_off.ensure(sizeof(int) * (size_t)(B + 1)));
-  FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
   const int n_chunks = choose_chunks(g, total_frames);
   if (e->kind == 0) {
@@ -535,15 +561,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   hipStream_t s = e->stream;
   fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
                  e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
-  fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>());
-  fb_launch_rowscan(s, e->tv.as<int>(), B, e->row_off.as<int>());
-  const int total_chunks = e->h_chunk_off[B];
-  FBCHK(e->chunk_sum.ensure(sizeof(double) * (size_t)total_chunks * fe.dim));
-  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(), B, total_chunks,
-                   e->dfeat.as<float>(), e->chunk_sum.as<double>());
-  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
-                 e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), B, total_chunks, e->any_long,
-                 e->feats.as<float>());
+  FBCHK(run_post_mfcc(e, B));
   if (e->kind == 0) {
     if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
     fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
@@ -1195,20 +1213,11 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   FBCHK(e->vrank.ensure(sizeof(int) * (size_t)T));
   FBCHK(e->tv.ensure(sizeof(int)));
   FBCHK(e->row_off.ensure(sizeof(int) * 2));
-  FBCHK(e->dfeat.ensure(sizeof(float) * (size_t)T * fe.dim));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(), e->frame_rec.as<int32_t>(), 1, T,
-                 e->mfcc.as<float>());
-  fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), 1, e->vrank.as<int>(), e->tv.as<int>());
-  fb_launch_rowscan(s, e->tv.as<int>(), 1, e->row_off.as<int>());
-  const int total_chunks = e->h_chunk_off[1];
-  FBCHK(e->chunk_sum.ensure(sizeof(double) * (size_t)total_chunks * fe.dim));
-  fb_launch_deltas(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(), 1, total_chunks,
-                   e->dfeat.as<float>(), e->chunk_sum.as<double>());
-  fb_launch_cmvn(s, fe, e->dfeat.as<float>(), e->frame_off.as<int>(), e->chunk_off.as<int>(),
-                 e->chunk_sum.as<double>(), e->vrank.as<int>(), e->row_off.as<int>(), 1, total_chunks, e->any_long,
-                 e->feats.as<float>());
+  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
+                 e->frame_rec.as<int32_t>(), 1, T, e->mfcc.as<float>());
+  FBCHK(run_post_mfcc(e, 1));
   HIPCHK(hipGetLastError());
   return FB_OK;
 }

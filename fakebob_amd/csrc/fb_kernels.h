@@ -67,10 +67,13 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
                     const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
                     int total_frames, float *mfcc);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
+// counter: one device int, zero before the first launch (the kernel leaves it at zero); row_off[B+1]
+// = exclusive scan of max(tv, 0), written by the workgroup that finishes last
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
-                   int *vrank, int *tv);
+                   int *vrank, int *tv, int *counter, int *row_off);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
-void fb_launch_rowscan(hipStream_t s, const int *tv, int B, int *row_off);
+bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
+                          const int *vrank, const int *row_off, int B, int t_max, float *feats);
 // add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk
 // column sums for the CMVN mean
 void fb_launch_deltas(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,

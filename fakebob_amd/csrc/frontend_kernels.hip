@@ -492,9 +492,13 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
 }
 
 // -------------------------------------------------------------------- VAD
+// The workgroup that finishes last (device-wide counter) also turns the voiced counts into the row
+// offsets of the compacted feature matrix (select-voiced-frames bookkeeping), so no separate scan
+// kernel is launched.  The counter is left at zero for the next launch.
 __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__restrict__ mfcc,
                                              const int *__restrict__ frame_off, int *__restrict__ vrank,
-                                             int *__restrict__ tv) {
+                                             int *__restrict__ tv, int B, int *__restrict__ counter,
+                                             int *__restrict__ row_off) {
   const int b = blockIdx.x;
   const int base = frame_off[b], T = frame_off[b + 1] - base;
   __shared__ double red[256];
@@ -535,33 +539,43 @@ __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__re
     if (threadIdx.x == 0) s_run += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
     __syncthreads();
   }
-  if (threadIdx.x == 0) tv[b] = s_run;
-}
-void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
-                   int *vrank, int *tv) {
-  hipLaunchKernelGGL(k_vad, dim3(B), dim3(256), 0, s, fe, mfcc, frame_off, vrank, tv);
-}
-
-__global__ __launch_bounds__(256) void k_rowscan(const int *__restrict__ tv, int B, int *__restrict__ row_off) {
-  // single block; B is small (utterances per batch)
-  __shared__ int s_part[256];
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&tv[b], s_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = (atomicAdd(counter, 1) == B - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // exclusive scan of max(tv, 0): thread = contiguous slice, wave scan by shuffles, 4 wave totals
   const int per = (B + 255) / 256;
   const int lo = threadIdx.x * per, hi = min(B, lo + per);
   int sum = 0;
-  for (int i = lo; i < hi; ++i) sum += tv[i] > 0 ? tv[i] : 0;
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int i = 0; i < 256; ++i) { int v = s_part[i]; s_part[i] = run; run += v; }
-    row_off[B] = run;
+  for (int i = lo; i < hi; ++i) {
+    const int v = __hip_atomic_load(&tv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum += v > 0 ? v : 0;
   }
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) s_wtot[w] = inc;
   __syncthreads();
-  int run = s_part[threadIdx.x];
-  for (int i = lo; i < hi; ++i) { row_off[i] = run; run += tv[i] > 0 ? tv[i] : 0; }
+  int run = inc - sum;
+  for (int i = 0; i < w; ++i) run += s_wtot[i];
+  if (threadIdx.x == 255) { row_off[B] = run + sum; *counter = 0; }
+  for (int i = lo; i < hi; ++i) {
+    const int v = __hip_atomic_load(&tv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    row_off[i] = run;
+    run += v > 0 ? v : 0;
+  }
 }
-void fb_launch_rowscan(hipStream_t s, const int *tv, int B, int *row_off) {
-  hipLaunchKernelGGL(k_rowscan, dim3(1), dim3(256), 0, s, tv, B, row_off);
+void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                   int *vrank, int *tv, int *counter, int *row_off) {
+  hipLaunchKernelGGL(k_vad, dim3(B), dim3(256), 0, s, fe, mfcc, frame_off, vrank, tv, B, counter, row_off);
 }
 
 // ------------------------------------------------------------------ deltas
@@ -676,6 +690,151 @@ __global__ __launch_bounds__(256) void k_cmvn_sliding(FbFrontendDev fe, const fl
     }
   }
 }
+// add-deltas | apply-cmvn-sliding | select-voiced-frames for utterances that fit the CMVN window
+// (every NES batch): one workgroup per utterance keeps the MFCCs and the delta features in LDS, so
+// the delta features never travel to HBM.  The mean is the float64 sum over the frames in order
+// (Kaldi's running window sum when the window covers the whole utterance).
+// ORDER/WIN > 0: delta options known at compile time (the recipe's 2/3 and Kaldi's default 2/2): the
+// tap loops unroll, coefficients live in registers and all LDS loads of an output are issued before
+// the dependent float64 adds.  ORDER < 0: any options.
+template <int ORDER, int WIN>
+__global__ __launch_bounds__(1024) void k_delta_cmvn(FbFrontendDev fe, const float *__restrict__ mfcc,
+                                                     const int *__restrict__ frame_off,
+                                                     const int *__restrict__ vrank,
+                                                     const int *__restrict__ row_off, int t_cap,
+                                                     float *__restrict__ feats) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int b = blockIdx.x, nc = fe.nc, dim = fe.dim, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const int order = ORDER > 0 ? ORDER : fe.order, dwin = ORDER > 0 ? WIN : fe.dwin;
+  const int maxlen = 2 * order * dwin + 1;
+  double *s_sum = s_dyn;                                        // [dim]
+  double *s_sc = s_sum + dim;                                   // [(order+1)][maxlen]
+  const int ctx = order * dwin;
+  float *s_mf = reinterpret_cast<float *>(s_sc + (order + 1) * maxlen);  // [ctx + T + ctx][nc], edges replicated
+  float *s_df = s_mf + (size_t)(t_cap + 2 * ctx) * nc;          // [T][dim]
+  int *s_vr = reinterpret_cast<int *>(s_df + (size_t)t_cap * dim);  // [T]
+  for (int i = tid; i < (order + 1) * maxlen; i += 1024) s_sc[i] = fe.dscale[i];
+  {  // MFCCs of the utterance: issue every load of this thread before the first LDS store
+    constexpr int NL = 8;
+    const float *src = mfcc + (size_t)base * nc;
+    const int n = T * nc;
+    for (int i0 = tid; i0 < n; i0 += 1024 * NL) {
+      float v[NL];
+#pragma unroll
+      for (int u = 0; u < NL; ++u) v[u] = src[min(i0 + 1024 * u, n - 1)];
+#pragma unroll
+      for (int u = 0; u < NL; ++u) if (i0 + 1024 * u < n) s_mf[ctx * nc + i0 + 1024 * u] = v[u];
+    }
+    for (int i = tid; i < ctx * nc; i += 1024) {  // Kaldi clamps the frame index at both ends
+      const int d = i % nc;
+      s_mf[i] = src[d];
+      s_mf[(ctx + T) * nc + i] = src[(size_t)(T - 1) * nc + d];
+    }
+  }
+  for (int i = tid; i < T; i += 1024) s_vr[i] = vrank[base + i];
+  __syncthreads();
+  double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
+  if constexpr (ORDER > 0) {
+#pragma unroll
+    for (int i = 0; i <= ORDER; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * ORDER * WIN + 1; ++j) creg[i][j] = s_sc[i * (2 * ORDER * WIN + 1) + j];
+  }
+  // ---- add-deltas: half-wave = frame, lane = coefficient (no divisions); float64 taps in order
+  for (int d0 = 0; d0 < nc; d0 += 32) {
+    const int d = d0 + (lane & 31);
+    for (int t = 2 * w + (lane >> 5); t < T; t += 32) {
+      if (d < nc) {
+        if constexpr (ORDER > 0) {
+#pragma unroll
+          for (int i = 0; i <= ORDER; ++i) {
+            constexpr int ML = 2 * ORDER * WIN + 1;
+            const int off = i * WIN;
+            float x[ML];
+            const float *row = s_mf + (t + ctx - off) * nc + d;
+#pragma unroll
+            for (int j = 0; j < ML; ++j)
+              if (j <= 2 * off) x[j] = row[j * nc];
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < ML; ++j)
+              if (j <= 2 * off) acc = __dadd_rn(acc, __dmul_rn(creg[i][j], (double)x[j]));
+            s_df[t * dim + i * nc + d] = (float)acc;
+          }
+        } else {
+          for (int i = 0; i <= order; ++i) {
+            const double *sc = s_sc + i * maxlen;
+            const int off = i * dwin;
+            double acc = 0.0;
+            // (zero coefficients are not skipped as add-deltas does: adding an exact zero changes nothing)
+            for (int j = 0; j <= 2 * off; ++j)
+              acc = __dadd_rn(acc, __dmul_rn(sc[j], (double)s_mf[(t + ctx - off + j) * nc + d]));
+            s_df[t * dim + i * nc + d] = (float)acc;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < dim) {  // frames in order; the loads of 8 frames are issued before their (dependent) adds
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)x[u];
+    }
+    for (; t < T; ++t) acc += (double)s_df[t * dim + tid];
+    s_sum[tid] = acc;
+  }
+  __syncthreads();
+  // ---- CMVN + voiced-row compaction: wave = frame, lane = dimension
+  const int rbase = row_off[b];
+  const double alpha = (double)(float)(-1.0 / (double)T);
+  for (int d = lane; d < dim; d += 64) {
+    const double shift = __dmul_rn(alpha, s_sum[d]);
+#pragma unroll 4
+    for (int t = w; t < T; t += 16) {
+      const int r = s_vr[t];
+      if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[t * dim + d], shift);
+    }
+  }
+}
+size_t fb_delta_cmvn_lds_bytes(const FbFrontendDev &fe, int t_cap) {
+  const int maxlen = 2 * fe.order * fe.dwin + 1;
+  return sizeof(double) * (size_t)(fe.dim + (fe.order + 1) * maxlen) +
+         sizeof(float) * ((size_t)(t_cap + 2 * fe.order * fe.dwin) * fe.nc + (size_t)t_cap * fe.dim) +
+         sizeof(int) * (size_t)t_cap + 16;
+}
+// returns false when the batch does not qualify (an utterance longer than the CMVN window or than
+// the LDS allows): the caller then runs fb_launch_deltas + fb_launch_cmvn
+bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
+                          const int *vrank, const int *row_off, int B, int t_max, float *feats) {
+  if (B <= 0) return true;
+  if (t_max > fe.cmn_window) return false;
+  const size_t shm = fb_delta_cmvn_lds_bytes(fe, t_max);
+  if (shm > 150 * 1024) return false;
+  static bool configured = false;  // raise the dynamic-LDS limit once per process
+  if (!configured) {
+    const void *fns[] = {reinterpret_cast<const void *>(k_delta_cmvn<2, 3>), reinterpret_cast<const void *>(k_delta_cmvn<2, 2>),
+                         reinterpret_cast<const void *>(k_delta_cmvn<-1, 0>)};
+    for (const void *fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;
+    configured = true;
+  }
+  if (fe.order == 2 && fe.dwin == 3)
+    hipLaunchKernelGGL((k_delta_cmvn<2, 3>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);
+  else if (fe.order == 2 && fe.dwin == 2)
+    hipLaunchKernelGGL((k_delta_cmvn<2, 2>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);
+  else
+    hipLaunchKernelGGL((k_delta_cmvn<-1, 0>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);
+  return true;
+}
+
 void fb_launch_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *dfeat, const int *frame_off,
                     const int *chunk_off, const double *chunk_sum, const int *vrank, const int *row_off, int B,
                     int total_chunks, bool any_long, float *feats) {
