@@ -71,7 +71,7 @@ struct DevBuf {
 struct fb_engine {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evg0 = nullptr, evg1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool time_gmm = false;       // record events around the GMM launch (bench)
   bool gmm_pending = false;
   double gmm_ms_acc = 0.0;
@@ -100,7 +100,10 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter;
+  DevBuf frame_rec, vad_counter, ctl, ctl_ls, trace_dev;
+  FbCtlDev *h_ctl = nullptr;  // pinned
+  hipEvent_t evg_ring[2 * 16] = {};
+  int evg_n = 0;
   int t_max = 0;
   std::vector<int32_t> h_frame_rec;
   DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
@@ -131,8 +134,8 @@ extern "C" int fb_engine_create(int device, fb_engine **out) {
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&e->ev0));
   HIPCHK(hipEventCreate(&e->ev1));
-  HIPCHK(hipEventCreate(&e->evg0));
-  HIPCHK(hipEventCreate(&e->evg1));
+  for (hipEvent_t &ev : e->evg_ring) HIPCHK(hipEventCreate(&ev));
+  HIPCHK(hipHostMalloc((void **)&e->h_ctl, sizeof(FbCtlDev), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->h_out, sizeof(FbNesDev), hipHostMallocDefault));
   fb_frontend_cfg cfg;
   fb_default_frontend(&cfg);
@@ -147,7 +150,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->vad_counter, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -157,8 +160,8 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (e->h_tv) (void)hipHostFree(e->h_tv);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
-  if (e->evg0) (void)hipEventDestroy(e->evg0);
-  if (e->evg1) (void)hipEventDestroy(e->evg1);
+  for (hipEvent_t ev : e->evg_ring) if (ev) (void)hipEventDestroy(ev);
+  if (e->h_ctl) (void)hipHostFree(e->h_ctl);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FB_OK;
@@ -519,6 +522,36 @@ static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   return (g.n_tiles + tpc - 1) / tpc;
 }
 
+// HIP-event timing of the dominant kernel (bench only): a ring of event pairs, because several
+// iterations may be queued before the host looks at the stream again
+static int time_collect(fb_engine *e) {
+  for (int i = 0; i < e->evg_n; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->evg_ring[2 * i], e->evg_ring[2 * i + 1]));
+    e->gmm_ms_acc += (double)ms;
+    e->gmm_launches += 1;
+  }
+  e->evg_n = 0;
+  e->gmm_pending = false;
+  return FB_OK;
+}
+static int time_begin(fb_engine *e) {
+  if (!e->time_gmm) return FB_OK;
+  if (e->evg_n >= 16) {  // ring full: drain (never happens with the batch sizes used)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    FBCHK(time_collect(e));
+  }
+  HIPCHK(hipEventRecord(e->evg_ring[2 * e->evg_n], e->stream));
+  return FB_OK;
+}
+static int time_end(fb_engine *e) {
+  if (!e->time_gmm) return FB_OK;
+  HIPCHK(hipEventRecord(e->evg_ring[2 * e->evg_n + 1], e->stream));
+  e->evg_n += 1;
+  e->gmm_pending = true;
+  return FB_OK;
+}
+
 // mfcc -> VAD (+ row offsets) -> deltas -> CMVN -> voiced-row compaction
 static int run_post_mfcc(fb_engine *e, int B) {
   const FbFrontendDev &fe = e->fe;
@@ -563,10 +596,10 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
                  e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, B));
   if (e->kind == 0) {
-    if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
+    FBCHK(time_begin(e));
     fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                   e->part_m.as<float>(), e->part_s.as<float>());
-    if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
+    FBCHK(time_end(e));
     fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
                            e->row_off.as<int>(), B, e->raw.as<double>());
   } else {
@@ -605,11 +638,11 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_sel.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
     // bench timing of the T-matrix contraction (k_iv_lin + k_iv_quad): the HBM-streaming kernels
-    if (e->time_gmm) HIPCHK(hipEventRecord(e->evg0, s));
+    FBCHK(time_begin(e));
     fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
                           e->iv_active.as<int>(), e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(),
                           e->iv_quad.as<double>());
-    if (e->time_gmm) { HIPCHK(hipEventRecord(e->evg1, s)); e->gmm_pending = true; }
+    FBCHK(time_end(e));
     fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
                        e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
@@ -960,30 +993,87 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B) {
 
 // One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
 static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
-                            const double *noise_dev, bool with_dist) {
+                            const double *noise_dev, bool with_dist, FbCtlDev *ctl = nullptr,
+                            double *trace_dev = nullptr, int trace_row = 0) {
   const int half = p->samples_per_draw / 2, B = 2 * half + 1;
   int ndp = 0;
+  const int *stop = ctl ? &ctl->stop : nullptr;
+  e->fe.stop = stop;
+  e->gmm.stop = stop;
   fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
                     p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
-                    e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>());
-  FBCHK(run_scoring(e, B, e->h_frame_off[B]));
+                    e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>(), stop);
+  const int rc = run_scoring(e, B, e->h_frame_off[B]);
+  e->fe.stop = nullptr;
+  e->gmm.stop = nullptr;
+  FBCHK(rc);
   fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->n_out, p->task, e->kind, p->attack_type,
                  e->zmean.as<double>(), e->zstd.as<double>(), p->threshold, p->adver_thresh, p->target,
                  p->true_label, e->dist_part.as<double>(), with_dist ? ndp : 0, e->scores.as<double>(),
-                 e->loss.as<double>(), e->nes_out.as<FbNesDev>());
+                 e->loss.as<double>(), e->nes_out.as<FbNesDev>(), ctl, trace_dev, trace_row);
+  return FB_OK;
+}
+
+// The NES loop of FakeBob.attack (FAKEBOB.py:171-216) with the loop control on the device
+// (FbCtlDev): `count` iterations starting at Philox iteration index `it_base` are queued `batch` at
+// a time; the host reads the control block once per batch.  reset: start a new attack (lr = max_lr,
+// empty loss history); otherwise continue the previous state (bench warm-up -> timed region).
+// trace_dev rows are indexed from it_base.
+static int attack_batch_size() {
+  const char *ev = getenv("FB_ATTACK_BATCH");
+  int k = ev ? atoi(ev) : 8;
+  return k < 1 ? 1 : (k > 16 ? 16 : k);
+}
+static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, const double *noise_all, int it_base,
+                           int count, bool reset, bool disable_stop, double *trace_dev) {
+  const int half = p->samples_per_draw / 2;
+  FBCHK(e->ctl.ensure(sizeof(FbCtlDev)));
+  FBCHK(e->ctl_ls.ensure(sizeof(double) * (size_t)(p->plateau_length > 0 ? p->plateau_length : 1)));
+  FbCtlDev *ctl = e->ctl.as<FbCtlDev>();
+  if (reset) {
+    FbCtlDev h;
+    memset(&h, 0, sizeof(h));
+    h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;
+    h.ls = e->ctl_ls.as<double>();
+    h.plateau_length = p->plateau_length;
+    h.disable_stop = disable_stop ? 1 : 0;
+    *e->h_ctl = h;
+    HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // h_ctl is reused for the read-back below
+  }
+  const double one_minus_m = 1.0 - p->momentum;
+  const int K = attack_batch_size();
+  int done = 0;
+  while (done < count) {
+    const int nb = count - done < K ? count - done : K;
+    for (int k = 0; k < nb; ++k) {
+      const int it = it_base + done + k;
+      const double *noise_dev = nullptr;
+      if (noise_all && half > 0) {
+        HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half,
+                              hipMemcpyHostToDevice, e->stream));
+        noise_dev = e->noise.as<double>();
+      }
+      FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base));
+      fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
+                            nullptr, 1, p->momentum, one_minus_m, 0.0, p->epsilon, e->audio.as<double>(),
+                            e->grad_m.as<double>(), e->adver.as<double>(), ctl);
+    }
+    HIPCHK(hipMemcpyAsync(e->h_ctl, ctl, sizeof(FbCtlDev), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->gmm_pending) FBCHK(time_collect(e));
+    if (e->h_ctl->err != 0)
+      return fb_fail(FB_E_NO_VOICED, "NES sample %d has no voiced frames", e->h_ctl->err - 1);
+    done += nb;
+    if (e->h_ctl->stop) break;
+  }
   return FB_OK;
 }
 
 static int fetch_out(fb_engine *e) {
   HIPCHK(hipMemcpyAsync(e->h_out, e->nes_out.p, sizeof(FbNesDev), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (e->gmm_pending) {
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->evg0, e->evg1));
-    e->gmm_ms_acc += (double)ms;
-    e->gmm_launches += 1;
-    e->gmm_pending = false;
-  }
+  if (e->gmm_pending) FBCHK(time_collect(e));
   if (e->h_out->err != 0)
     return fb_fail(FB_E_NO_VOICED, "NES sample %d has no voiced frames", e->h_out->err - 1);
   return FB_OK;
@@ -1044,36 +1134,18 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
   HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));  // grad = 0 (:157)
   if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
-  Plateau pl;
-  pl.lr = p->max_lr;
-  const double one_minus_m = 1.0 - p->momentum;
-  int rows = 0, it = 0;
-  bool broke = false;
-  for (it = 0; it < p->max_iter; ++it) {
-    const double *noise_dev = nullptr;
-    if (noise_all && half > 0) {
-      HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half,
-                            hipMemcpyHostToDevice, e->stream));
-      noise_dev = e->noise.as<double>();
-    }
-    FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true));
-    FBCHK(fetch_out(e));
-    e->nes_iters += 1;
-    double *row = trace ? trace + (size_t)rows * (3 + S) : nullptr;
-    const double adver_loss = e->h_out->adver_loss;
-    if (adver_loss < 0.0) {  // :181
-      if (row) { row[0] = e->h_out->distance; row[1] = adver_loss; row[2] = pl.lr; for (int s = 0; s < S; ++s) row[3 + s] = e->h_out->score0[s]; }
-      ++rows;
-      broke = true;
-      break;
-    }
-    pl.step(e->h_out->final_loss, p);
-    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
-                          nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
-                          e->grad_m.as<double>(), e->adver.as<double>());
-    if (row) { row[0] = e->h_out->distance; row[1] = adver_loss; row[2] = pl.lr; for (int s = 0; s < S; ++s) row[3 + s] = e->h_out->score0[s]; }
-    ++rows;
+  double *trace_dev = nullptr;
+  if (trace) {
+    FBCHK(e->trace_dev.ensure(sizeof(double) * (size_t)p->max_iter * (3 + S)));
+    trace_dev = e->trace_dev.as<double>();
   }
+  FBCHK(run_attack_core(e, p, N, noise_all, 0, p->max_iter, true, false, trace_dev));
+  const int rows = e->h_ctl->iters_done;  // one trace row per executed iteration, the stopping one included
+  const bool broke = e->h_ctl->broke != 0;
+  const int it = e->h_ctl->stop_iter;
+  e->nes_iters += rows;
+  if (trace && rows > 0)
+    HIPCHK(hipMemcpyAsync(trace, trace_dev, sizeof(double) * (size_t)rows * (3 + S), hipMemcpyDeviceToHost, e->stream));
   const int last_iter = broke ? it : p->max_iter - 1;
   *success_flag = (last_iter < p->max_iter - 1) ? 1 : -1;  // :219
   if (n_trace) *n_trace = rows;
@@ -1292,28 +1364,17 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
   HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
-  Plateau pl;
-  pl.lr = p->max_lr;
-  const double one_minus_m = 1.0 - p->momentum;
   double gmm_ms = 0.0;
   int64_t vrows = 0;
-  for (int it = 0; it < warmup + iters; ++it) {
-    if (it == warmup) {
-      HIPCHK(hipStreamSynchronize(e->stream));
-      HIPCHK(hipEventRecord(e->ev0, e->stream));
-      e->time_gmm = time_gmm != 0;
-      e->gmm_ms_acc = 0.0;
-      e->gmm_launches = 0;
-    }
-    // identical work to fb_attack's loop body (early stop disabled for timing)
-    FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, nullptr, true));
-    FBCHK(fetch_out(e));
-    e->nes_iters += 1;
-    pl.step(e->h_out->final_loss, p);
-    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), nullptr,
-                          nullptr, 1, p->momentum, one_minus_m, pl.lr, p->epsilon, e->audio.as<double>(),
-                          e->grad_m.as<double>(), e->adver.as<double>());
-  }
+  // identical work to fb_attack's loop (early stop disabled for timing)
+  FBCHK(run_attack_core(e, p, N, nullptr, 0, warmup > 0 ? warmup : 0, true, true, nullptr));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  e->time_gmm = time_gmm != 0;
+  e->gmm_ms_acc = 0.0;
+  e->gmm_launches = 0;
+  FBCHK(run_attack_core(e, p, N, nullptr, warmup > 0 ? warmup : 0, iters, warmup <= 0, true, nullptr));
+  e->nes_iters += warmup + iters;
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));
   e->time_gmm = false;

@@ -24,6 +24,7 @@ struct FbFrontendDev {
   const double *dct;      // [nc][nb] (float32 values widened)
   const double *lifter;   // [nc]
   const double *dscale;   // [(order+1)][2*order*dwin+1] delta kernels (float32 values widened)
+  const int *stop;        // nullable device flag: != 0 -> k_mfcc does nothing (attack already stopped)
 };
 
 // ---- NES ----------------------------------------------------------------
@@ -33,13 +34,24 @@ struct FbFrontendDev {
 void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
                        const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part,
-                       float *zbuf /* nullable: float32 normals [half][N] for the gradient kernel */);
+                       float *zbuf /* nullable: float32 normals [half][N] for the gradient kernel */,
+                       const int *stop = nullptr /* nullable: device flag, != 0 -> the launch does nothing */);
 // plain quantisation of float64 audio (model.score on float input)
 void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q);
 // noise dump (tests)
 void fb_launch_noise(hipStream_t s, uint64_t seed, uint32_t iter, uint32_t stream, int64_t N, int half,
                      float *z);
 
+// Device-side control block of an attack (FAKEBOB.py:171-203): early stop on loss[0] < 0 (:181), the
+// plateau learning-rate schedule (:195-200) and the per-iteration trace rows are handled by the loss
+// kernel itself, so the host can queue several NES iterations ahead and only looks at the block once
+// per batch.  Iterations queued behind the stopping one see `stop` and do nothing.
+struct FbCtlDev {
+  double lr, min_lr, plateau_drop;
+  double *ls;  // [plateau_length] recent losses
+  int n_ls, plateau_length;
+  int stop, broke, stop_iter, iters_done, err, disable_stop;
+};
 struct FbNesDev {  // device control/result block of one NES iteration
   double adver_loss, final_loss, distance;
   int err;       // !=0: utterance (err-1) had no voiced frames
@@ -51,13 +63,14 @@ struct FbNesDev {  // device control/result block of one NES iteration
 void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,
                     int attack_type, const double *z_mean, const double *z_std, double threshold,
                     double adver_thresh, int target, int true_label, const double *dist_part,
-                    int n_dist_part, double *scores, double *loss, FbNesDev *out);
+                    int n_dist_part, double *scores, double *loss, FbNesDev *out, FbCtlDev *ctl = nullptr,
+                    double *trace = nullptr, int it = 0);
 // grad estimate (numpy-pairwise order) + optional momentum/sign/clip update.
 // do_update: 0 = only grad_out; 1 = momentum+update with lr.
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
                            const float *zbuf, const double *noise_pos, double *grad_out, int do_update,
                            double momentum, double one_minus_m, double lr, double epsilon,
-                           const double *audio, double *grad_m, double *adver);
+                           const double *audio, double *grad_m, double *adver, const FbCtlDev *ctl = nullptr);
 
 // ---- front-end ------------------------------------------------------------
 // MFCC of every frame of a (ragged) batch.  wav_off[B+1], frame_off[B+1] device arrays.
@@ -92,6 +105,7 @@ struct FbGmmDev {
   // bf16x3 variant (k_gmm_bx3): K padded to 16*NK >= D + 3, images [n_tiles][n_items][3][NK][64] x 16 B
   int mode, NK;
   const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
+  const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
 };
 #define FB_GMM_MODE_F32 0
 #define FB_GMM_MODE_BX3 1

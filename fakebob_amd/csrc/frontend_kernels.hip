@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
                                               const int64_t *__restrict__ wav_off,
                                               const int *__restrict__ frame_off, int B, int total_frames,
                                               float *__restrict__ mfcc) {
+  if (fe.stop && *fe.stop) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int P = fe.P, Nc = P >> 1, L = fe.L, nb = fe.nb, nc = fe.nc;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
                                                                        const int4 *__restrict__ frame_rec,
                                                                        int total_frames,
                                                                        float *__restrict__ mfcc) {
+  if (fe.stop && *fe.stop) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = 64 * FB_R4_WAVES, Nc = 256;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restr
                                                 const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
                                                 int rows_cap, float *__restrict__ part_m,
                                                 float *__restrict__ part_s) {
+  if (g.stop && *g.stop) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROWF = 2 * KH + 4;
   constexpr int IMGF = 32 * ROWF + 32;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_bx3(FbGmmDev g, const float *__r
                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
                                                     int rows_cap, float *__restrict__ part_m,
                                                     float *__restrict__ part_s) {
+  if (g.stop && *g.stop) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG4 = 3 * NK * 64;  // 16-byte units per item
   constexpr int NST = (IMG4 + 255) / 256;

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
                                                  const double *__restrict__ noise_pos,
                                                  int16_t *__restrict__ q,
                                                  double *__restrict__ dist_part,
-                                                 float *__restrict__ zbuf) {
+                                                 float *__restrict__ zbuf, const int *__restrict__ stop) {
+  if (stop && *stop) return;
   const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
   const int64_t n0 = n4 * 4;
@@ -82,12 +83,13 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
 
 void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
-                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part, float *zbuf) {
+                       const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part, float *zbuf,
+                       const int *stop) {
   int64_t n4 = (N + 3) / 4;
   dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)(half > 0 ? half : 1));
   if (n_dist_part) *n_dist_part = (int)grid.x;
   hipLaunchKernelGGL(k_perturb, grid, dim3(256), 0, s, adver, audio, N, half, sigma, seed, iter, stream,
-                     noise_pos, q, dist_part, zbuf);
+                     noise_pos, q, dist_part, zbuf, stop);
 }
 
 __global__ __launch_bounds__(256) void k_quantize(const double *__restrict__ x, int64_t n, double scale,
@@ -188,6 +190,9 @@ __device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
   return ret;
 }
 
+// SMALL: samples_per_draw <= 128 -- numpy's sum is a single block then and the kernel needs no
+// recursion stack (the stack lives in scratch memory, which also slows the dispatch down)
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, const int *__restrict__ tv,
                                               int B, int M, int task, int znorm_all, int attack_type,
                                               const double *__restrict__ z_mean,
@@ -195,7 +200,9 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
                                               double adver_thresh, int target, int true_label,
                                               const double *__restrict__ dist_part, int n_dist_part,
                                               double *__restrict__ scores, double *__restrict__ loss,
-                                              FbNesDev *__restrict__ out) {
+                                              FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
+                                              double *__restrict__ trace, int it) {
+  if (ctl && ctl->stop) return;  // queued behind the stopping iteration
   const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
   __shared__ int s_err;
   if (threadIdx.x == 0) s_err = 0;
@@ -238,21 +245,67 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
     const int spd = B - 1;
     out->adver_loss = loss[0];
     auto el = [&](int i) { return D1{loss[1 + i]}; };
-    out->final_loss = spd > 0 ? __ddiv_rn(fb_np_sum<D1>(el, 0, spd).v, (double)spd) : 0.0;  // np.mean :243
+    const double lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : 0.0;  // np.mean :243
     for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
     double d = 0.0;
     for (int i = 0; i < n_dist_part; ++i) d = dist_part[i] > d ? dist_part[i] : d;
     out->distance = d;
     out->err = s_err;
+    if (ctl) {
+      double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
+      const double al = loss[0];
+      if (s_err) {
+        ctl->err = s_err;
+        ctl->stop = 1;
+      } else {
+        if (al < 0.0 && !ctl->disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
+          ctl->stop = 1;
+          ctl->broke = 1;
+          ctl->stop_iter = it;
+        } else {  // :195-200
+          const int PL = ctl->plateau_length;
+          if (PL > 0) {
+            int n = ctl->n_ls;
+            if (n < PL) {
+              ctl->ls[n++] = out->final_loss;
+            } else {
+              for (int i = 1; i < PL; ++i) ctl->ls[i - 1] = ctl->ls[i];
+              ctl->ls[PL - 1] = out->final_loss;
+            }
+            if (n == PL && ctl->ls[PL - 1] > ctl->ls[0]) {
+              if (ctl->lr > ctl->min_lr) {
+                const double l2 = __ddiv_rn(ctl->lr, ctl->plateau_drop);
+                ctl->lr = l2 > ctl->min_lr ? l2 : ctl->min_lr;
+              }
+              n = 0;
+            }
+            ctl->n_ls = n;
+          }
+        }
+        if (row) {
+          row[0] = d; row[1] = al; row[2] = ctl->lr;
+          for (int m = 0; m < S; ++m) row[3 + m] = scores[m];
+        }
+        ctl->iters_done = it + 1;
+      }
+    }
   }
 }
 
 void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,
                     int attack_type, const double *z_mean, const double *z_std, double threshold,
                     double adver_thresh, int target, int true_label, const double *dist_part,
-                    int n_dist_part, double *scores, double *loss, FbNesDev *out) {
-  hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, znorm_all, attack_type, z_mean, z_std,
-                     threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out);
+                    int n_dist_part, double *scores, double *loss, FbNesDev *out, FbCtlDev *ctl, double *trace,
+                    int it) {
+  if (B - 1 <= 128)
+    hipLaunchKernelGGL(k_loss<true>, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, znorm_all, attack_type, z_mean,
+                       z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
+                       ctl, trace, it);
+  else
+    hipLaunchKernelGGL(k_loss<false>, dim3(1), dim3(256), 0, s, raw, tv, B, M, task, znorm_all, attack_type, z_mean,
+                       z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
+                       ctl, trace, it);
 }
 
 // ------------------------------------------------------------- grad + update
@@ -260,27 +313,44 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 // then grad = m*pre + (1-m)*grad (:193), adver -= lr*sign(grad), clip (:202-203).
 // The normals come back from the buffer k_perturb wrote (zbuf, float32 [half][N]) or from the
 // caller's float64 tensor (noise_pos [N][half]); products are summed in numpy's pairwise order.
+#define FB_GRAD_LDS_PAIRS 40  // normals of a 256-sample block staged in LDS up to samples_per_draw = 80
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ loss, int64_t N, int half,
                                                      double sigma, const float *__restrict__ zbuf,
                                                      const double *__restrict__ noise_pos,
                                                      double *__restrict__ grad_out, int do_update,
                                                      double momentum, double one_minus_m, double lr,
                                                      double epsilon, const double *__restrict__ audio,
-                                                     double *__restrict__ grad_m, double *__restrict__ adver) {
-  extern __shared__ double s_loss[];  // loss[1..spd]
+                                                     double *__restrict__ grad_m, double *__restrict__ adver,
+                                                     const FbCtlDev *__restrict__ ctl) {
+  if (ctl) {  // device-controlled attack: the loss kernel decided whether to go on and with which step
+    if (ctl->stop) return;
+    lr = ctl->lr;
+  }
+  extern __shared__ double s_loss[];  // loss[1..spd], then (zbuf path) the block's normals [half][256]
   const int spd = 2 * half;
+  float *s_z = reinterpret_cast<float *>(s_loss + spd);
   for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
-  __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool lds_z = !noise_pos && half <= FB_GRAD_LDS_PAIRS;
+  if (lds_z) {  // every load of the thread is in flight before the first use
+    const int64_t nc = n < N ? n : N - 1;
+    for (int j = 0; j < half; ++j) s_z[j * 256 + threadIdx.x] = zbuf[(int64_t)j * N + nc];
+  }
+  __syncthreads();
   if (n >= N) return;
   auto el = [&](int i) -> D1 {
     const int j = i < half ? i : i - half;
-    double z = noise_pos ? noise_pos[n * half + j] : (double)zbuf[(int64_t)j * N + n];
+    double z = noise_pos ? noise_pos[n * half + j]
+                         : (lds_z ? (double)s_z[j * 256 + threadIdx.x] : (double)zbuf[(int64_t)j * N + n]);
     if (i >= half) z = -z;
     return D1{__dmul_rn(s_loss[i], z)};
   };
   double g = 0.0;
-  if (spd > 0) g = __ddiv_rn(__ddiv_rn(fb_np_sum<D1>(el, 0, spd).v, (double)spd), sigma);
+  if (spd > 0) {
+    const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
+  }
   if (grad_out) grad_out[n] = g;
   if (do_update) {
     double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
@@ -300,9 +370,14 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
                            const float *zbuf, const double *noise_pos, double *grad_out, int do_update,
                            double momentum, double one_minus_m, double lr, double epsilon,
-                           const double *audio, double *grad_m, double *adver) {
+                           const double *audio, double *grad_m, double *adver, const FbCtlDev *ctl) {
   int blocks = (int)((N + 255) / 256);
   size_t shm = sizeof(double) * (size_t)(2 * half > 0 ? 2 * half : 1);
-  hipLaunchKernelGGL(k_grad_update, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, noise_pos,
-                     grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio, grad_m, adver);
+  if (!noise_pos && half <= FB_GRAD_LDS_PAIRS) shm += sizeof(float) * 256 * (size_t)half;
+  if (2 * half <= 128)
+    hipLaunchKernelGGL(k_grad_update<true>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, noise_pos,
+                       grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio, grad_m, adver, ctl);
+  else
+    hipLaunchKernelGGL(k_grad_update<false>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, noise_pos,
+                       grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio, grad_m, adver, ctl);
 }
