@@ -91,7 +91,7 @@ struct fb_engine {
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
   int n_out = 0;  // columns of `raw`: models (GMM) or enrolled speakers (i-vector)
   FbIvDev iv;
-  DevBuf iv_fg, iv_tri, iv_sim, iv_u, iv_backend;
+  DevBuf iv_fg, iv_fg64, iv_tri, iv_sim, iv_u, iv_backend;
   DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_linv, iv_ivec, iv_fail, iv_active, iv_bws, iv_pairs, iv_llf;
   int iv_kchunks = 96;
   int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
@@ -152,7 +152,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
-                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_tri,
+                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
                     &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
@@ -803,6 +803,7 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
   if (C <= 0 || D <= 0 || R <= 0 || L <= 0 || S <= 0) return fb_fail(FB_E_ARG, "bad i-vector system shape");
   if (!e->have_fe || e->fe.dim != D) return fb_fail(FB_E_ARG, "UBM dim %d != front-end feature dim %d", D, e->have_fe ? e->fe.dim : -1);
   if (R > 512 || L > 512 || D > 80 || D > 255) return fb_fail(FB_E_ARG, "unsupported sizes R=%d L=%d D=%d (R,L <= 512, D <= 80)", R, L, D);
+  if (C > 4096) return fb_fail(FB_E_LIMIT, "at most 4096 Gaussians in the i-vector UBM (got %d)", C);
   if (S > 60) return fb_fail(FB_E_ARG, "at most 60 enrolled speakers per engine");
   if (task == FB_TASK_SV && S != 1) return fb_fail(FB_E_ARG, "SV takes exactly one enrolled speaker");
   if (sy->num_gselect <= 0 || sy->num_gselect > 64 || sy->num_gselect > C) return fb_fail(FB_E_ARG, "num_gselect must be in [1, min(64, C)]");
@@ -866,6 +867,21 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
     FBCHK(e->iv_tri.ensure(tr.size()));
     HIPCHK(hipMemcpy(e->iv_tri.p, tr.data(), tr.size(), hipMemcpyHostToDevice));
     e->iv.fg_gconsts = base; e->iv.fg_mic = base + n_gc; e->iv.fg_P = base + n_gc + n_mic;
+    {  // float64 image of the same numbers for the register-blocked full-covariance kernel
+      const size_t stride = (size_t)triD + D + 1;
+      std::vector<double> f64((size_t)C * stride);
+      for (int c = 0; c < C; ++c) {
+        double *o = &f64[(size_t)c * stride];
+        const float *P = sy->fg_inv_covars + (size_t)c * triD;
+        for (int r = 0, idx = 0; r < D; ++r)
+          for (int cc = 0; cc <= r; ++cc, ++idx) o[idx] = (cc == r) ? 0.5 * (double)P[idx] : (double)P[idx];
+        for (int d = 0; d < D; ++d) o[triD + d] = (double)sy->fg_means_invcovars[(size_t)c * D + d];
+        o[triD + D] = (double)fg_gc[c];
+      }
+      FBCHK(e->iv_fg64.ensure(sizeof(double) * f64.size()));
+      HIPCHK(hipMemcpy(e->iv_fg64.p, f64.data(), sizeof(double) * f64.size(), hipMemcpyHostToDevice));
+      e->iv.fg64 = e->iv_fg64.as<double>();
+    }
     e->iv.tri_r = e->iv_tri.as<unsigned char>(); e->iv.tri_c = e->iv.tri_r + triD;
   }
   // ---- extractor: Sigma^-1 M and U derived on the device (IvectorExtractor::ComputeDerivedVars)

@@ -76,42 +76,76 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 // Values are independent of the (atomic) bucket order: each pair writes its own output slot.
 #define FB_IV_CH 128  // bucket entries per workgroup
 
+// wave = frame, every lane keeps Cpad/64 of the frame's values in REGISTERS (component lane + 64 j) with
+// their running maximum; a round = wave arg-max of the 64 lane maxima by DPP (no LDS, no bpermute),
+// then only the owning lane removes the winner and rescans its registers.  Order: descending by
+// (value, index) like std::greater<pair<float,int>> (gmm-gselect).
+template <int NJ>
 __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
                                                    const int *__restrict__ n_rows_ptr, int *__restrict__ sel,
                                                    int *__restrict__ hist) {
-  extern __shared__ __attribute__((aligned(16))) float smf[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n_rows = *n_rows_ptr;
   const int row = blockIdx.x * 4 + w;
-  if (row >= n_rows) return;  // whole wave exits; no block-level barriers below
-  const int Cpad = iv.Cpad, nsel = iv.nsel;
-  float *vals = smf + (size_t)w * Cpad;
-  const float *lr = ll + (size_t)row * Cpad;
-  for (int i = lane; i < Cpad; i += 64) vals[i] = (i < iv.C) ? lr[i] : -FLT_MAX;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // top-nsel, descending by (value, index) like std::greater<pair<float,int>>
-  int my_k = -1;  // lane j < nsel keeps the j-th selected component
-  for (int s = 0; s < nsel; ++s) {
-    float bv = -FLT_MAX;
-    int bi = -1;
-    for (int i = lane; i < Cpad; i += 64) {
-      const float v = vals[i];
-      if (v > bv || (v == bv && i > bi)) { bv = v; bi = i; }
-    }
+  if (row >= n_rows) return;
+  const int nsel = iv.nsel;
+  const float *lr = ll + (size_t)row * iv.Cpad;
+  float v[NJ];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == s) my_k = bi;
-    if (lane == 0 && bi >= 0) vals[bi] = -FLT_MAX;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = (i < iv.C) ? lr[min(i, iv.Cpad - 1)] : -FLT_MAX;
   }
+  // per-lane candidates: the three best of the lane's registers, refilled (rarely) by a rescan
+  float t0v, t1v, t2v;
+  int t0j, t1j, t2j;
+#define FB_TOP3()                                                                                  \
+  {                                                                                                \
+    t0v = t1v = t2v = -FLT_MAX;                                                                    \
+    t0j = t1j = t2j = -1;                                                                          \
+    _Pragma("unroll") for (int j = NJ - 1; j >= 0; --j) { /* descending index + strict '>': ties keep the larger index */ \
+      const float x = v[j];                                                                        \
+      const bool g0 = x > t0v, g1 = x > t1v, g2 = x > t2v;                                         \
+      t2v = g1 ? t1v : (g2 ? x : t2v); t2j = g1 ? t1j : (g2 ? j : t2j);                            \
+      t1v = g0 ? t0v : (g1 ? x : t1v); t1j = g0 ? t0j : (g1 ? j : t1j);                            \
+      t0v = g0 ? x : t0v; t0j = g0 ? j : t0j;                                                      \
+    }                                                                                              \
+  }
+  FB_TOP3()
+  int my_k = -1;  // lane s < nsel keeps the s-th selected component
+  for (int s = 0; s < nsel; ++s) {
+    float bv = t0v;
+    int bi = lane + 64 * (t0j < 0 ? 0 : t0j);
+#define FB_ARGMAX_STEP(CTRL, RM)                                                              \
+    {                                                                                         \
+      const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv), __float_as_int(bv), CTRL, RM, 0xf, false)); \
+      const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, RM, 0xf, false);               \
+      if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }                             \
+    }
+    FB_ARGMAX_STEP(0xb1, 0xf)   // quad_perm [1,0,3,2]
+    FB_ARGMAX_STEP(0x4e, 0xf)   // quad_perm [2,3,0,1]
+    FB_ARGMAX_STEP(0x141, 0xf)  // row_half_mirror
+    FB_ARGMAX_STEP(0x140, 0xf)  // row_mirror
+    FB_ARGMAX_STEP(0x142, 0xa)  // row_bcast15
+    FB_ARGMAX_STEP(0x143, 0xc)  // row_bcast31
+#undef FB_ARGMAX_STEP
+    // (fewer than nsel components: the remaining slots stay -1, as with an exhausted heap)
+    const bool none = __builtin_amdgcn_readlane(__float_as_int(bv), 63) == __float_as_int(-FLT_MAX);
+    const int win = none ? -1 : __builtin_amdgcn_readlane(bi, 63);
+    if (lane == s) my_k = win;
+    bool refill = false;
+    if (!none && (win & 63) == lane) {  // the owner hands its best candidate out (and forgets the value)
+      const int wj = win >> 6;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) v[j] = (j == wj) ? -FLT_MAX : v[j];
+      t0v = t1v; t0j = t1j; t1v = t2v; t1j = t2j; t2v = -FLT_MAX; t2j = -1;
+      refill = t0j < 0;  // candidates exhausted: look at the registers again
+    }
+    if (__any(refill)) {
+      if (refill) FB_TOP3()
+    }
+  }
+#undef FB_TOP3
   if (lane < nsel) {
     sel[(size_t)row * nsel + lane] = my_k;
     if (my_k >= 0 && my_k < iv.C) atomicAdd(&hist[my_k], 1);
@@ -219,6 +253,82 @@ __global__ __launch_bounds__(256) void k_iv_fullcov(FbIvDev iv, const float *__r
   }
 }
 
+// Same numbers, D known at compile time: thread = (frame, slot) pair of the component's bucket, the
+// frame in registers (float64), and the component's packed precision matrix / linear term read through
+// wave-uniform addresses, i.e. scalar loads feeding v_fma_f64 as SGPR operands -- no LDS, no cross-lane
+// reduction.   1/2 x'Px = sum_r x_r (sum_{c<r} P_rc x_c + 1/2 P_rr x_r): D(D+1)/2 + D fma per pair.
+template <int D>
+__global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const float *__restrict__ feats,
+                                                           const int *__restrict__ bstart,
+                                                           const int *__restrict__ wstart,
+                                                           const int *__restrict__ pairs, float *__restrict__ llf) {
+  const int n_work = wstart[iv.C];
+  const int wi = blockIdx.x;
+  if (wi >= n_work) return;
+  int lo = 0, hi = iv.C;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (wstart[mid] <= wi) lo = mid; else hi = mid;
+  }
+  const int k = __builtin_amdgcn_readfirstlane(lo);
+  constexpr int TRI = D * (D + 1) / 2;
+  const int e0 = bstart[k] + (wi - wstart[k]) * FB_IV_CH;
+  const int e1 = min(bstart[k + 1], e0 + FB_IV_CH);
+  const int e = e0 + (int)threadIdx.x;
+  const bool ok = e < e1;
+  const int pr = pairs[ok ? e : e0];
+  const int row = pr / iv.nsel;
+  double x[D];
+  {
+    const float4 *fr = reinterpret_cast<const float4 *>(feats + (size_t)row * D);  // D % 4 == 0
+#pragma unroll
+    for (int q = 0; q < D / 4; ++q) {
+      const float4 v = fr[q];
+      x[4 * q] = (double)v.x; x[4 * q + 1] = (double)v.y; x[4 * q + 2] = (double)v.z; x[4 * q + 3] = (double)v.w;
+    }
+  }
+  const double *Pk = iv.fg64 + (size_t)k * (TRI + D + 1);  // uniform -> s_load
+  // the packed triangle is walked in chunks of 16 entries (two s_load_dwordx16): the next chunk is
+  // requested before the current one is consumed and a scheduling barrier keeps the compiler from
+  // hoisting more loads than the scalar register file holds
+  // The packed triangle is walked in chunks of 16 entries (two s_load_dwordx16 through inline asm, so
+  // the compiler can neither merge nor hoist them -- left to itself it requests the whole matrix up
+  // front and spills the scalar register file): chunk j+1 is requested, chunk j is consumed, then one
+  // s_waitcnt lgkmcnt(0) (scalar loads return out of order, there is no partial wait).
+  typedef double fb_d8 __attribute__((ext_vector_type(8)));
+  fb_d8 c0, c1, n0, n1;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=s"(c0), "=s"(c1) : "s"(Pk) : "memory");
+  double half_quad = 0.0;
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      const int idx = r * (r + 1) / 2 + c;  // compile-time after unrolling
+      if ((idx & 15) == 0) {                // chunk boundary
+        if (idx > 0) {
+          // every fma of the finished chunk feeds one of these three values and every later one starts
+          // from them: routing them through an (empty) asm pins the chunk between the two loads
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(n1), "+v"(a0), "+v"(a1), "+v"(half_quad));
+          c0 = n0; c1 = n1;
+        }
+        if (idx + 16 < TRI) {  // request the next chunk (the record is padded, see fb_load_ivector)
+          const double *nx = Pk + idx + 16;
+          asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(n0), "=s"(n1) : "s"(nx) : "memory");
+        }
+      }
+      const double pv = (idx & 8) ? c1[idx & 7] : c0[idx & 7];
+      if (c & 1) a1 = fma(pv, x[c], a1); else a0 = fma(pv, x[c], a0);
+    }
+    half_quad = fma(x[r], a0 + a1, half_quad);
+  }
+  double lin = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) lin = fma(Pk[TRI + d], x[d], lin);
+  if (ok) llf[pr] = (float)(Pk[TRI + D] + (lin - half_quad));
+}
+
 // softmax over the nsel full-covariance log-likelihoods of a frame + min-post pruning: lane = slot
 __global__ __launch_bounds__(256) void k_iv_post(FbIvDev iv, const int *__restrict__ n_rows_ptr,
                                                  const int *__restrict__ sel, const float *__restrict__ llf,
@@ -263,14 +373,23 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   const int C = iv.C;
   int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *cursor = wstart + (C + 1);
   (void)hipMemsetAsync(hist, 0, sizeof(int) * C, s);
-  hipLaunchKernelGGL(k_iv_select, dim3((rows_cap + 3) / 4), dim3(256), sizeof(float) * 4 * (size_t)iv.Cpad, s, iv,
-                     ll, n_rows_ptr, sel, hist);
+  {
+    const dim3 grid((rows_cap + 3) / 4), blk(256);
+    const int nj = (iv.Cpad + 63) / 64;
+    if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
+    else if (nj <= 8) hipLaunchKernelGGL(k_iv_select<8>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
+    else if (nj <= 16) hipLaunchKernelGGL(k_iv_select<16>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
+    else if (nj <= 32) hipLaunchKernelGGL(k_iv_select<32>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
+    else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);  // C <= 4096 (fb_load_ivector)
+  }
   hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, cursor);
   const int n_pairs_cap = rows_cap * iv.nsel;
   hipLaunchKernelGGL(k_iv_bucket_fill, dim3((n_pairs_cap + 255) / 256), dim3(256), 0, s, iv, n_rows_ptr, sel, bstart,
                      cursor, pairs);
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
-  if (iv.triD <= 42 * 64)
+  if (iv.D == 72)
+    hipLaunchKernelGGL((k_iv_fullcov_t<72>), dim3(work_cap), dim3(FB_IV_CH), 0, s, iv, feats, bstart, wstart, pairs, llf);
+  else if (iv.triD <= 42 * 64)
     hipLaunchKernelGGL((k_iv_fullcov<42>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);
   else
     hipLaunchKernelGGL((k_iv_fullcov<52>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);
