@@ -522,6 +522,21 @@ static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   return (g.n_tiles + tpc - 1) / tpc;
 }
 
+// FB_DEBUG_SYNC=1: synchronise after every stage and report it on stderr (fault localisation)
+static bool fb_debug_sync_on() {
+  static int v = -1;
+  if (v < 0) { const char *ev = getenv("FB_DEBUG_SYNC"); v = (ev && atoi(ev) != 0) ? 1 : 0; }
+  return v == 1;
+}
+#define FB_DBG_SYNC(e, what)                                                                        \
+  do {                                                                                              \
+    if (fb_debug_sync_on()) {                                                                       \
+      hipError_t err_ = hipStreamSynchronize((e)->stream);                                          \
+      fprintf(stderr, "[fb] %s: %s\n", what, hipGetErrorString(err_));                               \
+      fflush(stderr);                                                                               \
+    }                                                                                               \
+  } while (0)
+
 // HIP-event timing of the dominant kernel (bench only): a ring of event pairs, because several
 // iterations may be queued before the host looks at the stream again
 static int time_collect(fb_engine *e) {
@@ -630,22 +645,29 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(e->iv_fail.ensure(sizeof(int)));
     FBCHK(e->iv_active.ensure(sizeof(int) * (size_t)(iv.C + 1)));
     HIPCHK(hipMemsetAsync(e->iv_fail.p, 0, sizeof(int), s));
+    FB_DBG_SYNC(e, "front-end");
     fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                        e->iv_ll.as<float>());
+    FB_DBG_SYNC(e, "gmm_dump");
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
                              e->iv_pairs.as<int>(), e->iv_llf.as<float>());
+    FB_DBG_SYNC(e, "select_post");
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_sel.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
+    FB_DBG_SYNC(e, "stats");
     // bench timing of the T-matrix contraction (k_iv_lin + k_iv_quad): the HBM-streaming kernels
     FBCHK(time_begin(e));
     fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
                           e->iv_active.as<int>(), e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(),
                           e->iv_quad.as<double>());
     FBCHK(time_end(e));
+    FB_DBG_SYNC(e, "contract");
     fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
                        e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    FB_DBG_SYNC(e, "solve");
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
+    FB_DBG_SYNC(e, "backend");
   }
   HIPCHK(hipGetLastError());
   e->last_total_frames = total_frames;
@@ -1035,9 +1057,12 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
 // a time; the host reads the control block once per batch.  reset: start a new attack (lr = max_lr,
 // empty loss history); otherwise continue the previous state (bench warm-up -> timed region).
 // trace_dev rows are indexed from it_base.
-static int attack_batch_size() {
+static int attack_batch_size(const fb_engine *e) {
+  // Iterations queued per host round trip.  Beyond ~4 the host is off the critical path anyway, and
+  // every iteration queued behind the stopping one is (cheap, but not free) wasted work.
+  (void)e;
   const char *ev = getenv("FB_ATTACK_BATCH");
-  int k = ev ? atoi(ev) : 8;
+  int k = ev ? atoi(ev) : 4;
   return k < 1 ? 1 : (k > 16 ? 16 : k);
 }
 static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, const double *noise_all, int it_base,
@@ -1058,7 +1083,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     HIPCHK(hipStreamSynchronize(e->stream));  // h_ctl is reused for the read-back below
   }
   const double one_minus_m = 1.0 - p->momentum;
-  const int K = attack_batch_size();
+  const int K = attack_batch_size(e);
   int done = 0;
   while (done < count) {
     const int nb = count - done < K ? count - done : K;
@@ -1070,7 +1095,9 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
                               hipMemcpyHostToDevice, e->stream));
         noise_dev = e->noise.as<double>();
       }
+      if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
       FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base));
+      FB_DBG_SYNC(e, "loss");
       fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
                             nullptr, 1, p->momentum, one_minus_m, 0.0, p->epsilon, e->audio.as<double>(),
                             e->grad_m.as<double>(), e->adver.as<double>(), ctl);

@@ -294,11 +294,12 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const flo
   // The packed triangle is walked in chunks of 16 entries (two s_load_dwordx16 through inline asm, so
   // the compiler can neither merge nor hoist them -- left to itself it requests the whole matrix up
   // front and spills the scalar register file): chunk j+1 is requested, chunk j is consumed, then one
-  // s_waitcnt lgkmcnt(0) (scalar loads return out of order, there is no partial wait).
+  // s_waitcnt lgkmcnt(0) (scalar loads return out of order, there is no partial wait).  The outputs are
+  // early-clobber: the first load may land before the second one has read its address registers.
   typedef double fb_d8 __attribute__((ext_vector_type(8)));
   fb_d8 c0, c1, n0, n1;
   asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-               : "=s"(c0), "=s"(c1) : "s"(Pk) : "memory");
+               : "=&s"(c0), "=&s"(c1) : "s"(Pk) : "memory");
   double half_quad = 0.0;
 #pragma unroll
   for (int r = 0; r < D; ++r) {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const flo
         }
         if (idx + 16 < TRI) {  // request the next chunk (the record is padded, see fb_load_ivector)
           const double *nx = Pk + idx + 16;
-          asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(n0), "=s"(n1) : "s"(nx) : "memory");
+          asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(n0), "=&s"(n1) : "s"(nx) : "memory");
         }
       }
       const double pv = (idx & 8) ? c1[idx & 7] : c0[idx & 7];
@@ -524,7 +525,9 @@ __global__ __launch_bounds__(512) void k_iv_lin(FbIvDev iv, const double *__rest
     }
   }
   const int nb = min(FB_IV_BT, B - b0);
-  for (int bb = 0; bb < nb; ++bb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
+#pragma unroll  // (a runtime trip count would index acc[] dynamically and push it to scratch memory)
+  for (int bb = 0; bb < FB_IV_BT; ++bb)
+    if (bb < nb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
 }
 // quad[b][e] = sum_k gamma[b][k] U[k][e]; thread = one packed element e
 __global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__restrict__ gammaT,
@@ -548,7 +551,9 @@ __global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__res
     for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(gr[bb], uv, acc[bb]);
   }
   const int nb = min(FB_IV_BT, B - b0);
-  for (int bb = 0; bb < nb; ++bb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
+#pragma unroll
+  for (int bb = 0; bb < FB_IV_BT; ++bb)
+    if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
 }
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *active, int *n_active, double *linp, double *quad) {
@@ -575,7 +580,7 @@ __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(1024) void k_iv_solve(FbIvDev iv, const double *__restrict__ quad,
+__global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__restrict__ quad,
                                                    const double *__restrict__ linp, int n_kchunks, int B,
                                                    double *__restrict__ Aall, double *__restrict__ LinvAll,
                                                    double *__restrict__ ivec, int *__restrict__ fail) {
@@ -776,7 +781,7 @@ void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(1024), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
+  hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(512), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
 }
 
 // ------------------------------------------------------ back-end (K11/K12)
