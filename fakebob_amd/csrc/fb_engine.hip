@@ -623,7 +623,11 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(e->iv_ll.ensure(sizeof(float) * (size_t)total_frames * iv.Cpad));
     FBCHK(e->iv_sel.ensure(sizeof(int) * (size_t)total_frames * iv.nsel));
     FBCHK(e->iv_post.ensure(sizeof(float) * (size_t)total_frames * iv.nsel));
-    FBCHK(e->iv_bws.ensure(sizeof(int) * (size_t)(4 * iv.C + 8)));
+    {
+      const size_t cap = e->iv_bws.cap;
+      FBCHK(e->iv_bws.ensure(sizeof(int) * (fb_iv_bucket_ws_ints(iv, total_frames) + 8)));
+      if (e->iv_bws.cap != cap) HIPCHK(hipMemsetAsync(e->iv_bws.p, 0, e->iv_bws.cap, s));  // flags start clean
+    }
     FBCHK(e->iv_pairs.ensure(sizeof(int) * (size_t)total_frames * iv.nsel));
     FBCHK(e->iv_llf.ensure(sizeof(float) * (size_t)total_frames * iv.nsel));
     const int Bpad = (B + 31) / 32 * 32;
@@ -653,14 +657,14 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
                              e->iv_pairs.as<int>(), e->iv_llf.as<float>());
     FB_DBG_SYNC(e, "select_post");
-    fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_sel.as<int>(),
+    fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
     FB_DBG_SYNC(e, "stats");
     // bench timing of the T-matrix contraction (k_iv_lin + k_iv_quad): the HBM-streaming kernels
     FBCHK(time_begin(e));
     fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
-                          e->iv_active.as<int>(), e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(),
-                          e->iv_quad.as<double>());
+                          e->iv_bws.as<int>() + 3 * (size_t)iv.C + 2, e->iv_active.as<int>(),
+                          e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(), e->iv_quad.as<double>());
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
     fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
@@ -945,6 +949,8 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
     e->iv.mean_vec = b + o_mean; e->iv.ldaT = b + o_lda; e->iv.plda_mean = b + o_pm; e->iv.pldaT = b + o_pt;
     e->iv.plda_psi = b + o_psi; e->iv.train = b + o_tr;
   }
+  // the bucket workspace is laid out by C: a different system must not inherit stale `flags`
+  if (e->iv_bws.p) HIPCHK(hipMemset(e->iv_bws.p, 0, e->iv_bws.cap));
   FbIvDev &iv = e->iv;
   iv.C = C; iv.Cpad = e->gmm.n_tiles * 32; iv.D = D; iv.R = R; iv.L = L; iv.S = S; iv.lda_cols = sy->lda_cols;
   iv.nsel = sy->num_gselect; iv.triD = triD; iv.triR = triR; iv.min_post = (float)sy->min_post;

@@ -141,15 +141,17 @@ struct FbIvDev {
 };
 void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, const double *sinv_packed,
                          double *sim, double *u);
-// bucket_ws: 4*C + 2 ints of workspace; pairs / llf: rows_cap * nsel entries
+// bucket_ws: fb_iv_bucket_ws_ints() ints of workspace, zero before the first use; pairs / llf: rows_cap * nsel
+size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap);
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
                               int *pairs, float *llf);
 // gammaT [C][Bpad], XT [C*D][Bpad]: utterance-minor, zero-padded to Bpad (multiple of 32)
-void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *sel,
-                        const float *post, int B, int Bpad, double *gammaT, double *XT);
+void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
+                        const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
-                           int Bpad, int n_kchunks, int *active, int *n_active, double *linp, double *quad);
+                           int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
+                           double *quad);
 void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                         int B, double *Aall, double *LinvAll, double *ivec, int *fail);
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr);

@@ -82,8 +82,7 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 // (value, index) like std::greater<pair<float,int>> (gmm-gselect).
 template <int NJ>
 __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
-                                                   const int *__restrict__ n_rows_ptr, int *__restrict__ sel,
-                                                   int *__restrict__ hist) {
+                                                   const int *__restrict__ n_rows_ptr, int *__restrict__ sel) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n_rows = *n_rows_ptr;
   const int row = blockIdx.x * 4 + w;
@@ -146,17 +145,51 @@ __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__re
     }
   }
 #undef FB_TOP3
-  if (lane < nsel) {
-    sel[(size_t)row * nsel + lane] = my_k;
-    if (my_k >= 0 && my_k < iv.C) atomicAdd(&hist[my_k], 1);
-  }
+  if (lane < nsel) sel[(size_t)row * nsel + lane] = my_k;
 }
 
-// bstart[C+1] = exclusive scan of hist; wstart[C+1] = exclusive scan of ceil(hist/CH); cursor = 0
-__global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, const int *__restrict__ hist,
-                                                         int *__restrict__ bstart, int *__restrict__ wstart,
-                                                         int *__restrict__ cursor) {
+// Stable partition of the (frame, slot) pairs by component -- a counting sort without global atomics:
+//   k_iv_bucket_count  block = FB_IV_FB consecutive frames: per-component counts of the block (LDS)
+//   k_iv_bucket_scan   per component: exclusive scan over the blocks (-> the block's first slot in the
+//                      bucket); totals -> bstart / wstart
+//   k_iv_bucket_fill   block = the same frames, walked in order by one wave: pairs[] ends up sorted by
+//                      (component, frame), i.e. utterance-major and in time order inside every bucket --
+//                      which is what lets k_iv_stats accumulate deterministically straight from the buckets.
+#define FB_IV_FB 64  // frames per partition block
+__global__ __launch_bounds__(256) void k_iv_bucket_count(FbIvDev iv, const int *__restrict__ n_rows_ptr,
+                                                         const int *__restrict__ sel, int *__restrict__ cnt) {
+  extern __shared__ int s_cnt[];  // [Cpad]
+  const int Cpad = iv.Cpad, nsel = iv.nsel, n_rows = *n_rows_ptr;
+  for (int i = threadIdx.x; i < Cpad; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  const int r0 = blockIdx.x * FB_IV_FB, r1 = min(n_rows, r0 + FB_IV_FB);
+  for (int e = r0 * nsel + (int)threadIdx.x; e < r1 * nsel; e += 256) {
+    const int k = sel[e];
+    if (k >= 0 && k < iv.C) atomicAdd(&s_cnt[k], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cpad; i += 256) cnt[(size_t)blockIdx.x * Cpad + i] = s_cnt[i];
+}
+// cnt[blk][k] -> pref[blk][k] = exclusive prefix over blk, hist[k] = total; then bstart[C+1] = exclusive scan of
+// hist and wstart[C+1] = exclusive scan of ceil(hist / FB_IV_CH).  Single workgroup.
+__global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, int Cpad, int n_blk, const int *__restrict__ cnt,
+                                                         int *__restrict__ pref, int *__restrict__ hist,
+                                                         int *__restrict__ bstart, int *__restrict__ wstart) {
   __shared__ int sa[1024], sb[1024];
+  for (int k = threadIdx.x; k < C; k += 1024) {  // coalesced over k for every block; loads 8 blocks ahead
+    int run = 0;
+    int j = 0;
+    for (; j + 8 <= n_blk; j += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = cnt[(size_t)(j + u) * Cpad + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { pref[(size_t)(j + u) * Cpad + k] = run; run += v[u]; }
+    }
+    for (; j < n_blk; ++j) { pref[(size_t)j * Cpad + k] = run; run += cnt[(size_t)j * Cpad + k]; }
+    hist[k] = run;
+  }
+  __syncthreads();
   const int per = (C + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(C, lo + per);
   int a = 0, bsum = 0;
@@ -164,32 +197,54 @@ __global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, const int *__res
   sa[threadIdx.x] = a;
   sb[threadIdx.x] = bsum;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int ra = 0, rb = 0;
-    for (int i = 0; i < 1024; ++i) { const int va = sa[i], vb = sb[i]; sa[i] = ra; sb[i] = rb; ra += va; rb += vb; }
-    bstart[C] = ra;
-    wstart[C] = rb;
+  // exclusive scan of the 1024 partials: wave scans by shuffles + 16 wave totals
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int ia = a, ib = bsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64);
+    if (lane >= o) { ia += ua; ib += ub; }
   }
   __syncthreads();
-  int ra = sa[threadIdx.x], rb = sb[threadIdx.x];
+  if (lane == 63) { sa[w] = ia; sb[w] = ib; }
+  __syncthreads();
+  int ra = ia - a, rb = ib - bsum;
+  for (int i = 0; i < w; ++i) { ra += sa[i]; rb += sb[i]; }
+  if (threadIdx.x == 1023) { bstart[C] = ra + a; wstart[C] = rb + bsum; }
   for (int k = lo; k < hi; ++k) {
     bstart[k] = ra;
     wstart[k] = rb;
-    cursor[k] = 0;
     ra += hist[k];
     rb += (hist[k] + FB_IV_CH - 1) / FB_IV_CH;
   }
 }
-
-__global__ __launch_bounds__(256) void k_iv_bucket_fill(FbIvDev iv, const int *__restrict__ n_rows_ptr,
-                                                        const int *__restrict__ sel, const int *__restrict__ bstart,
-                                                        int *__restrict__ cursor, int *__restrict__ pairs) {
-  const int n = *n_rows_ptr * iv.nsel;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int k = sel[i];
-  if (k < 0 || k >= iv.C) return;
-  pairs[bstart[k] + atomicAdd(&cursor[k], 1)] = i;
+// one wave per partition block; frames in order, the slots of a frame in parallel (their components are
+// distinct, so the LDS counters are conflict-free)
+__global__ __launch_bounds__(64) void k_iv_bucket_fill(FbIvDev iv, const int *__restrict__ n_rows_ptr,
+                                                       const int *__restrict__ sel, const int *__restrict__ cnt,
+                                                       const int *__restrict__ bstart, int *__restrict__ pairs) {
+  extern __shared__ int s_pos[];  // [Cpad] next free slot of every bucket for this block
+  const int Cpad = iv.Cpad, nsel = iv.nsel, n_rows = *n_rows_ptr, lane = threadIdx.x;
+  const int r0 = blockIdx.x * FB_IV_FB, r1 = min(n_rows, r0 + FB_IV_FB);
+  if (r0 >= r1) return;
+  for (int i = lane; i < iv.C; i += 64) s_pos[i] = bstart[i] + cnt[(size_t)blockIdx.x * Cpad + i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int r = r0; r < r1; ++r) {
+    if (lane < nsel) {
+      const int e = r * nsel + lane;
+      const int k = sel[e];
+      if (k >= 0 && k < iv.C) {
+        const int p = s_pos[k];
+        s_pos[k] = p + 1;
+        pairs[p] = e;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // TRI64 = ceil(D(D+1)/2 / 64): 42 for D = 72 (the recipe), 52 covers D <= 80
@@ -367,26 +422,33 @@ __global__ __launch_bounds__(256) void k_iv_post(FbIvDev iv, const int *__restri
   if (lane < nsel) post[(size_t)row * nsel + lane] = p;
 }
 
+// bucket_ws (ints): hist[C], bstart[C+1], wstart[C+1], flags[C] (zero on entry, see k_iv_active),
+// cnt[n_blk][Cpad], pref[n_blk][Cpad] with n_blk = ceil(rows_cap / FB_IV_FB)
+size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
+  return (size_t)4 * iv.C + 2 + (size_t)2 * ((rows_cap + FB_IV_FB - 1) / FB_IV_FB) * iv.Cpad;
+}
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
                               int *pairs, float *llf) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
-  int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *cursor = wstart + (C + 1);
-  (void)hipMemsetAsync(hist, 0, sizeof(int) * C, s);
+  int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *cnt = wstart + (C + 1) + C;
+  const int n_blk = (rows_cap + FB_IV_FB - 1) / FB_IV_FB;
+  int *pref = cnt + (size_t)n_blk * iv.Cpad;
   {
     const dim3 grid((rows_cap + 3) / 4), blk(256);
     const int nj = (iv.Cpad + 63) / 64;
-    if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
-    else if (nj <= 8) hipLaunchKernelGGL(k_iv_select<8>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
-    else if (nj <= 16) hipLaunchKernelGGL(k_iv_select<16>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
-    else if (nj <= 32) hipLaunchKernelGGL(k_iv_select<32>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);
-    else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, hist);  // C <= 4096 (fb_load_ivector)
+    if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
+    else if (nj <= 8) hipLaunchKernelGGL(k_iv_select<8>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
+    else if (nj <= 16) hipLaunchKernelGGL(k_iv_select<16>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
+    else if (nj <= 32) hipLaunchKernelGGL(k_iv_select<32>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
+    else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);  // C <= 4096 (fb_load_ivector)
   }
-  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, cursor);
+  const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
+  hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
+  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist, bstart, wstart);
+  hipLaunchKernelGGL(k_iv_bucket_fill, dim3(n_blk), dim3(64), lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
   const int n_pairs_cap = rows_cap * iv.nsel;
-  hipLaunchKernelGGL(k_iv_bucket_fill, dim3((n_pairs_cap + 255) / 256), dim3(256), 0, s, iv, n_rows_ptr, sel, bstart,
-                     cursor, pairs);
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
   if (iv.D == 72)
     hipLaunchKernelGGL((k_iv_fullcov_t<72>), dim3(work_cap), dim3(FB_IV_CH), 0, s, iv, feats, bstart, wstart, pairs, llf);
@@ -398,68 +460,93 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
 }
 
 // ------------------------------------------------------- statistics (K10a)
-// grid (B, C/64): thread (c = tid&63, dg = tid>>6) owns component k0+c and feature dims dg, dg+4, ...
-#define FB_IV_DMAX4 20  // D <= 80
-__global__ __launch_bounds__(256) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
-                                                  const int *__restrict__ row_off, const int *__restrict__ sel,
-                                                  const float *__restrict__ post, int Bpad,
-                                                  double *__restrict__ gammaT, double *__restrict__ XT) {
-  extern __shared__ __attribute__((aligned(16))) float smf[];
-  const int b = blockIdx.x, k0 = blockIdx.y * 64;
-  const int D = iv.D, nsel = iv.nsel;
-  float *Pd = smf;           // [64 rows][64 comps]
-  float *F = smf + 64 * 64;  // [64 rows][D]
-  const int r0 = row_off[b], r1 = row_off[b + 1];
-  const int c = threadIdx.x & 63, dg = threadIdx.x >> 6;
-  double acc[FB_IV_DMAX4];
-#pragma unroll
-  for (int i = 0; i < FB_IV_DMAX4; ++i) acc[i] = 0.0;
-  double gam = 0.0;
-  for (int rb = r0; rb < r1; rb += 64) {
-    const int nr = min(64, r1 - rb);
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) Pd[i] = 0.0f;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nr * nsel; e += 256) {
-      const int rl = e / nsel;
-      const size_t o = (size_t)(rb + rl) * nsel + (e - rl * nsel);
-      const float p = post[o];
-      const int k = sel[o] - k0;
-      if (p != 0.0f && k >= 0 && k < 64) Pd[rl * 64 + k] = p;
+// gamma[b][k] = sum_t post, X[b][k][:] = sum_t post * x_t, accumulated straight from the component's bucket:
+// the stable partition left its (frame, slot) pairs in (utterance, time) order, so the pairs of one
+// (component, utterance) are a contiguous run.  Workgroup = component (B + 1 parallel binary searches give
+// the runs), wave = utterance (16 at a time): the wave adds the frames of its run in order -- lane d owns
+// dimension d (and d + 64), float64, the same operations in the same order as a frame-major loop -- with
+// the feature rows of the next 16 pairs in flight.  Only the ~15 % of the Gaussians that were selected at all cost
+// anything; utterances without a pair of this component get explicit zeros (the contraction reads whole
+// rows of an active component).  flags[k] = 1 when any posterior is non-zero (-> k_iv_active).
+#define FB_IV_SG 16  // feature rows in flight per wave (two register buffers of this size)
+__global__ __launch_bounds__(1024) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
+                                                   const int *__restrict__ row_off, const int *__restrict__ pairs,
+                                                   const int *__restrict__ bstart, const float *__restrict__ post,
+                                                   int B, int Bpad, double *__restrict__ gammaT,
+                                                   double *__restrict__ XT, int *__restrict__ flags) {
+  extern __shared__ int s_seg[];  // [B + 1] first pair of every utterance inside the bucket
+  const int k = blockIdx.x, D = iv.D, nsel = iv.nsel;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int e0 = bstart[k], e1 = bstart[k + 1];
+  if (e0 >= e1) return;
+  // utterance boundaries: thread b does its own binary search (all B + 1 searches in parallel)
+  for (int b = threadIdx.x; b <= B; b += blockDim.x) {
+    const int key = row_off[b] * nsel;
+    int lo = e0, hi = e1;  // first index with pairs[idx] >= key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (pairs[mid] < key) lo = mid + 1; else hi = mid;
     }
-    for (int i = threadIdx.x; i < nr * D; i += 256) F[i] = feats[(size_t)rb * D + i];
-    __syncthreads();
-    for (int rl = 0; rl < nr; ++rl) {
-      const float p = Pd[rl * 64 + c];
-      if (p != 0.0f) {
-        const double wv = (double)p;
-        gam = __dadd_rn(gam, wv);
-        const float *fr = F + rl * D;
+    s_seg[b] = lo;
+  }
+  __syncthreads();
+  const bool two = lane + 64 < D;  // this lane also owns dimension lane + 64 (D <= 128)
+  bool any = false;
+  for (int b = w; b < B; b += nw) {
+    const int s0 = s_seg[b], s1 = s_seg[b + 1];
+    double acc0 = 0.0, acc1 = 0.0, gam = 0.0;
+    for (int c0 = s0; c0 < s1; c0 += 64) {
+      const int n = min(64, s1 - c0);
+      int pr = 0;
+      float p = 0.0f;
+      if (lane < n) { pr = pairs[c0 + lane]; p = post[pr]; }
+      const int rowl = pr / nsel;  // (lanes >= n: p = 0, row 0 -- loads stay in bounds, contributions are skipped)
+      float xa0[FB_IV_SG], xa1[FB_IV_SG], xb0[FB_IV_SG], xb1[FB_IV_SG];
+      auto fetch = [&](int i0, float (&x0)[FB_IV_SG], float (&x1)[FB_IV_SG]) {
 #pragma unroll
-        for (int i = 0; i < FB_IV_DMAX4; ++i) {
-          const int d = dg + 4 * i;
-          if (d < D) acc[i] = __dadd_rn(acc[i], __dmul_rn(wv, (double)fr[d]));
+        for (int u = 0; u < FB_IV_SG; ++u) {
+          const int row = __shfl(rowl, min(i0 + u, 63), 64);
+          const float *fr = feats + (size_t)row * D;
+          x0[u] = lane < D ? fr[lane] : 0.0f;
+          x1[u] = two ? fr[lane + 64] : 0.0f;
+        }
+      };
+      auto add = [&](int i0, const float (&x0)[FB_IV_SG], const float (&x1)[FB_IV_SG]) {
+#pragma unroll
+        for (int u = 0; u < FB_IV_SG; ++u) {
+          const float pv = __shfl(p, min(i0 + u, 63), 64);
+          if (i0 + u < n && pv != 0.0f) {  // wave-uniform
+            const double wv = (double)pv;
+            gam = __dadd_rn(gam, wv);
+            acc0 = __dadd_rn(acc0, __dmul_rn(wv, (double)x0[u]));
+            acc1 = __dadd_rn(acc1, __dmul_rn(wv, (double)x1[u]));
+            any = true;
+          }
+        }
+      };
+      // frames strictly in order; the rows of the next group are requested before the current one is added
+      fetch(0, xa0, xa1);
+      for (int i0 = 0; i0 < n; i0 += 2 * FB_IV_SG) {
+        if (i0 + FB_IV_SG < n) fetch(i0 + FB_IV_SG, xb0, xb1);
+        add(i0, xa0, xa1);
+        if (i0 + FB_IV_SG < n) {
+          if (i0 + 2 * FB_IV_SG < n) fetch(i0 + 2 * FB_IV_SG, xa0, xa1);
+          add(i0 + FB_IV_SG, xb0, xb1);
         }
       }
     }
-    __syncthreads();
+    if (lane < D) XT[((size_t)k * D + lane) * Bpad + b] = acc0;
+    if (two) XT[((size_t)k * D + lane + 64) * Bpad + b] = acc1;
+    if (lane == 0) gammaT[(size_t)k * Bpad + b] = gam;
   }
-  // outputs are utterance-minor ([k][Bpad], [k*D+d][Bpad]) so that the contraction kernels can fetch
-  // the per-utterance coefficients of one row with scalar loads
-  const int k = k0 + c;
-  if (k < iv.C) {
-    if (dg == 0) gammaT[(size_t)k * Bpad + b] = gam;
-#pragma unroll
-    for (int i = 0; i < FB_IV_DMAX4; ++i) {
-      const int d = dg + 4 * i;
-      if (d < D) XT[((size_t)k * D + d) * Bpad + b] = acc[i];
-    }
-  }
+  if (lane == 0 && any) flags[k] = 1;
 }
-void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *sel,
-                        const float *post, int B, int Bpad, double *gammaT, double *XT) {
-  size_t shm = sizeof(float) * (64 * 64 + 64 * (size_t)iv.D);
-  hipLaunchKernelGGL(k_iv_stats, dim3(B, (iv.C + 63) / 64), dim3(256), shm, s, iv, feats, row_off, sel, post, Bpad,
-                     gammaT, XT);
+void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
+                        const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT) {
+  const int *bstart = bucket_ws + iv.C;
+  int *flags = const_cast<int *>(bucket_ws) + 3 * (size_t)iv.C + 2;
+  hipLaunchKernelGGL(k_iv_stats, dim3(iv.C), dim3(1024), sizeof(int) * (size_t)(B + 1), s, iv, feats, row_off, pairs,
+                     bstart, post, B, Bpad, gammaT, XT, flags);
 }
 
 // ---------------------------------------------- T-matrix contraction (K10b)
@@ -467,8 +554,8 @@ void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, co
 // (Kaldi's GetIvectorDistMean skips gamma == 0 as well).  After gselect(20) + min-post pruning only a
 // few hundred of the C Gaussians are touched by a 3-s utterance, and the 51 utterances of an NES batch
 // are noisy copies of one utterance, so the contraction streams only the active rows of Sigma^-1 M / U.
-__global__ __launch_bounds__(1024) void k_iv_active(int C, int Bpad, const double *__restrict__ gammaT,
-                                                    int *__restrict__ active, int *__restrict__ n_active) {
+__global__ __launch_bounds__(1024) void k_iv_active(int C, int *__restrict__ flags, int *__restrict__ active,
+                                                    int *__restrict__ n_active) {
   __shared__ int s_cnt[17];
   __shared__ int s_base;
   if (threadIdx.x == 0) s_base = 0;
@@ -477,10 +564,7 @@ __global__ __launch_bounds__(1024) void k_iv_active(int C, int Bpad, const doubl
   for (int k0 = 0; k0 < C; k0 += 1024) {  // ascending k: deterministic list order
     const int k = k0 + threadIdx.x;
     int any = 0;
-    if (k < C) {
-      const double *g = gammaT + (size_t)k * Bpad;
-      for (int b = 0; b < Bpad; ++b) any |= (g[b] != 0.0);
-    }
+    if (k < C) { any = flags[k]; flags[k] = 0; }  // (k_iv_stats raises them; left clean for the next batch)
     const unsigned long long bal = __ballot(any);
     if (lane == 0) s_cnt[w] = __popcll(bal);
     __syncthreads();
@@ -556,10 +640,11 @@ __global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__res
     if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
 }
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
-                           int Bpad, int n_kchunks, int *active, int *n_active, double *linp, double *quad) {
+                           int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
+                           double *quad) {
   const int threads = (iv.R + 63) / 64 * 64;
   const int btiles = (B + FB_IV_BT - 1) / FB_IV_BT;
-  hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, Bpad, gammaT, active, n_active);
+  hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
   hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, btiles), dim3(threads), 0, s, iv, XT, active, n_active, B, Bpad,
                      n_kchunks, linp);
   hipLaunchKernelGGL(k_iv_quad, dim3((iv.triR + 255) / 256, btiles), dim3(256), 0, s, iv, gammaT, active, n_active,
