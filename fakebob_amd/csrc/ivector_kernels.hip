@@ -659,6 +659,7 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain mat-vec /
 // mat-mat products.  ivec = solution with the prior offset removed from component 0.
 #define FB_IV_NB 32
+typedef double fb_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src);
@@ -679,7 +680,8 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
   double *rhs = smd;                  // [R]
   double *Dg = rhs + ((R + 1) & ~1);  // [NB][LD]  L11
   double *Di = Dg + FB_IV_NB * LD;    // [NB][LD]  L11^-1
-  double *Lp = Di + FB_IV_NB * LD;    // [R+4][LD] panel below the diagonal block
+  constexpr int LDP = FB_IV_NB + 2;   // panel row stride: conflict-free for the MFMA fragment reads
+  double *Lp = Di + FB_IV_NB * LD;    // [R+16][LDP] panel below the diagonal block
   const double *qb = quad + (size_t)b * iv.triR;
   // ---- unpack the lower triangle (+ I): wave w walks rows w, w+nw, ...; lanes walk columns
   for (int r = wv; r < R; r += nw) {
@@ -702,115 +704,169 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
     }
   }
   __syncthreads();
-  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
-    const int nb = min(FB_IV_NB, R - j0);
-    // (a) diagonal block -> LDS (identity beyond nb so the fixed-size register code stays valid)
-    for (int i = tid; i < FB_IV_NB * FB_IV_NB; i += nt) {
-      const int r = i / FB_IV_NB, c = i - r * FB_IV_NB;
-      double v = (r == c) ? 1.0 : 0.0;
-      if (r < nb && c < nb) v = (c <= r) ? A[(size_t)(j0 + r) * R + j0 + c] : 0.0;
-      Dg[r * LD + c] = v;
-    }
-    __syncthreads();
-    if (wv == 0) {
-      // factor: lane r (< 32) holds row r
-      double row[FB_IV_NB];
-      const int rr = lane & 31;
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) row[c] = Dg[rr * LD + c];
-      bool bad = false;
+  // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
+  // registers (lane = row for the factor, lane = column for the inverse; pivots and columns are broadcast
+  // with v_readlane).  Leaves L11 in Dg and in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
+  // fixed-size code valid for a short last block.
+  auto factor_block = [&](int j0, int nb, int pi) {
+    double row[FB_IV_NB];
+    const int rr = lane & 31;
+    {
+      const double *ar = A + (size_t)(j0 + min(rr, nb - 1)) * R + j0;
 #pragma unroll
       for (int c = 0; c < FB_IV_NB; ++c) {
-        const double d = fb_readlane_f64(row[c], c);
-        bad |= !(d > 0.0);
-        const double piv = sqrt(d > 0.0 ? d : 1.0);
-        const double l = (rr == c) ? piv : row[c] / piv;
-        row[c] = (rr >= c) ? l : 0.0;
-#pragma unroll
-        for (int cc = c + 1; cc < FB_IV_NB; ++cc) row[cc] = fma(-l, fb_readlane_f64(l, cc), row[cc]);
+        const double v = ar[min(c, nb - 1)];
+        row[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
       }
-      if (bad && lane == 0) atomicMax(fail, b + 1);
-      if (lane < FB_IV_NB) {
+    }
+    bool bad = false;
+    double rinv_mine = 1.0;  // lane c keeps 1 / L11[c][c]
 #pragma unroll
-        for (int c = 0; c < FB_IV_NB; ++c) Dg[rr * LD + c] = row[c];
+    for (int c = 0; c < FB_IV_NB; ++c) {
+      const double d = fb_readlane_f64(row[c], c);
+      bad |= !(d > 0.0);
+      // 1/sqrt(d) by v_rsq_f64 + two Newton steps (full double precision) instead of a sqrt and 32
+      // divisions on the critical path of the column loop
+      const double dd = d > 0.0 ? d : 1.0;
+      double ri = __builtin_amdgcn_rsq(dd);
+      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+      const double piv = dd * ri;
+      if (rr == c) rinv_mine = ri;
+      const double l = (rr == c) ? piv : row[c] * ri;
+      row[c] = (rr >= c) ? l : 0.0;
+#pragma unroll
+      for (int cc = c + 1; cc < FB_IV_NB; ++cc) row[cc] = fma(-l, fb_readlane_f64(l, cc), row[cc]);
+    }
+    if (bad && lane == 0) atomicMax(fail, b + 1);
+    if (lane < FB_IV_NB) {
+#pragma unroll
+      for (int c = 0; c < FB_IV_NB; ++c) {
+        Dg[rr * LD + c] = row[c];
+        if (rr < nb && c <= rr) A[(size_t)(j0 + rr) * R + j0 + c] = row[c];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
-      double li[FB_IV_NB];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
+    double li[FB_IV_NB];
+#pragma unroll
+    for (int r = 0; r < FB_IV_NB; ++r) {
+      double sacc = (r == rr) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) sacc = fma(-Dg[r * LD + q], li[q], sacc);
+      li[r] = sacc * fb_readlane_f64(rinv_mine, r);
+    }
+    if (lane < FB_IV_NB) {
 #pragma unroll
       for (int r = 0; r < FB_IV_NB; ++r) {
-        double sacc = (r == rr) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = 0; q < r; ++q) sacc = fma(-Dg[r * LD + q], li[q], sacc);
-        li[r] = sacc / Dg[r * LD + r];
+        Di[r * LD + rr] = li[r];
+        Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = li[r];
       }
-      if (lane < FB_IV_NB) {
+    }
+  };
+  // Right-looking blocked Cholesky with look-ahead: while the other waves apply panel j to the trailing
+  // matrix, wave 0 first updates the three 16x16 tiles of the NEXT diagonal block, then factors and
+  // inverts it -- the serial part runs in the shadow of the update.
+  if (wv == 0) factor_block(0, min(FB_IV_NB, R), 0);
+  __syncthreads();
+  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
+    const int nb = min(FB_IV_NB, R - j0);
+    // (b) panel below: X = A21 * L11^-T on the float64 matrix cores.  Wave = 16 rows: A fragment straight
+    //     from global A (lane l: row l % 16, column 4 q + l / 16), B fragment = L11^-1 from LDS (explicit
+    //     zeros above its diagonal), 2 column tiles x 8 steps.  Rows past the end contribute zeros, so the
+    //     panel copy in LDS is padded to a multiple of 16 rows for the update below.
+    const int m = R - j0 - nb;
+    const int mt16 = (m + 15) / 16;
+    for (int tI = wv; tI < mt16; tI += nw) {
+      const int i0 = 16 * tI;
+      const int ri = i0 + (lane & 15);
+      const bool rok = ri < m;
+      const double *arow = A + (size_t)(j0 + nb + (rok ? ri : 0)) * R + j0 + (lane >> 4);
+      fb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+      double av[8];
 #pragma unroll
-        for (int r = 0; r < FB_IV_NB; ++r) {
-          Di[r * LD + rr] = li[r];
-          Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = li[r];
+      for (int q = 0; q < 8; ++q) {  // (unconditional load on a clamped address, then masked)
+        const int kk = 4 * q + (lane >> 4);
+        const double v = arow[kk < nb ? 4 * q : 0];
+        av[q] = (rok && kk < nb) ? v : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = 4 * q + (lane >> 4);
+        const double b0v = Di[(lane & 15) * LD + kk], b1v = Di[(16 + (lane & 15)) * LD + kk];
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b0v, x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b1v, x1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr2 = i0 + (lane >> 4) + 4 * i, cc = lane & 15;
+        Lp[rr2 * LDP + cc] = x0[i];
+        Lp[rr2 * LDP + 16 + cc] = x1[i];
+        if (rr2 < m) {
+          double *ao = A + (size_t)(j0 + nb + rr2) * R + j0;
+          if (cc < nb) ao[cc] = x0[i];
+          if (16 + cc < nb) ao[16 + cc] = x1[i];
         }
       }
     }
     __syncthreads();
-    for (int i = tid; i < nb * nb; i += nt) {
-      const int r = i / nb, c = i - r * nb;
-      if (c <= r) A[(size_t)(j0 + r) * R + j0 + c] = Dg[r * LD + c];
-    }
-    // (b) panel below: X = A21 * L11^-T, one row per thread, independent dot products
-    const int m = R - j0 - nb;
-    for (int i = tid; i < m; i += nt) {
-      double a[FB_IV_NB];
-      double *arow = A + (size_t)(j0 + nb + i) * R + j0;
+    // (c) trailing update A22 -= L21 L21^T (lower triangle) in 16x16 tiles, 8 MFMAs each, both operands
+    //     from the LDS panel; the 4 results of a lane are 4 rows of one column, so 16 lanes write 128
+    //     contiguous bytes.  (Diagonal tiles also touch the strict upper triangle of A, which nothing reads.)
+    // NT tiles of one tile row at a time: their old values (global A, L2 latency) and column fragments
+    // are all requested before the first MFMA, the row fragment is loaded once.
+    auto update_tiles = [&](int tr, int tc0, int ntc) {  // tiles (tr, tc0 .. tc0 + ntc - 1), ntc <= 4
+      constexpr int NT = 4;
+      const double *lr = Lp + (size_t)(16 * tr + (lane & 15)) * LDP + (lane >> 4);
+      double af[8];
 #pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) a[c] = (c < nb) ? arow[c] : 0.0;
-      double *lrow = Lp + (size_t)i * LD;
+      for (int q = 0; q < 8; ++q) af[q] = lr[4 * q];
+      double *cp[NT][4];
+      double cv[NT][4];
+      bool ok[NT][4];
+      double bf[NT][8];
 #pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) {
-        double x = 0.0;
+      for (int u = 0; u < NT; ++u) {
+        const int tc = tc0 + min(u, ntc - 1);
+        const int cc2 = 16 * tc + (lane & 15);
 #pragma unroll
-        for (int q = 0; q <= c; ++q) x = fma(a[q], Di[c * LD + q], x);
-        lrow[c] = x;
-        if (c < nb) arow[c] = x;
+        for (int x = 0; x < 4; ++x) {
+          const int rr2 = 16 * tr + (lane >> 4) + 4 * x;
+          ok[u][x] = u < ntc && rr2 < m && cc2 < m;
+          cp[u][x] = A + (size_t)(j0 + nb + (ok[u][x] ? rr2 : 0)) * R + j0 + nb + (ok[u][x] ? cc2 : 0);
+          cv[u][x] = *cp[u][x];
+        }
+        const double *lc = Lp + (size_t)(16 * tc + (lane & 15)) * LDP + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bf[u][q] = lc[4 * q];
       }
-    }
-    // zero the padding rows of the panel so the 4x4 tiles below need no bounds checks
-    for (int i = m * LD + tid; i < ((m + 3) & ~3) * LD; i += nt) Lp[i] = 0.0;
-    __syncthreads();
-    // (c) trailing update A22 -= L21 L21^T (lower triangle), 4x4 register tiles from the LDS panel
-    const int mt = (m + 3) / 4;
-    const int ntile = mt * (mt + 1) / 2;
-    for (int i = tid; i < ntile; i += nt) {
-      int tr = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
-      while ((tr + 1) * (tr + 2) / 2 <= i) ++tr;
-      while (tr * (tr + 1) / 2 > i) --tr;
-      const int tc = i - tr * (tr + 1) / 2;
-      const int r0 = 4 * tr, c0 = 4 * tc;
-      const double *lr = Lp + (size_t)r0 * LD, *lc = Lp + (size_t)c0 * LD;
-      double sacc[4][4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+      for (int u = 0; u < NT; ++u) {
+        fb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int y = 0; y < 4; ++y) sacc[x][y] = 0.0;
-#pragma unroll 4
-      for (int q = 0; q < FB_IV_NB; ++q) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { av[x] = lr[x * LD + q]; bv[x] = lc[x * LD + q]; }
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[u][q], acc, 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y) sacc[x][y] = fma(av[x], bv[y], sacc[x][y]);
+          if (ok[u][x]) *cp[u][x] = cv[u][x] - acc[x];
       }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          const int rr2 = r0 + x, cc2 = c0 + y;
-          if (rr2 < m && cc2 <= rr2) A[(size_t)(j0 + nb + rr2) * R + j0 + nb + cc2] -= sacc[x][y];
-        }
+    };
+    if (wv == 0) {
+      if (m > 0) {  // tiles (0,0), (1,0), (1,1) = the next diagonal block, then its factorisation
+        update_tiles(0, 0, 1);
+        if (mt16 > 1) update_tiles(1, 0, 2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the factor reads what other lanes just stored
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        factor_block(j0 + nb, min(FB_IV_NB, m), pi + 1);
+      }
+    } else {
+      // work items = (tile row tr >= 2, group of 4 column tiles); rows are dealt out longest first
+      int item = 0;
+      for (int tr = mt16 - 1; tr >= 2; --tr)
+        for (int tc0 = 0; tc0 <= tr; tc0 += 4, ++item)
+          if (item % (nw - 1) == wv - 1) update_tiles(tr, tc0, min(4, tr + 1 - tc0));
     }
     __syncthreads();
   }
@@ -860,7 +916,7 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
 void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                         int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
   const int R = iv.R;
-  size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + (size_t)(R + 4) * (FB_IV_NB + 1));
+  size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + (size_t)(R + 16) * (FB_IV_NB + 2));
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
