@@ -579,65 +579,105 @@ __global__ __launch_bounds__(1024) void k_iv_active(int C, int *__restrict__ fla
 }
 
 // Both kernels stream float64 parameter rows exactly once per pass (coalesced, one column per thread)
-// and keep BT utterances of accumulators in VGPRs.  The per-utterance coefficients of the current row
-// (gammaT[k][*] / XT[q][*], contiguous, zero-padded to Bpad) are wave-uniform: they are fetched with
-// scalar loads and enter v_fmac_f64 as SGPR operands -- no LDS, no barriers.
+// and keep BT utterances of accumulators in VGPRs.  The per-utterance coefficients of a chunk of KC rows
+// (gammaT[k][*] / XT[q][*], contiguous, zero-padded to Bpad) are staged in LDS and read back as
+// broadcasts, so the only long-latency accesses of the inner loop are the parameter loads themselves --
+// and those are issued 8 rows ahead.  (An earlier version fetched the coefficients with scalar loads;
+// 64 SGPRs per row left no room to run ahead and the kernels sat on the load latency.)
 #define FB_IV_BT 32
+#define FB_IV_KC 32  // parameter rows per staged chunk
 __global__ __launch_bounds__(512) void k_iv_lin(FbIvDev iv, const double *__restrict__ XT,
                                                 const int *__restrict__ active, const int *__restrict__ n_active,
                                                 int B, int Bpad, int n_kchunks, double *__restrict__ linp) {
+  __shared__ __attribute__((aligned(16))) double s_c[FB_IV_KC][FB_IV_BT];
   const int R = iv.R, D = iv.D;
   const int na = *n_active;
   const int per = (na + n_kchunks - 1) / n_kchunks;  // active components per chunk
   const int a0 = blockIdx.x * per, a1 = min(na, a0 + per);
   const int b0 = blockIdx.y * FB_IV_BT;
-  const int r = threadIdx.x;
-  if (r >= R) return;
+  const int r = min((int)threadIdx.x, R - 1);  // (threads past R keep loading valid addresses, never store)
+  const int nq = (a1 - a0) * D;                // parameter rows of this block: (component, d) pairs
   double acc[FB_IV_BT];
 #pragma unroll
   for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
-  for (int ai = a0; ai < a1; ++ai) {
-    const int k = active[ai];
-    const double *sim = iv.sim + (size_t)k * D * R + r;
-    const double *xk = XT + (size_t)k * D * Bpad + b0;
-#pragma unroll 2
-    for (int d = 0; d < D; ++d) {
-      const double v = sim[(size_t)d * R];
-      const double *xr = xk + (size_t)d * Bpad;  // uniform address -> s_load
+  for (int q0 = 0; q0 < nq; q0 += FB_IV_KC) {
+    const int nk = min(FB_IV_KC, nq - q0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < FB_IV_KC * FB_IV_BT; i += blockDim.x) {
+      const int kk = i / FB_IV_BT, bb = i - kk * FB_IV_BT;
+      double v = 0.0;
+      if (kk < nk) {
+        const int q = q0 + kk, ai = a0 + q / D;
+        v = XT[((size_t)active[ai] * D + (q - (ai - a0) * D)) * Bpad + b0 + bb];
+      }
+      s_c[kk][bb] = v;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < nk; k0 += 8) {
+      double pv[8];
 #pragma unroll
-      for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(xr[bb], v, acc[bb]);
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + min(k0 + u, nk - 1), ai = a0 + q / D;
+        pv[u] = iv.sim[((size_t)active[ai] * D + (q - (ai - a0) * D)) * R + r];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k0 + u < nk) {
+#pragma unroll
+          for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(s_c[k0 + u][bb], pv[u], acc[bb]);
+        }
+      }
     }
   }
   const int nb = min(FB_IV_BT, B - b0);
+  if ((int)threadIdx.x < R) {
 #pragma unroll  // (a runtime trip count would index acc[] dynamically and push it to scratch memory)
-  for (int bb = 0; bb < FB_IV_BT; ++bb)
-    if (bb < nb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
+    for (int bb = 0; bb < FB_IV_BT; ++bb)
+      if (bb < nb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
+  }
 }
 // quad[b][e] = sum_k gamma[b][k] U[k][e]; thread = one packed element e
 __global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__restrict__ gammaT,
                                                  const int *__restrict__ active, const int *__restrict__ n_active,
                                                  int B, int Bpad, double *__restrict__ quad) {
+  __shared__ __attribute__((aligned(16))) double s_c[FB_IV_KC][FB_IV_BT];
+  __shared__ int s_k[FB_IV_KC];
   const int triR = iv.triR;
   const int na = *n_active;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = min((int)(blockIdx.x * 256 + threadIdx.x), triR - 1);
   const int b0 = blockIdx.y * FB_IV_BT;
-  if (e >= triR) return;
   double acc[FB_IV_BT];
 #pragma unroll
   for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
   const double *up = iv.u + e;
-#pragma unroll 2
-  for (int ai = 0; ai < na; ++ai) {
-    const int k = active[ai];
-    const double uv = up[(size_t)k * triR];
-    const double *gr = gammaT + (size_t)k * Bpad + b0;  // uniform address -> s_load
+  for (int a0 = 0; a0 < na; a0 += FB_IV_KC) {
+    const int nk = min(FB_IV_KC, na - a0);
+    __syncthreads();
+    if (threadIdx.x < FB_IV_KC) s_k[threadIdx.x] = active[a0 + min((int)threadIdx.x, nk - 1)];
+    for (int i = threadIdx.x; i < FB_IV_KC * FB_IV_BT; i += 256) {
+      const int kk = i / FB_IV_BT, bb = i - kk * FB_IV_BT;
+      s_c[kk][bb] = kk < nk ? gammaT[(size_t)active[a0 + kk] * Bpad + b0 + bb] : 0.0;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < nk; k0 += 8) {
+      double pv[8];
 #pragma unroll
-    for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(gr[bb], uv, acc[bb]);
+      for (int u = 0; u < 8; ++u) pv[u] = up[(size_t)s_k[min(k0 + u, nk - 1)] * triR];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k0 + u < nk) {
+#pragma unroll
+          for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(s_c[k0 + u][bb], pv[u], acc[bb]);
+        }
+      }
+    }
   }
   const int nb = min(FB_IV_BT, B - b0);
+  if ((int)(blockIdx.x * 256 + threadIdx.x) < triR) {
 #pragma unroll
-  for (int bb = 0; bb < FB_IV_BT; ++bb)
-    if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
+    for (int bb = 0; bb < FB_IV_BT; ++bb)
+      if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
+  }
 }
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
