@@ -363,7 +363,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
   HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
   // bf16x3 images (k_gmm_bx3): exact 3-way bf16 split of every parameter, gconst in the K padding
-  const int NK = (D + 3 + 15) / 16;
+  const int NK = (D + 3 + 15) / 16 < 3 ? 3 : (D + 3 + 15) / 16;  // kernels are instantiated for NK = 3..6 (zero padding is free)
   const char *mode_env = getenv("FB_GMM_MODE");
   const int mode = (mode_env && strcmp(mode_env, "f32") == 0) ? FB_GMM_MODE_F32 : FB_GMM_MODE_BX3;
   if (mode == FB_GMM_MODE_BX3) {

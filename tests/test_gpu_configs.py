@@ -1,0 +1,95 @@
+"""GPU parity for the non-default code paths: generic MFCC kernel (padded_length != 512), generic and
+compile-time delta options, feature dims that need other GMM kernel instantiations, the plain f32-MFMA
+GMM kernel, long utterances (sliding CMVN), and the attack's host-round-trip batch size."""
+import numpy as np
+import pytest
+
+from fakebob_amd.engine import Engine, nes_params
+from fakebob_amd.models import stack_models, synthetic_audio, synthetic_gmm_system
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4
+
+
+def _wav(utt, n=48000):
+    return (synthetic_audio(utt, n) * 32768.0).astype(np.int16)
+
+
+FRONTENDS = [
+    dict(),                                                          # recipe: P=512, deltas 2/3  (k_mfcc_r4, k_delta_cmvn<2,3>)
+    dict(delta_window=2),                                            # k_delta_cmvn<2,2>
+    dict(delta_order=1, delta_window=2),                             # generic delta path, D = 48
+    dict(delta_order=0),                                             # no deltas, D = 24
+    dict(sample_freq=8000.0, frame_length=200, frame_shift=80, padded_length=256, high_freq=3700.0),  # generic k_mfcc
+    dict(num_ceps=20, num_mel_bins=23, delta_order=3, delta_window=2),  # D = 80
+]
+
+
+@pytest.mark.parametrize("over", FRONTENDS)
+def test_frontend_and_scores_for_other_configs(oracle, over):
+    cfg = oracle.default_cfg(**over)
+    e = Engine(0)
+    try:
+        e.set_frontend(**over)
+        D = e.feat_dim
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=D)
+        e.load_gmm([ubm] + spk)
+        wavs = [_wav(0, 24000), _wav(1, 9000), _wav(2, 40000)]
+        for w in wavs[:2]:
+            fg, Tg = e.debug_feats(w)
+            fo, To = oracle.frontend(cfg, w)
+            assert Tg == To and fg.shape == fo.shape
+            assert np.abs(fg.astype(np.float64) - fo).max() <= 2e-5
+        raw_g, tv_g = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, tv_o = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=4)
+        assert np.array_equal(tv_g, tv_o)
+        assert np.abs(raw_g - raw_o).max() <= SCORE_TOL
+    finally:
+        e.close()
+
+
+def test_f32_mfma_gmm_kernel_still_matches(oracle, monkeypatch):
+    monkeypatch.setenv("FB_GMM_MODE", "f32")
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=3, C=256, D=72)
+        e.load_gmm([ubm] + spk)
+        wavs = [_wav(3, 30000), _wav(4, 16000)]
+        raw_g, _ = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, _ = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=4)
+        assert np.abs(raw_g - raw_o).max() <= SCORE_TOL
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("batch", ["1", "3", "16"])
+def test_attack_is_independent_of_the_queue_depth(monkeypatch, batch):
+    """Early stop, plateau schedule and trace live on the device; the number of iterations queued per host
+    round trip must not change anything."""
+    ubm, spk = synthetic_gmm_system(n_speakers=3, C=128, D=72)
+    audio = synthetic_audio(6, 16000)
+
+    def run():
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            e.set_system("OSI")
+            raw, _ = e.score_raw([(audio * 32768.0).astype(np.int16)])
+            sc = raw[0, 1:] - raw[0, 0]
+            target = int(np.argsort(sc)[-2])
+            p = nes_params("OSI", "targeted", samples_per_draw=10, max_iter=40, target=target,
+                           threshold=float(sc.max()) - 0.05, epsilon=0.004, max_lr=0.002, seed=11, stream=2)
+            return e.attack(p, audio)
+        finally:
+            e.close()
+
+    monkeypatch.setenv("FB_ATTACK_BATCH", "4")
+    ref = run()
+    monkeypatch.setenv("FB_ATTACK_BATCH", batch)
+    got = run()
+    assert got[1] == ref[1]                          # success flag
+    assert np.array_equal(got[0], ref[0])            # int16 adversarial audio
+    assert np.array_equal(got[2], ref[2])            # float64 adversarial audio (bit-identical)
+    assert np.array_equal(got[3], ref[3])            # trace rows (bit-identical)
