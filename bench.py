@@ -97,8 +97,10 @@ def bench_ivector(args, torch):
     tri = 400 * 401 // 2
     bytes_stream = 8.0 * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)       # Sigma^-1 M + U, float64, read once
     n_active = eng.debug_iv_active()
-    n_btiles = (SPD + 1 + 31) // 32                                    # utterance tiles of 32 -> passes over the rows
-    bytes_exec = 8.0 * n_active * (D_FEAT * 400 + tri) * n_btiles
+    n_bgroups = (SPD + 1 + 63) // 64                                   # utterance groups of 64 -> passes over the rows
+    bytes_exec = 8.0 * n_active * (D_FEAT * 400 + tri) * n_bgroups
+    # f64 MFMA work actually issued: 64-row tiles (51 useful), only the active rows
+    flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * 400 + tri)
     con_ms = ms_con / args.steps
     out = {"metric": "NES iterations/sec (i-vector-PLDA SV, samples_per_draw=50, 3 s@16 kHz)", "value": its,
            "unit": "NES iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -108,15 +110,19 @@ def bench_ivector(args, torch):
            "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
                                   "%d attacks in flight" % K, "attacks_in_flight_per_gpu": K,
                       "voiced_rows_per_iter": rows, "model_load_s": t_load},
-           "roofline": {"kernel": "k_iv_lin + k_iv_quad (T-matrix contraction, float64)", "bound": "hbm",
+           "roofline": {"kernel": "k_iv_contract_gemm<lin> + <quad> (T-matrix contraction, LDS-tiled float64 MFMA "
+                                  "v_mfma_f64_16x16x4, active rows only)", "bound": "hbm",
                         "achieved": bytes_stream / (con_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_stream / (con_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                         "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_stream,
                         "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
                         "executed_gbps": bytes_exec / (con_ms * 1e-3) / 1e9,
                         "note": "algorithmic = both matrices streamed once (SURVEY.md 8(d)); the kernels stream only "
-                                "the rows of components with posterior mass, once per 32-utterance tile",
-                        "flops_per_launch": 2.0 * (SPD + 1) * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)}}
+                                "the rows of components with posterior mass, once per 64-utterance group",
+                        "flops_per_launch": 2.0 * (SPD + 1) * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri),
+                        "mfma_f64": {"executed_flops_per_launch": flops_exec,
+                                     "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
+                                     "frac": flops_exec / (con_ms * 1e-3) / 1e12 / 78.6}}}
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         import numpy as np

@@ -22,6 +22,8 @@
 #include "fb_device.h"
 #include "fb_kernels.h"
 
+typedef double fb_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64
+
 // ------------------------------------------------------- derived variables
 // SIM[k][d][r] = sum_e Sinv[k][d][e] * M[k][e][r]
 __global__ __launch_bounds__(256) void k_iv_derive_sim(int C, int D, int R, const double *__restrict__ M,
@@ -679,16 +681,148 @@ __global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__res
       if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
   }
 }
+// The two contractions as one LDS-tiled GEMM on the float64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   out[b][n] = sum_q AT[q][b] * P[q][n],   q = the rows of the ACTIVE components only,
+// P = U (quad: one row per component, n = packed element) or Sigma^-1 M (lin: D rows per component,
+// n = i-vector dimension, split over blockIdx.y chunks of the active list whose partials the solve
+// kernel adds up).  Workgroup tile = 64 utterances x 128 columns, K in stages of FB_CG_KC parameter rows:
+// every row segment is 1 KB of contiguous HBM, fetched once with 16-byte loads into registers while the
+// previous stage is multiplied, then parked in LDS (row strides padded so that the two half-waves of a
+// fragment read hit disjoint banks).  Wave = 32 columns x 64 utterances = 8 accumulator tiles.
+// The f64 MFMA peak equals the vector peak (78.6 TF); what it buys is 2048 flops per instruction and two
+// 8-byte operand reads per lane instead of one per fma, which is what lets the parameter stream run at
+// HBM speed.
+#define FB_CG_NT 128   // columns per workgroup
+#define FB_CG_LDA 80   // doubles per staged coefficient row (64 + 16: bank offset 32 between rows)
+#define FB_CG_LDB 144  // doubles per staged parameter row (128 + 16)
+template <bool IS_LIN, int FB_CG_KC>  // FB_CG_KC = parameter rows per stage (measured best: 16 for lin, 8 for quad)
+__global__ __launch_bounds__(256) void k_iv_contract_gemm(FbIvDev iv, const double *__restrict__ AT, int ldA,
+                                                          const int *__restrict__ active,
+                                                          const int *__restrict__ n_active, int B,
+                                                          int n_kchunks, double *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double sA[2][FB_CG_KC * FB_CG_LDA];
+  __shared__ __attribute__((aligned(16))) double sB[2][FB_CG_KC * FB_CG_LDB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int N = IS_LIN ? iv.R : iv.triR;
+  const int DK = IS_LIN ? iv.D : 1;
+  const double *P = IS_LIN ? iv.sim : iv.u;
+  const int n0 = blockIdx.x * FB_CG_NT;
+  const int b0 = blockIdx.z * 64;
+  const int na = *n_active;
+  int a0 = 0, a1 = na;
+  if (IS_LIN) {
+    const int per = (na + n_kchunks - 1) / n_kchunks;
+    a0 = blockIdx.y * per;
+    a1 = min(na, a0 + per);
+  }
+  const int nq = max(0, a1 - a0) * DK;
+  const int nst = (nq + FB_CG_KC - 1) / FB_CG_KC;
+  // loader roles: a parameter stage is KC rows x 64 16-byte pieces, a coefficient stage KC rows x 32
+  constexpr int NPB = FB_CG_KC * 64 / 256;           // 16-byte parameter pieces per thread and stage
+  constexpr int NPA = FB_CG_KC * 32 / 256;           // coefficient pieces per thread and stage
+  double2 rb[NPB], ra[NPA];
+  auto row_of = [&](int q) -> size_t {                // parameter / coefficient row of contraction index q
+    const int qc = min(q, nq - 1);
+    const int ai = a0 + (IS_LIN ? qc / DK : qc);
+    const int k = active[ai];
+    return IS_LIN ? (size_t)k * DK + (qc - (ai - a0) * DK) : (size_t)k;
+  };
+  auto fetch = [&](int st) {
+    const int q0 = st * FB_CG_KC;
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int piece = tid + 256 * u, r = piece >> 6, c = (piece & 63) * 2;
+      const size_t prow = row_of(q0 + r);
+      const double *src = P + prow * N;
+      const double x = src[min(n0 + c, N - 1)], y = src[min(n0 + c + 1, N - 1)];  // clamped, then masked
+      const bool rok = q0 + r < nq;
+      const double2 v = make_double2((rok && n0 + c < N) ? x : 0.0, (rok && n0 + c + 1 < N) ? y : 0.0);
+      rb[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int piece = tid + 256 * u, lr = piece >> 5, lc = (piece & 31) * 2;
+      const size_t prow = row_of(q0 + lr);
+      const double *src = AT + prow * ldA;
+      const double x = src[min(b0 + lc, ldA - 1)], y = src[min(b0 + lc + 1, ldA - 1)];
+      const bool rok = q0 + lr < nq;
+      ra[u] = make_double2((rok && b0 + lc < ldA) ? x : 0.0, (rok && b0 + lc + 1 < ldA) ? y : 0.0);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int piece = tid + 256 * u, r = piece >> 6, c = (piece & 63) * 2;
+      *reinterpret_cast<double2 *>(&sB[buf][r * FB_CG_LDB + c]) = rb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int piece = tid + 256 * u, lr = piece >> 5, lc = (piece & 31) * 2;
+      *reinterpret_cast<double2 *>(&sA[buf][lr * FB_CG_LDA + lc]) = ra[u];
+    }
+  };
+  fb_d4 acc[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[c][t] = fb_d4{0.0, 0.0, 0.0, 0.0};
+  if (nst > 0) {
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nst) fetch(st + 1);
+#pragma unroll
+      for (int ks = 0; ks < FB_CG_KC / 4; ++ks) {
+        const int kk = 4 * ks + (lane >> 4);
+        double af[4], bf[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = sA[buf][kk * FB_CG_LDA + 16 * t + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bf[c] = sB[buf][kk * FB_CG_LDB + 32 * w + 16 * c + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf[c], acc[c][t], 0, 0, 0);
+      }
+      if (st + 1 < nst) park(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  double *o = IS_LIN ? out + (size_t)blockIdx.y * B * N : out;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int col = n0 + 32 * w + 16 * c + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = b0 + 16 * t + (lane >> 4) + 4 * i;
+        if (row < B && col < N) o[(size_t)row * N + col] = acc[c][t][i];
+      }
+  }
+}
+
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
                            double *quad) {
   const int threads = (iv.R + 63) / 64 * 64;
   const int btiles = (B + FB_IV_BT - 1) / FB_IV_BT;
   hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
-  hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, btiles), dim3(threads), 0, s, iv, XT, active, n_active, B, Bpad,
-                     n_kchunks, linp);
-  hipLaunchKernelGGL(k_iv_quad, dim3((iv.triR + 255) / 256, btiles), dim3(256), 0, s, iv, gammaT, active, n_active,
-                     B, Bpad, quad);
+  if (getenv("FB_IV_CONTRACT_VALU")) {  // the vector-ALU formulation (kept for comparison / odd sizes)
+    hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, btiles), dim3(threads), 0, s, iv, XT, active, n_active, B, Bpad,
+                       n_kchunks, linp);
+    hipLaunchKernelGGL(k_iv_quad, dim3((iv.triR + 255) / 256, btiles), dim3(256), 0, s, iv, gammaT, active,
+                       n_active, B, Bpad, quad);
+    return;
+  }
+  const int bgroups = (B + 63) / 64;
+  hipLaunchKernelGGL((k_iv_contract_gemm<true, 16>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0,
+                     s, iv, XT, Bpad, active, n_active, B, n_kchunks, linp);
+  hipLaunchKernelGGL((k_iv_contract_gemm<false, 8>), dim3((iv.triR + FB_CG_NT - 1) / FB_CG_NT, 1, bgroups), dim3(256), 0, s,
+                     iv, gammaT, Bpad, active, n_active, B, 1, quad);
 }
 
 // --------------------------------------------------------- solve (K10c)
@@ -699,7 +833,6 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain mat-vec /
 // mat-mat products.  ivec = solution with the prior offset removed from component 0.
 #define FB_IV_NB 32
-typedef double fb_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src);
