@@ -660,7 +660,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
     FB_DBG_SYNC(e, "stats");
-    // bench timing of the T-matrix contraction (k_iv_lin + k_iv_quad): the HBM-streaming kernels
+    // bench timing of the T-matrix contraction (the two k_iv_contract_gemm launches)
     FBCHK(time_begin(e));
     fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
                           e->iv_bws.as<int>() + 3 * (size_t)iv.C + 2, e->iv_active.as<int>(),

@@ -8,14 +8,17 @@
 // are float32 values like Kaldi's, accumulated into float64 statistics in frame order
 // (deterministic: no atomics anywhere).
 //
-//   k_gmm<KH,DUMP>      diagonalised-UBM log-likelihoods of every component (gmm_kernels.hip)
-//   k_iv_select_post    per frame: top-n Gaussians, full-covariance log-likelihoods, softmax,
-//                       min-post pruning
-//   k_iv_stats          zeroth / first order statistics per (utterance, 64-component slab)
-//   k_iv_lin / _quad    the T-matrix contraction: lin = sum_k (S_k^-1 M_k)^T F_k,
-//                       quad = I + sum_k N_k U_k   (HBM-streaming of 0.47 GB + 1.3 GB of float64)
-//   k_iv_solve          blocked Cholesky + triangular solves of the B (R x R) systems
-//   k_iv_backend        mean subtraction, LDA, length norm, PLDA transform, LLR vs enrolled
+//   k_gmm_bx3<NK,true>    diagonalised-UBM log-likelihoods of every component (gmm_kernels.hip)
+//   k_iv_select           per frame: top-n Gaussians (registers + DPP arg-max)
+//   k_iv_bucket_*         stable, atomic-free partition of the (frame, slot) pairs by component
+//   k_iv_fullcov_t        full-covariance log-likelihoods, component parameters as scalar operands
+//   k_iv_post             softmax + min-post pruning per frame
+//   k_iv_stats            zeroth / first order statistics per (component, utterance) from the buckets
+//   k_iv_active           list of the components with posterior mass
+//   k_iv_contract_gemm    the T-matrix contraction: lin = sum_k (S_k^-1 M_k)^T F_k, quad = sum_k N_k U_k
+//                         as an LDS-tiled float64-MFMA GEMM over the active rows (of 0.47 GB + 1.3 GB)
+//   k_iv_solve            blocked Cholesky (f64 MFMA, look-ahead) + triangular solves of the B (R x R) systems
+//   k_iv_backend          mean subtraction, LDA, length norm, PLDA transform, LLR vs enrolled
 #include <float.h>
 #include <stdlib.h>
 
@@ -580,107 +583,6 @@ __global__ __launch_bounds__(1024) void k_iv_active(int C, int *__restrict__ fla
   if (threadIdx.x == 0) *n_active = s_base;
 }
 
-// Both kernels stream float64 parameter rows exactly once per pass (coalesced, one column per thread)
-// and keep BT utterances of accumulators in VGPRs.  The per-utterance coefficients of a chunk of KC rows
-// (gammaT[k][*] / XT[q][*], contiguous, zero-padded to Bpad) are staged in LDS and read back as
-// broadcasts, so the only long-latency accesses of the inner loop are the parameter loads themselves --
-// and those are issued 8 rows ahead.  (An earlier version fetched the coefficients with scalar loads;
-// 64 SGPRs per row left no room to run ahead and the kernels sat on the load latency.)
-#define FB_IV_BT 32
-#define FB_IV_KC 32  // parameter rows per staged chunk
-__global__ __launch_bounds__(512) void k_iv_lin(FbIvDev iv, const double *__restrict__ XT,
-                                                const int *__restrict__ active, const int *__restrict__ n_active,
-                                                int B, int Bpad, int n_kchunks, double *__restrict__ linp) {
-  __shared__ __attribute__((aligned(16))) double s_c[FB_IV_KC][FB_IV_BT];
-  const int R = iv.R, D = iv.D;
-  const int na = *n_active;
-  const int per = (na + n_kchunks - 1) / n_kchunks;  // active components per chunk
-  const int a0 = blockIdx.x * per, a1 = min(na, a0 + per);
-  const int b0 = blockIdx.y * FB_IV_BT;
-  const int r = min((int)threadIdx.x, R - 1);  // (threads past R keep loading valid addresses, never store)
-  const int nq = (a1 - a0) * D;                // parameter rows of this block: (component, d) pairs
-  double acc[FB_IV_BT];
-#pragma unroll
-  for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
-  for (int q0 = 0; q0 < nq; q0 += FB_IV_KC) {
-    const int nk = min(FB_IV_KC, nq - q0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < FB_IV_KC * FB_IV_BT; i += blockDim.x) {
-      const int kk = i / FB_IV_BT, bb = i - kk * FB_IV_BT;
-      double v = 0.0;
-      if (kk < nk) {
-        const int q = q0 + kk, ai = a0 + q / D;
-        v = XT[((size_t)active[ai] * D + (q - (ai - a0) * D)) * Bpad + b0 + bb];
-      }
-      s_c[kk][bb] = v;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < nk; k0 += 8) {
-      double pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int q = q0 + min(k0 + u, nk - 1), ai = a0 + q / D;
-        pv[u] = iv.sim[((size_t)active[ai] * D + (q - (ai - a0) * D)) * R + r];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (k0 + u < nk) {
-#pragma unroll
-          for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(s_c[k0 + u][bb], pv[u], acc[bb]);
-        }
-      }
-    }
-  }
-  const int nb = min(FB_IV_BT, B - b0);
-  if ((int)threadIdx.x < R) {
-#pragma unroll  // (a runtime trip count would index acc[] dynamically and push it to scratch memory)
-    for (int bb = 0; bb < FB_IV_BT; ++bb)
-      if (bb < nb) linp[((size_t)blockIdx.x * B + b0 + bb) * R + r] = acc[bb];
-  }
-}
-// quad[b][e] = sum_k gamma[b][k] U[k][e]; thread = one packed element e
-__global__ __launch_bounds__(256) void k_iv_quad(FbIvDev iv, const double *__restrict__ gammaT,
-                                                 const int *__restrict__ active, const int *__restrict__ n_active,
-                                                 int B, int Bpad, double *__restrict__ quad) {
-  __shared__ __attribute__((aligned(16))) double s_c[FB_IV_KC][FB_IV_BT];
-  __shared__ int s_k[FB_IV_KC];
-  const int triR = iv.triR;
-  const int na = *n_active;
-  const int e = min((int)(blockIdx.x * 256 + threadIdx.x), triR - 1);
-  const int b0 = blockIdx.y * FB_IV_BT;
-  double acc[FB_IV_BT];
-#pragma unroll
-  for (int i = 0; i < FB_IV_BT; ++i) acc[i] = 0.0;
-  const double *up = iv.u + e;
-  for (int a0 = 0; a0 < na; a0 += FB_IV_KC) {
-    const int nk = min(FB_IV_KC, na - a0);
-    __syncthreads();
-    if (threadIdx.x < FB_IV_KC) s_k[threadIdx.x] = active[a0 + min((int)threadIdx.x, nk - 1)];
-    for (int i = threadIdx.x; i < FB_IV_KC * FB_IV_BT; i += 256) {
-      const int kk = i / FB_IV_BT, bb = i - kk * FB_IV_BT;
-      s_c[kk][bb] = kk < nk ? gammaT[(size_t)active[a0 + kk] * Bpad + b0 + bb] : 0.0;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < nk; k0 += 8) {
-      double pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pv[u] = up[(size_t)s_k[min(k0 + u, nk - 1)] * triR];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (k0 + u < nk) {
-#pragma unroll
-          for (int bb = 0; bb < FB_IV_BT; ++bb) acc[bb] = fma(s_c[k0 + u][bb], pv[u], acc[bb]);
-        }
-      }
-    }
-  }
-  const int nb = min(FB_IV_BT, B - b0);
-  if ((int)(blockIdx.x * 256 + threadIdx.x) < triR) {
-#pragma unroll
-    for (int bb = 0; bb < FB_IV_BT; ++bb)
-      if (bb < nb) quad[(size_t)(b0 + bb) * triR + e] = acc[bb];
-  }
-}
 // The two contractions as one LDS-tiled GEMM on the float64 matrix cores (v_mfma_f64_16x16x4_f64):
 //   out[b][n] = sum_q AT[q][b] * P[q][n],   q = the rows of the ACTIVE components only,
 // P = U (quad: one row per component, n = packed element) or Sigma^-1 M (lin: D rows per component,
@@ -808,16 +710,7 @@ __global__ __launch_bounds__(256) void k_iv_contract_gemm(FbIvDev iv, const doub
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
                            double *quad) {
-  const int threads = (iv.R + 63) / 64 * 64;
-  const int btiles = (B + FB_IV_BT - 1) / FB_IV_BT;
   hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
-  if (getenv("FB_IV_CONTRACT_VALU")) {  // the vector-ALU formulation (kept for comparison / odd sizes)
-    hipLaunchKernelGGL(k_iv_lin, dim3(n_kchunks, btiles), dim3(threads), 0, s, iv, XT, active, n_active, B, Bpad,
-                       n_kchunks, linp);
-    hipLaunchKernelGGL(k_iv_quad, dim3((iv.triR + 255) / 256, btiles), dim3(256), 0, s, iv, gammaT, active,
-                       n_active, B, Bpad, quad);
-    return;
-  }
   const int bgroups = (B + 63) / 64;
   hipLaunchKernelGGL((k_iv_contract_gemm<true, 16>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0,
                      s, iv, XT, Bpad, active, n_active, B, n_kchunks, linp);
