@@ -100,7 +100,7 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter, ctl, ctl_ls, trace_dev;
+  DevBuf frame_rec, vad_counter, ctl, ctl_ls, trace_dev, enr_ll, enr_aux, enr_stats;
   FbCtlDev *h_ctl = nullptr;  // pinned
   hipEvent_t evg_ring[2 * 16] = {};
   int evg_n = 0;
@@ -150,7 +150,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -1342,6 +1342,40 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   HIPCHK(hipGetLastError());
   return FB_OK;
 }
+
+// Enrolment statistics (build_spk_models.py:184-216, `gmm-global-acc-stats --update-flags=m`): posteriors
+// of the loaded GMM (the UBM, loaded alone) on the voiced frames of one utterance.
+extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, double *occ, double *F, int *tv_out) {
+  if (!e || !wav || !occ || !F || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (!e->have_gmm || e->kind != 0 || e->gmm.M != 1)
+    return fb_fail(FB_E_STATE, "load exactly one diagonal GMM (the UBM) before accumulating statistics");
+  FBCHK(debug_frontend(e, wav, n));  // MFCC, VAD, deltas, CMVN, voiced rows of this utterance
+  const int T = e->h_frame_off[1];
+  const FbGmmDev &g = e->gmm;
+  const int ld = g.n_tiles * 32;
+  FBCHK(e->enr_ll.ensure(sizeof(float) * (size_t)T * ld));
+  FBCHK(e->enr_aux.ensure(sizeof(float) * 2 * (size_t)T));
+  FBCHK(e->enr_stats.ensure(sizeof(double) * (size_t)g.C * (g.D + 1)));
+  hipStream_t s = e->stream;
+  const int *n_rows_ptr = e->row_off.as<int>() + 1;
+  fb_launch_gmm_dump(s, g, e->feats.as<float>(), n_rows_ptr, T, choose_chunks(g, T), e->enr_ll.as<float>());
+  double *d_occ = e->enr_stats.as<double>(), *d_F = d_occ + g.C;
+  fb_launch_gmm_post_stats(s, g.C, ld, g.D, e->enr_ll.as<float>(), e->feats.as<float>(), n_rows_ptr, T,
+                           e->enr_aux.as<float>(), e->enr_aux.as<float>() + T, d_occ, d_F);
+  int tv = 0;
+  HIPCHK(hipMemcpyAsync(&tv, e->tv.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(occ, d_occ, sizeof(double) * (size_t)g.C, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(F, d_F, sizeof(double) * (size_t)g.C * g.D, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  if (tv_out) *tv_out = tv;
+  if (tv <= 0) return fb_fail(FB_E_NO_VOICED, "enrolment utterance has no voiced frames");
+  return FB_OK;
+}
+
+// i-vectors of the last scored batch (enrolment: build_spk_models.py:104-150 keeps the enrolment utterance's
+// i-vector as the speaker identity)
+extern "C" int fb_last_ivectors(fb_engine *e, int B, double *ivecs) { return fb_debug_ivectors(e, B, ivecs); }
 
 extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T_out) {
   if (!mfcc) return fb_fail(FB_E_ARG, "mfcc is NULL");

@@ -115,6 +115,10 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
 // single model (g.M == 1): ll[row][n_tiles*32] = every component log-likelihood (gmm-gselect input)
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                         int rows_cap, int n_chunks, float *ll);
+// enrolment statistics of a single model from its dump matrix ll[rows][ld]: occ[C], F[C][D] (float64)
+void fb_launch_gmm_post_stats(hipStream_t s, int C, int ld, int D, const float *ll, const float *feats,
+                              const int *n_rows_ptr, int rows_cap, float *mx, float *inv_sum, double *occ,
+                              double *F);
 // raw[b][m] = mean over voiced rows of logsumexp (merging the chunk partials)
 void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                             int rows_cap, int n_chunks, const int *row_off, int B, double *raw);

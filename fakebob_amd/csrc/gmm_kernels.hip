@@ -24,6 +24,8 @@
 //     workgroups; chunk partials (max, sumexp) are merged by k_gmm_finalize, which
 //     also performs the voiced-frame average in float64 in a fixed order
 //     (deterministic, no atomics).
+#include <float.h>
+
 #include "fb_device.h"
 #include "fb_kernels.h"
 
@@ -485,4 +487,85 @@ void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_
                             int rows_cap, int n_chunks, const int *row_off, int B, double *raw) {
   hipLaunchKernelGGL(k_gmm_finalize, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
                      row_off, B, raw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Enrolment (build_spk_models.py:184-216): `gmm-global-acc-stats --update-flags=m` = per-frame posteriors
+// of the UBM components (float32 soft-max of the component log-likelihoods, Kaldi's ComponentPosteriors)
+// accumulated in float64: occ[k] = sum_t p_tk, F[k][:] = sum_t p_tk x_t, frames in order.
+//   k_gmm_lse          wave = frame: max and sum(exp) over the C log-likelihoods of the dump matrix
+//   k_gmm_post_stats   workgroup = 64-component slab, thread (c, dg) owns component c and dims dg, dg+4, ...;
+//                      frames are staged 64 at a time (posterior tile + feature tile in LDS)
+__global__ __launch_bounds__(256) void k_gmm_lse(int C, int ld, const float *__restrict__ ll,
+                                                 const int *__restrict__ n_rows_ptr, float *__restrict__ mx,
+                                                 float *__restrict__ inv_sum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= *n_rows_ptr) return;
+  const float *lr = ll + (size_t)row * ld;
+  float m = -FLT_MAX;
+  for (int i = lane; i < C; i += 64) m = fmaxf(m, lr[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float ssum = 0.0f;
+  for (int i = lane; i < C; i += 64) ssum += expf(lr[i] - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+  if (lane == 0) { mx[row] = m; inv_sum[row] = 1.0f / ssum; }
+}
+#define FB_PS_DMAX4 20  // D <= 80
+__global__ __launch_bounds__(256) void k_gmm_post_stats(int C, int ld, int D, const float *__restrict__ ll,
+                                                        const float *__restrict__ feats,
+                                                        const int *__restrict__ n_rows_ptr,
+                                                        const float *__restrict__ mx,
+                                                        const float *__restrict__ inv_sum,
+                                                        double *__restrict__ occ, double *__restrict__ F) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  float *Pd = smf;           // [64 rows][64 comps]
+  float *X = smf + 64 * 64;  // [64 rows][D]
+  const int n_rows = *n_rows_ptr, k0 = blockIdx.x * 64;
+  const int c = threadIdx.x & 63, dg = threadIdx.x >> 6;
+  double acc[FB_PS_DMAX4];
+#pragma unroll
+  for (int i = 0; i < FB_PS_DMAX4; ++i) acc[i] = 0.0;
+  double gam = 0.0;
+  for (int rb = 0; rb < n_rows; rb += 64) {
+    const int nr = min(64, n_rows - rb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * 64; i += 256) {
+      const int rl = i >> 6, cc = i & 63;
+      const int k = k0 + cc;
+      // Kaldi: exp(ll - max) scaled by 1/sum, all in float32
+      Pd[i] = k < C ? expf(ll[(size_t)(rb + rl) * ld + k] - mx[rb + rl]) * inv_sum[rb + rl] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < nr * D; i += 256) X[i] = feats[(size_t)rb * D + i];
+    __syncthreads();
+    for (int rl = 0; rl < nr; ++rl) {
+      const double wv = (double)Pd[rl * 64 + c];
+      gam = __dadd_rn(gam, wv);
+      const float *fr = X + rl * D;
+#pragma unroll
+      for (int i = 0; i < FB_PS_DMAX4; ++i) {
+        const int d = dg + 4 * i;
+        if (d < D) acc[i] = __dadd_rn(acc[i], __dmul_rn(wv, (double)fr[d]));
+      }
+    }
+  }
+  const int k = k0 + c;
+  if (k < C) {
+    if (dg == 0) occ[k] = gam;
+#pragma unroll
+    for (int i = 0; i < FB_PS_DMAX4; ++i) {
+      const int d = dg + 4 * i;
+      if (d < D) F[(size_t)k * D + d] = acc[i];
+    }
+  }
+}
+void fb_launch_gmm_post_stats(hipStream_t s, int C, int ld, int D, const float *ll, const float *feats,
+                              const int *n_rows_ptr, int rows_cap, float *mx, float *inv_sum, double *occ,
+                              double *F) {
+  if (rows_cap <= 0) return;
+  hipLaunchKernelGGL(k_gmm_lse, dim3((rows_cap + 3) / 4), dim3(256), 0, s, C, ld, ll, n_rows_ptr, mx, inv_sum);
+  hipLaunchKernelGGL(k_gmm_post_stats, dim3((C + 63) / 64), dim3(256), sizeof(float) * (64 * 64 + 64 * (size_t)D), s, C,
+                     ld, D, ll, feats, n_rows_ptr, mx, inv_sum, occ, F);
 }

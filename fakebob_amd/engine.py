@@ -67,6 +67,7 @@ class Engine(object):
         N.check(self._L.fb_load_gmm(self._h, C.c_int(M), C.c_int(Cn), C.c_int(D), N.ptr(gc),
                                     N.ptr(miv), N.ptr(iv)))
         self.n_models = M
+        self._gmm_shape = (Cn, D)
         self.task = "OSI"
 
     def load_ivector(self, system, task="OSI"):
@@ -91,6 +92,24 @@ class Engine(object):
     def debug_ivectors(self, B, R):
         out = np.empty((B, R), np.float64)
         N.check(self._L.fb_debug_ivectors(self._h, C.c_int(B), N.ptr(out)))
+        return out
+
+    def gmm_acc_stats(self, wav):
+        """UBM (loaded alone) posterior statistics of one utterance: occ[C], F[C,D] (float64), voiced frames."""
+        wav = np.ascontiguousarray(wav).reshape(-1)
+        if wav.dtype != np.int16:
+            raise TypeError("gmm_acc_stats takes int16 samples")
+        Cn, D = self._gmm_shape
+        occ = np.empty(Cn, np.float64)
+        F = np.empty((Cn, D), np.float64)
+        tv = C.c_int()
+        N.check(self._L.fb_gmm_acc_stats(self._h, N.ptr(wav), C.c_int64(wav.size), N.ptr(occ), N.ptr(F), C.byref(tv)))
+        return occ, F, tv.value
+
+    def last_ivectors(self, B, R):
+        """i-vectors (B, R) of the batch scored last with an i-vector system."""
+        out = np.empty((B, R), np.float64)
+        N.check(self._L.fb_last_ivectors(self._h, C.c_int(B), N.ptr(out)))
         return out
 
     def debug_iv_active(self):

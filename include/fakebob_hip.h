@@ -200,6 +200,18 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
                    int *Tv, int *T);
 /* i-vectors [B*R] (float64, prior offset removed) of the last scored batch */
 int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
+
+/* ---- enrolment (build_spk_models.py) ------------------------------------------
+ * fb_gmm_acc_stats replaces `gmm-global-acc-stats --update-flags=m final.dubm feats acc`
+ * (build_spk_models.py:197-204): with the UBM loaded ALONE (fb_load_gmm, M = 1) it returns the float64
+ * zeroth / first order statistics occ[C], F[C*D] of one utterance's voiced, CMVN'd delta features.  The
+ * MAP mean update itself (gmm-global-est-map.cc:62-92, `MapDiagGmmUpdate`, means only) is a C*D
+ * element-wise formula done by the host mirror (fakebob_amd/enroll.py).
+ * fb_last_ivectors returns the i-vectors (B x R, float64, before mean subtraction / LDA) of the batch scored
+ * last with an i-vector system: the enrolment identity of ivector_PLDA (build_spk_models.py:104-150). */
+int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, double *occ, double *F, int *tv_out);
+int fb_last_ivectors(fb_engine *e, int B, double *ivecs);
+
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
 int fb_debug_iv_active(fb_engine *e, int *n_active);

@@ -503,6 +503,58 @@ int fbo_gmm_score_batch(const fbo_frontend_cfg *c, const int16_t *wav, const int
   return err;
 }
 
+/* ------------------- enrolment: gmm-global-acc-stats + MapDiagGmmUpdate [EXT] */
+/* build_spk_models.py:184-216.  Per voiced frame: component log-likelihoods (float64 here, Kaldi: float32
+ * sgemv), float32 soft-max as Kaldi's ComponentPosteriors / ApplySoftMax (max, sequential sum of exp,
+ * scale by 1/sum), posteriors accumulated in float64 (AccumDiagGmm) in frame order. */
+int fbo_gmm_acc_stats(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, const float *gc,
+                      const float *miv, const float *iv, int C, int D, double *occ, double *F) {
+  int T = fbo_num_frames(c, n);
+  if (T <= 0) return -1;
+  float *feats = (float *)malloc(sizeof(float) * (size_t)T * D);
+  int Tt = 0;
+  int tv = fbo_frontend(c, wav, n, feats, &Tt);
+  if (tv <= 0) { free(feats); return -1; }
+  for (int k = 0; k < C; ++k) occ[k] = 0.0;
+  for (size_t i = 0; i < (size_t)C * D; ++i) F[i] = 0.0;
+  float *ll = (float *)malloc(sizeof(float) * C);
+  for (int t = 0; t < tv; ++t) {
+    const float *f = feats + (size_t)t * D;
+    float mx = -INFINITY;
+    for (int k = 0; k < C; ++k) {
+      const float *m = miv + (size_t)k * D, *v = iv + (size_t)k * D;
+      double a = 0.0, b = 0.0;
+      for (int d = 0; d < D; ++d) { a += (double)m[d] * (double)f[d]; b += (double)v[d] * (double)(float)(f[d] * f[d]); }
+      ll[k] = (float)((double)gc[k] + a - 0.5 * b);
+      if (ll[k] > mx) mx = ll[k];
+    }
+    float sum = 0.0f;
+    for (int k = 0; k < C; ++k) { ll[k] = expf(ll[k] - mx); sum += ll[k]; }
+    const float inv = 1.0f / sum;
+    for (int k = 0; k < C; ++k) {
+      const double p = (double)(float)(ll[k] * inv);
+      occ[k] += p;
+      double *Fk = F + (size_t)k * D;
+      for (int d = 0; d < D; ++d) Fk[d] += p * (double)f[d];
+    }
+  }
+  free(ll); free(feats);
+  return tv;
+}
+/* MapDiagGmmUpdate, update-flags = "m", mean_tau (gmm-global-est-map.cc:31,62-92): only components with
+ * occupancy > 0 move: mean' = F/(occ+tau) + tau/(occ+tau) * mean, in float64 (DiagGmmNormal). */
+void fbo_map_update_means(const double *means, const double *occ, const double *F, int C, int D, double tau,
+                          double *new_means) {
+  for (int k = 0; k < C; ++k) {
+    for (int d = 0; d < D; ++d) {
+      const double old = means[(size_t)k * D + d];
+      double v = old;
+      if (occ[k] > 0.0) v = F[(size_t)k * D + d] * (1.0 / (occ[k] + tau)) + (tau / (occ[k] + tau)) * old;
+      new_means[(size_t)k * D + d] = v;
+    }
+  }
+}
+
 /* --------------------------------------------------------------- NES core */
 double fbo_np_sum(const double *a, int64_t n) {
   /* numpy pairwise_sum (loops_utils.h.src), contiguous float64, verified

@@ -99,6 +99,12 @@ double fbo_diag_gmm_loglikes(const float *gconsts, const float *means_invvars,
  * models: gconsts[M*C], means_invvars[M*C*D], inv_vars[M*C*D].
  * returns 0, or -(b+1) if utterance b has no voiced frames. tv_out[B] optional.
  * nthreads>1 uses OpenMP over utterances (CPU-baseline timing only). */
+/* enrolment (build_spk_models.py:184-216; gmm-global-est-map.cc:62-92): UBM posterior statistics of one
+ * utterance (returns its voiced-frame count, -1 if none) and the means-only MAP update */
+int fbo_gmm_acc_stats(const fbo_frontend_cfg *cfg, const int16_t *wav, int64_t n, const float *gc,
+                      const float *miv, const float *iv, int C, int D, double *occ, double *F);
+void fbo_map_update_means(const double *means, const double *occ, const double *F, int C, int D, double tau,
+                          double *new_means);
 int fbo_gmm_score_batch(const fbo_frontend_cfg *cfg, const int16_t *wav,
                         const int64_t *off, int B, const float *gconsts,
                         const float *means_invvars, const float *inv_vars,

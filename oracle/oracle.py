@@ -188,6 +188,34 @@ def gmm_score_batch(cfg, wavs, gconsts, miv, iv, nthreads=1):
     return raw, tv
 
 
+def gmm_acc_stats(cfg, wav, gconsts, miv, iv):
+    """UBM posterior statistics of one utterance: (occ[C], F[C,D], voiced frames)."""
+    gconsts = np.ascontiguousarray(gconsts, np.float32).reshape(-1)
+    miv = np.ascontiguousarray(miv, np.float32)
+    iv = np.ascontiguousarray(iv, np.float32)
+    Cn, D = miv.shape[-2:]
+    wav = np.ascontiguousarray(wav, np.int16)
+    occ = np.empty(Cn, np.float64)
+    F = np.empty((Cn, D), np.float64)
+    lib().fbo_gmm_acc_stats.restype = C.c_int
+    tv = lib().fbo_gmm_acc_stats(C.byref(cfg), _p(wav), C.c_int64(wav.size), _p(gconsts), _p(miv), _p(iv),
+                                 C.c_int(Cn), C.c_int(D), _p(occ), _p(F))
+    if tv <= 0:
+        raise RuntimeError("oracle: no voiced frames")
+    return occ, F, tv
+
+
+def map_update_means(means, occ, F, tau=10.0):
+    means = np.ascontiguousarray(means, np.float64)
+    Cn, D = means.shape
+    out = np.empty((Cn, D), np.float64)
+    lib().fbo_map_update_means.restype = None
+    lib().fbo_map_update_means(_p(means), _p(np.ascontiguousarray(occ, np.float64)),
+                               _p(np.ascontiguousarray(F, np.float64)), C.c_int(Cn), C.c_int(D),
+                               C.c_double(tau), _p(out))
+    return out
+
+
 def np_sum(a):
     a = np.ascontiguousarray(a, np.float64)
     return lib().fbo_np_sum(_p(a), C.c_int64(a.size))

@@ -97,3 +97,18 @@ def test_csi_site_filtering(tmp_path):
     un = AM.build_attack_list("CSI", "untargeted", model, str(tmp_path / "data" / "test-set"),
                               str(tmp_path / "data" / "illegal-set"), str(tmp_path / "a"), str(tmp_path / "c"))
     assert len(un) == n_ok and all(it["target"] is None for it in un)
+
+
+def test_evaluate_counterpart_on_site(tmp_path):
+    """fakebob_amd.evaluate (test.py counterpart): the three tasks of the GMM architecture on the synthetic site."""
+    from fakebob_amd import attack_main as AM
+    from fakebob_amd import evaluate as E
+    ids, ubm, spk = _site(tmp_path)
+    ml = AM.load_spk_models(str(tmp_path / "model"), ids, "gmm")
+    r = E.evaluate("gmm", ml, str(tmp_path / "pre-models"), str(tmp_path / "data" / "test-set"),
+                   str(tmp_path / "data" / "illegal-set"), group_prefix=str(tmp_path / "ev"))
+    assert set(r) == {"CSI", "SV", "OSI"}
+    assert 0.0 <= r["CSI"]["accuracy"] <= 100.0
+    for k in ("FRR", "FAR"):
+        assert 0.0 <= r["SV"][k] <= 100.0 and 0.0 <= r["OSI"][k] <= 100.0
+    assert 0.0 <= r["OSI"]["IER"] <= 100.0 and np.isfinite(r["SV"]["threshold"]) and np.isfinite(r["OSI"]["threshold"])
