@@ -254,8 +254,11 @@ __device__ __forceinline__ f32x16 fb_bx_item(const u32x4 *__restrict__ cur4, int
   return acc;
 }
 
+#ifndef FB_BX_OCC
+#define FB_BX_OCC 2
+#endif
 template <int NK, bool DUMP>
-__global__ __launch_bounds__(256, 2) void k_gmm_bx3(FbGmmDev g, const float *__restrict__ feats,
+__global__ __launch_bounds__(256, FB_BX_OCC) void k_gmm_bx3(FbGmmDev g, const float *__restrict__ feats,
                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
                                                     int rows_cap, float *__restrict__ part_m,
                                                     float *__restrict__ part_s) {
