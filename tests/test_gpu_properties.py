@@ -1,0 +1,101 @@
+"""Size-independent properties at BASELINE.json's full sizes (C = 2048, D = 72, 3 s @ 16 kHz, spd = 50), where
+the CPU oracle is too slow to be the checker: determinism, independence from batch composition and order,
+agreement between the scoring entry points, and invariants of the NES step."""
+import numpy as np
+import pytest
+
+from fakebob_amd.engine import Engine, nes_params
+from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _wav(utt, n=48000):
+    return (synthetic_audio(utt, n) * 32768.0).astype(np.int16)
+
+
+def test_gmm_scores_do_not_depend_on_batch_composition(engine, full_system):
+    ubm, spk = full_system
+    engine.load_gmm([ubm] + spk)
+    wavs = [_wav(0), _wav(1, 30000), _wav(2), _wav(3, 70000), _wav(4, 16000)]
+    raw_all, tv_all = engine.score_raw(wavs)
+    perm = [3, 0, 4, 2, 1]
+    raw_p, tv_p = engine.score_raw([wavs[i] for i in perm])
+    assert np.array_equal(raw_p, raw_all[perm]) and np.array_equal(tv_p, tv_all[perm])   # bit-identical
+    for i in (1, 3):
+        # a different batch size changes how the component range is chunked over the chip, i.e. the order of the
+        # float32 log-sum-exp partials: same numbers up to float32 rounding of a frame log-likelihood
+        raw_1, tv_1 = engine.score_raw([wavs[i]])
+        assert np.abs(raw_1[0] - raw_all[i]).max() <= 2e-6 and tv_1[0] == tv_all[i]
+    # float input in [-1, 1) is the same utterance as its int16 samples (gmm_ubm_OSI.py:83-85)
+    raw_f, _ = engine.score_raw([w.astype(np.float64) / 32768.0 for w in wavs[:2]])
+    raw_i, _ = engine.score_raw(wavs[:2])                       # same batch shape -> same chunking -> same bits
+    assert np.array_equal(raw_f, raw_i)
+
+
+def test_nes_iteration_is_deterministic_and_consistent_with_scoring(full_system):
+    ubm, spk = full_system
+    audio = synthetic_audio(7, 48000)
+    outs = []
+    for rep in range(2):
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            e.set_system("OSI")
+            p = nes_params("OSI", "targeted", samples_per_draw=50, target=2, threshold=0.1, seed=42, stream=3)
+            outs.append(e.get_grad(p, audio, it=5))
+            if rep == 0:
+                raw, _ = e.score_raw([(audio * 32768.0).astype(np.int16)])
+                score0 = raw[0, 1:] - raw[0, 0]
+        finally:
+            e.close()
+    (fl0, g0, al0, sc0), (fl1, g1, al1, sc1) = outs
+    assert fl0 == fl1 and al0 == al1 and np.array_equal(g0, g1) and np.array_equal(sc0, sc1)   # bit-identical reruns
+    assert np.abs(sc0[:5] - score0).max() <= 2e-6              # column 0 of the NES batch is the clean utterance
+    others = np.delete(sc0[:5], 2)
+    assert al0 == max(others.max(), 0.1) + 0.0 - sc0[2]         # OSI targeted loss of FAKEBOB.py:262 on those scores
+    assert np.all(np.isfinite(g0)) and np.abs(g0).max() > 0
+
+
+def test_attack_respects_the_linf_ball_and_reports_consistently(full_system):
+    ubm, spk = full_system
+    audio = synthetic_audio(9, 48000)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        e.set_system("OSI")
+        raw, _ = e.score_raw([(audio * 32768.0).astype(np.int16)])
+        sc = raw[0, 1:] - raw[0, 0]
+        target = int(np.argsort(sc)[-2])
+        p = nes_params("OSI", "targeted", samples_per_draw=50, max_iter=30, target=target, epsilon=0.002,
+                       threshold=float(sc.max()) - 0.02, seed=1, stream=0)
+        adv, flag, adv_f, trace = e.attack(p, audio)
+        adv2, flag2, adv_f2, trace2 = e.attack(p, audio)
+    finally:
+        e.close()
+    assert flag == flag2 and np.array_equal(adv, adv2) and np.array_equal(trace, trace2)      # deterministic
+    assert np.abs(adv_f - audio).max() <= 0.002 + 1e-15 and np.abs(adv_f).max() <= 1.0       # clip (:202-203)
+    assert np.array_equal(adv, np.trunc(adv_f * 32768.0).astype(np.int64).astype(np.int16))  # final int16 cast (:220)
+    n = trace.shape[0]
+    assert 1 <= n <= 30 and (flag == 1) == (n < 30 or trace[-1, 1] < 0 and n - 1 < 29)
+    assert np.all(np.diff(trace[:, 2]) <= 0)                    # the learning rate never grows
+    assert np.all(trace[:, 0] <= 0.002 + 1e-12)                 # reported distance stays inside the ball
+    if flag == 1:
+        assert trace[-1, 1] < 0 and np.all(trace[:-1, 1] >= 0)  # stops at the first iteration with loss[0] < 0
+
+
+def test_ivector_scores_do_not_depend_on_batch_composition():
+    sy = synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=2)
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        wavs = [_wav(0), _wav(1, 30000), _wav(2), _wav(3, 20000)]
+        llr_all, tv_all = e.score_raw(wavs)
+        perm = [2, 0, 3, 1]
+        llr_p, tv_p = e.score_raw([wavs[i] for i in perm])
+        assert np.array_equal(tv_p, tv_all[perm])
+        assert np.array_equal(llr_p, llr_all[perm])             # no atomics anywhere: bit-identical
+        llr_1, _ = e.score_raw([wavs[1]])
+        assert np.abs(llr_1[0] - llr_all[1]).max() <= 1e-6      # (other chunking of the diagonal pre-selection)
+    finally:
+        e.close()
