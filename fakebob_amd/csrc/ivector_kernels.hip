@@ -11,7 +11,7 @@
 //   k_gmm_bx3<NK,true>    diagonalised-UBM log-likelihoods of every component (gmm_kernels.hip)
 //   k_iv_select           per frame: top-n Gaussians (registers + DPP arg-max)
 //   k_iv_bucket_*         stable, atomic-free partition of the (frame, slot) pairs by component
-//   k_iv_fullcov_t        full-covariance log-likelihoods, component parameters as scalar operands
+//   k_iv_fullcov_lds      full-covariance log-likelihoods, component record broadcast from LDS
 //   k_iv_post             softmax + min-post pruning per frame
 //   k_iv_stats            zeroth / first order statistics per (component, utterance) from the buckets
 //   k_iv_active           list of the components with posterior mass
@@ -313,15 +313,20 @@ __global__ __launch_bounds__(256) void k_iv_fullcov(FbIvDev iv, const float *__r
   }
 }
 
-// Same numbers, D known at compile time: thread = (frame, slot) pair of the component's bucket, the
-// frame in registers (float64), and the component's packed precision matrix / linear term read through
-// wave-uniform addresses, i.e. scalar loads feeding v_fma_f64 as SGPR operands -- no LDS, no cross-lane
-// reduction.   1/2 x'Px = sum_r x_r (sum_{c<r} P_rc x_c + 1/2 P_rr x_r): D(D+1)/2 + D fma per pair.
+// Same numbers, D known at compile time: thread = (frame, slot) pair of the component's bucket with the
+// frame in registers (float64); the component's float64 record (packed precision matrix with halved
+// diagonal, linear term, gconst: fg64) is staged in LDS by one coalesced copy per workgroup and read back
+// as broadcasts -- no cross-lane reduction.  1/2 x'Px = sum_r x_r (sum_{c<r} P_rc x_c + 1/2 P_rr x_r):
+// D(D+1)/2 + D fma per pair; bound by the LDS issue rate.  (A version feeding the matrix through scalar
+// loads / SGPR operands waited on an L2 round trip every 16 entries -- the 21 KB record does not fit the
+// scalar cache -- and was 1.7x slower.)
 template <int D>
-__global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const float *__restrict__ feats,
-                                                           const int *__restrict__ bstart,
-                                                           const int *__restrict__ wstart,
-                                                           const int *__restrict__ pairs, float *__restrict__ llf) {
+__global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_lds(FbIvDev iv, const float *__restrict__ feats,
+                                                             const int *__restrict__ bstart,
+                                                             const int *__restrict__ wstart,
+                                                             const int *__restrict__ pairs, float *__restrict__ llf) {
+  constexpr int TRI = D * (D + 1) / 2, REC = TRI + D + 1;
+  __shared__ __attribute__((aligned(16))) double sP[(REC + 1) & ~1];
   const int n_work = wstart[iv.C];
   const int wi = blockIdx.x;
   if (wi >= n_work) return;
@@ -330,8 +335,11 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const flo
     const int mid = (lo + hi) >> 1;
     if (wstart[mid] <= wi) lo = mid; else hi = mid;
   }
-  const int k = __builtin_amdgcn_readfirstlane(lo);
-  constexpr int TRI = D * (D + 1) / 2;
+  const int k = lo;
+  {
+    const double *src = iv.fg64 + (size_t)k * REC;
+    for (int i = threadIdx.x; i < REC; i += FB_IV_CH) sP[i] = src[i];
+  }
   const int e0 = bstart[k] + (wi - wstart[k]) * FB_IV_CH;
   const int e1 = min(bstart[k + 1], e0 + FB_IV_CH);
   const int e = e0 + (int)threadIdx.x;
@@ -347,19 +355,13 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const flo
       x[4 * q] = (double)v.x; x[4 * q + 1] = (double)v.y; x[4 * q + 2] = (double)v.z; x[4 * q + 3] = (double)v.w;
     }
   }
-  const double *Pk = iv.fg64 + (size_t)k * (TRI + D + 1);  // uniform -> s_load
-  // the packed triangle is walked in chunks of 16 entries (two s_load_dwordx16): the next chunk is
-  // requested before the current one is consumed and a scheduling barrier keeps the compiler from
-  // hoisting more loads than the scalar register file holds
-  // The packed triangle is walked in chunks of 16 entries (two s_load_dwordx16 through inline asm, so
-  // the compiler can neither merge nor hoist them -- left to itself it requests the whole matrix up
-  // front and spills the scalar register file): chunk j+1 is requested, chunk j is consumed, then one
-  // s_waitcnt lgkmcnt(0) (scalar loads return out of order, there is no partial wait).  The outputs are
-  // early-clobber: the first load may land before the second one has read its address registers.
-  typedef double fb_d8 __attribute__((ext_vector_type(8)));
-  fb_d8 c0, c1, n0, n1;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(c0), "=&s"(c1) : "s"(Pk) : "memory");
+  __syncthreads();
+  // chunks of 16 entries: the next chunk is read while the current one is consumed; an empty asm that the
+  // accumulators pass through (with a memory clobber) keeps the compiler from hoisting the whole record
+  // into registers
+  double cur[16], nxt[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { cur[i] = sP[i]; nxt[i] = sP[16 + i]; }
   double half_quad = 0.0;
 #pragma unroll
   for (int r = 0; r < D; ++r) {
@@ -367,27 +369,24 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_t(FbIvDev iv, const flo
 #pragma unroll
     for (int c = 0; c <= r; ++c) {
       const int idx = r * (r + 1) / 2 + c;  // compile-time after unrolling
-      if ((idx & 15) == 0) {                // chunk boundary
-        if (idx > 0) {
-          // every fma of the finished chunk feeds one of these three values and every later one starts
-          // from them: routing them through an (empty) asm pins the chunk between the two loads
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(n1), "+v"(a0), "+v"(a1), "+v"(half_quad));
-          c0 = n0; c1 = n1;
-        }
-        if (idx + 16 < TRI) {  // request the next chunk (the record is padded, see fb_load_ivector)
-          const double *nx = Pk + idx + 16;
-          asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(n0), "=&s"(n1) : "s"(nx) : "memory");
+      if (idx > 0 && (idx & 15) == 0) {
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(half_quad) : : "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        if (idx + 16 < TRI) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) nxt[i] = sP[idx + 16 + i];  // (the record is longer than TRI: stays in bounds)
         }
       }
-      const double pv = (idx & 8) ? c1[idx & 7] : c0[idx & 7];
+      const double pv = cur[idx & 15];
       if (c & 1) a1 = fma(pv, x[c], a1); else a0 = fma(pv, x[c], a0);
     }
     half_quad = fma(x[r], a0 + a1, half_quad);
   }
   double lin = 0.0;
 #pragma unroll
-  for (int d = 0; d < D; ++d) lin = fma(Pk[TRI + d], x[d], lin);
-  if (ok) llf[pr] = (float)(Pk[TRI + D] + (lin - half_quad));
+  for (int d = 0; d < D; ++d) lin = fma(sP[TRI + d], x[d], lin);
+  if (ok) llf[pr] = (float)(sP[TRI + D] + (lin - half_quad));
 }
 
 // softmax over the nsel full-covariance log-likelihoods of a frame + min-post pruning: lane = slot
@@ -456,7 +455,7 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   const int n_pairs_cap = rows_cap * iv.nsel;
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
   if (iv.D == 72)
-    hipLaunchKernelGGL((k_iv_fullcov_t<72>), dim3(work_cap), dim3(FB_IV_CH), 0, s, iv, feats, bstart, wstart, pairs, llf);
+    hipLaunchKernelGGL((k_iv_fullcov_lds<72>), dim3(work_cap), dim3(FB_IV_CH), 0, s, iv, feats, bstart, wstart, pairs, llf);
   else if (iv.triD <= 42 * 64)
     hipLaunchKernelGGL((k_iv_fullcov<42>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);
   else
