@@ -176,11 +176,13 @@ __global__ __launch_bounds__(256) void k_iv_bucket_count(FbIvDev iv, const int *
   for (int i = threadIdx.x; i < Cpad; i += 256) cnt[(size_t)blockIdx.x * Cpad + i] = s_cnt[i];
 }
 // cnt[blk][k] -> pref[blk][k] = exclusive prefix over blk, hist[k] = total; then bstart[C+1] = exclusive scan of
-// hist and wstart[C+1] = exclusive scan of ceil(hist / FB_IV_CH).  Single workgroup.
+// hist and wstart[C+1] = exclusive scan of ceil(hist / FB_IV_CH); nz[0 .. nz[C]) = the non-empty buckets.
+// Single workgroup.
 __global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, int Cpad, int n_blk, const int *__restrict__ cnt,
                                                          int *__restrict__ pref, int *__restrict__ hist,
-                                                         int *__restrict__ bstart, int *__restrict__ wstart) {
-  __shared__ int sa[1024], sb[1024];
+                                                         int *__restrict__ bstart, int *__restrict__ wstart,
+                                                         int *__restrict__ nz) {
+  __shared__ int sa[1024], sb[1024], sc[1024];
   for (int k = threadIdx.x; k < C; k += 1024) {  // coalesced over k for every block; loads 8 blocks ahead
     int run = 0;
     int j = 0;
@@ -197,28 +199,25 @@ __global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, int Cpad, int n_
   __syncthreads();
   const int per = (C + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(C, lo + per);
-  int a = 0, bsum = 0;
-  for (int k = lo; k < hi; ++k) { a += hist[k]; bsum += (hist[k] + FB_IV_CH - 1) / FB_IV_CH; }
-  sa[threadIdx.x] = a;
-  sb[threadIdx.x] = bsum;
-  __syncthreads();
+  int a = 0, bsum = 0, nzc = 0;
+  for (int k = lo; k < hi; ++k) { a += hist[k]; bsum += (hist[k] + FB_IV_CH - 1) / FB_IV_CH; nzc += hist[k] > 0; }
   // exclusive scan of the 1024 partials: wave scans by shuffles + 16 wave totals
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int ia = a, ib = bsum;
+  int ia = a, ib = bsum, ic = nzc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64);
-    if (lane >= o) { ia += ua; ib += ub; }
+    const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64), uc = __shfl_up(ic, o, 64);
+    if (lane >= o) { ia += ua; ib += ub; ic += uc; }
   }
+  if (lane == 63) { sa[w] = ia; sb[w] = ib; sc[w] = ic; }
   __syncthreads();
-  if (lane == 63) { sa[w] = ia; sb[w] = ib; }
-  __syncthreads();
-  int ra = ia - a, rb = ib - bsum;
-  for (int i = 0; i < w; ++i) { ra += sa[i]; rb += sb[i]; }
-  if (threadIdx.x == 1023) { bstart[C] = ra + a; wstart[C] = rb + bsum; }
+  int ra = ia - a, rb = ib - bsum, rc = ic - nzc;
+  for (int i = 0; i < w; ++i) { ra += sa[i]; rb += sb[i]; rc += sc[i]; }
+  if (threadIdx.x == 1023) { bstart[C] = ra + a; wstart[C] = rb + bsum; nz[C] = rc + nzc; }
   for (int k = lo; k < hi; ++k) {
     bstart[k] = ra;
     wstart[k] = rb;
+    if (hist[k] > 0) nz[rc++] = k;  // ascending list of the non-empty buckets (-> k_iv_stats work items)
     ra += hist[k];
     rb += (hist[k] + FB_IV_CH - 1) / FB_IV_CH;
   }
@@ -426,17 +425,18 @@ __global__ __launch_bounds__(256) void k_iv_post(FbIvDev iv, const int *__restri
   if (lane < nsel) post[(size_t)row * nsel + lane] = p;
 }
 
-// bucket_ws (ints): hist[C], bstart[C+1], wstart[C+1], flags[C] (zero on entry, see k_iv_active),
+// bucket_ws (ints): hist[C], bstart[C+1], wstart[C+1], flags[C] (zero on entry, see k_iv_active), nz[C+1],
 // cnt[n_blk][Cpad], pref[n_blk][Cpad] with n_blk = ceil(rows_cap / FB_IV_FB)
 size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
-  return (size_t)4 * iv.C + 2 + (size_t)2 * ((rows_cap + FB_IV_FB - 1) / FB_IV_FB) * iv.Cpad;
+  return (size_t)5 * iv.C + 3 + (size_t)2 * ((rows_cap + FB_IV_FB - 1) / FB_IV_FB) * iv.Cpad;
 }
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
                               int *pairs, float *llf) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
-  int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *cnt = wstart + (C + 1) + C;
+  int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *nz = wstart + (C + 1) + C,
+      *cnt = nz + (C + 1);
   const int n_blk = (rows_cap + FB_IV_FB - 1) / FB_IV_FB;
   int *pref = cnt + (size_t)n_blk * iv.Cpad;
   {
@@ -450,7 +450,7 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
   hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
-  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist, bstart, wstart);
+  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist, bstart, wstart, nz);
   hipLaunchKernelGGL(k_iv_bucket_fill, dim3(n_blk), dim3(64), lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
   const int n_pairs_cap = rows_cap * iv.nsel;
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
@@ -466,38 +466,52 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
 // ------------------------------------------------------- statistics (K10a)
 // gamma[b][k] = sum_t post, X[b][k][:] = sum_t post * x_t, accumulated straight from the component's bucket:
 // the stable partition left its (frame, slot) pairs in (utterance, time) order, so the pairs of one
-// (component, utterance) are a contiguous run.  Workgroup = component (B + 1 parallel binary searches give
-// the runs), wave = utterance (16 at a time): the wave adds the frames of its run in order -- lane d owns
+// (component, utterance) are a contiguous run.  FB_IV_SSPLIT workgroups per component, wave = utterance
+// (64 in flight per component): the wave adds the frames of its run in order -- lane d owns
 // dimension d (and d + 64), float64, the same operations in the same order as a frame-major loop -- with
 // the feature rows of the next 16 pairs in flight.  Only the ~15 % of the Gaussians that were selected at all cost
 // anything; utterances without a pair of this component get explicit zeros (the contraction reads whole
 // rows of an active component).  flags[k] = 1 when any posterior is non-zero (-> k_iv_active).
-#define FB_IV_SG 16  // feature rows in flight per wave (two register buffers of this size)
-__global__ __launch_bounds__(1024) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
-                                                   const int *__restrict__ row_off, const int *__restrict__ pairs,
-                                                   const int *__restrict__ bstart, const float *__restrict__ post,
-                                                   int B, int Bpad, double *__restrict__ gammaT,
-                                                   double *__restrict__ XT, int *__restrict__ flags) {
-  extern __shared__ int s_seg[];  // [B + 1] first pair of every utterance inside the bucket
-  const int k = blockIdx.x, D = iv.D, nsel = iv.nsel;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int e0 = bstart[k], e1 = bstart[k + 1];
-  if (e0 >= e1) return;
-  // utterance boundaries: thread b does its own binary search (all B + 1 searches in parallel)
-  for (int b = threadIdx.x; b <= B; b += blockDim.x) {
-    const int key = row_off[b] * nsel;
-    int lo = e0, hi = e1;  // first index with pairs[idx] >= key
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (pairs[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    s_seg[b] = lo;
+__device__ __forceinline__ int fb_wave_lower_bound(const int *__restrict__ a, int lo, int hi, int key, int lane) {
+  // first index in [lo, hi) with a[idx] >= key (hi if none); a[] ascending; all lanes return the same value.
+  // 64 probes per round instead of one: a range of n elements needs ceil(log64 n) dependent loads.
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) / 64;
+    const int idx = lo + lane * step;
+    const int v = idx < hi ? a[idx] : 0x7fffffff;
+    const unsigned long long ge = __ballot(v >= key);
+    const int first = ge ? (int)__builtin_ctzll(ge) : 64;  // probes below `first` are < key
+    if (first == 0) return lo;
+    const int nhi = first == 64 ? hi : min(hi, lo + first * step);
+    lo = lo + (first - 1) * step + 1;
+    hi = nhi;
   }
-  __syncthreads();
+  const int idx = lo + lane;
+  const int v = idx < hi ? a[idx] : 0x7fffffff;
+  const unsigned long long ge = __ballot(v >= key);
+  return ge ? lo + (int)__builtin_ctzll(ge) : hi;
+}
+#define FB_IV_SG 16  // feature rows in flight per wave (two register buffers of this size)
+#define FB_IV_SSPLIT 16 // workgroups per component (utterances dealt round-robin): spreads the few very popular
+                        // components, whose buckets hold thousands of pairs, over several CUs
+__global__ __launch_bounds__(256) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
+                                                   const int *__restrict__ row_off, const int *__restrict__ pairs,
+                                                   const int *__restrict__ bstart, const int *__restrict__ nz,
+                                                   const float *__restrict__ post, int B, int Bpad,
+                                                   double *__restrict__ gammaT, double *__restrict__ XT,
+                                                   int *__restrict__ flags) {
+  const int D = iv.D, nsel = iv.nsel;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int n_items = nz[iv.C] * FB_IV_SSPLIT;  // work item = (non-empty bucket, utterance residue class)
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const int k = nz[item / FB_IV_SSPLIT], ys = item % FB_IV_SSPLIT;
+  const int e0 = bstart[k], e1 = bstart[k + 1];
   const bool two = lane + 64 < D;  // this lane also owns dimension lane + 64 (D <= 128)
   bool any = false;
-  for (int b = w; b < B; b += nw) {
-    const int s0 = s_seg[b], s1 = s_seg[b + 1];
+  for (int b = ys + FB_IV_SSPLIT * w; b < B; b += FB_IV_SSPLIT * nw) {
+    // the run of this utterance inside the bucket: two 64-ary searches (<= 3 dependent loads each)
+    const int s0 = fb_wave_lower_bound(pairs, e0, e1, row_off[b] * nsel, lane);
+    const int s1 = fb_wave_lower_bound(pairs, s0, e1, row_off[b + 1] * nsel, lane);
     double acc0 = 0.0, acc1 = 0.0, gam = 0.0;
     for (int c0 = s0; c0 < s1; c0 += 64) {
       const int n = min(64, s1 - c0);
@@ -544,13 +558,15 @@ __global__ __launch_bounds__(1024) void k_iv_stats(FbIvDev iv, const float *__re
     if (lane == 0) gammaT[(size_t)k * Bpad + b] = gam;
   }
   if (lane == 0 && any) flags[k] = 1;
+  }
 }
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT) {
   const int *bstart = bucket_ws + iv.C;
   int *flags = const_cast<int *>(bucket_ws) + 3 * (size_t)iv.C + 2;
-  hipLaunchKernelGGL(k_iv_stats, dim3(iv.C), dim3(1024), sizeof(int) * (size_t)(B + 1), s, iv, feats, row_off, pairs,
-                     bstart, post, B, Bpad, gammaT, XT, flags);
+  const int *nz = bucket_ws + 4 * (size_t)iv.C + 2;
+  hipLaunchKernelGGL(k_iv_stats, dim3(2048), dim3(256), 0, s, iv, feats, row_off, pairs, bstart, nz, post, B, Bpad,
+                     gammaT, XT, flags);
 }
 
 // ---------------------------------------------- T-matrix contraction (K10b)
