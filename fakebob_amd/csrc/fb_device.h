@@ -119,6 +119,27 @@ __device__ __forceinline__ double fb_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// A float32 score as the reference sees it after Kaldi's text output (6 significant digits, operator<<)
+// and Python's float(): nearest double of the 6-digit decimal.  Exact powers of ten from a table and one
+// correctly rounded division, so host (oracle) and device agree bit for bit.
+__host__ __device__ inline double fb_round6(double xin) {
+  const double x = (double)(float)xin;
+  if (x == 0.0 || !(x == x) || x - x != 0.0) return x;
+  const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                          1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const double ax = x < 0.0 ? -x : x;
+  int e = 0;  // 10^e <= ax < 10^(e+1)
+  if (ax >= 1.0) { while (e < 21 && ax >= p10[e + 1]) ++e; }
+  else { while (e > -16 && ax * p10[-e] < 1.0) --e; }
+  const int k = 5 - e;  // scale to 6 integer digits
+  double scaled = k >= 0 ? ax * p10[k > 22 ? 22 : k] : ax / p10[-k];
+  double r = rint(scaled);
+  int kk = k;
+  if (r >= 1e6) { r = rint(r / 10.0); kk -= 1; }
+  const double v = kk >= 0 ? r / p10[kk > 22 ? 22 : kk] : r * p10[-kk];
+  return x < 0.0 ? -v : v;
+}
+
 // DPP row/bank reductions (VALU data path, no LDS round trips): after the six steps lane 63 holds
 // the wave total, which is broadcast through a scalar register.  Summation order: pairs, quads,
 // half rows, rows (lanes of a 16-lane row), then rows 0+1 / 2+3, then halves -- fixed, so the

@@ -176,6 +176,7 @@ extern "C" void fb_default_frontend(fb_frontend_cfg *c) {
   c->use_energy = 1; c->raw_energy = 1; c->energy_floor = 0.0;
   c->vad_energy_threshold = 5.5; c->vad_energy_mean_scale = 0.5; c->vad_proportion_threshold = 0.12;
   c->vad_frames_context = 2; c->delta_window = 3; c->delta_order = 2; c->cmn_window = 300;
+  c->text_scores = 0;
 }
 
 static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
@@ -295,6 +296,8 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, e->melw_n)) > 150 * 1024)
     return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
   e->cfg = *c;
+  e->gmm.text_scores = c->text_scores;
+  e->iv.text_scores = c->text_scores;
   e->have_fe = true;
   e->cached_B = -1;
   if (e->have_gmm && e->gmm.D != dim) e->have_gmm = false;
@@ -416,6 +419,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.M = M; g.C = C; g.D = D; g.KH = KH; g.n_tiles = n_tiles; g.n_items = n_items; g.img_floats = IMGF;
   g.images = e->gmm_images.as<float>();
   g.mode = mode; g.NK = NK;
+  g.text_scores = e->cfg.text_scores;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
   g.item_model = e->gmm_items.as<int>();
   e->n_groups = G;
@@ -952,6 +956,7 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
   // the bucket workspace is laid out by C: a different system must not inherit stale `flags`
   if (e->iv_bws.p) HIPCHK(hipMemset(e->iv_bws.p, 0, e->iv_bws.cap));
   FbIvDev &iv = e->iv;
+  iv.text_scores = e->cfg.text_scores;
   iv.C = C; iv.Cpad = e->gmm.n_tiles * 32; iv.D = D; iv.R = R; iv.L = L; iv.S = S; iv.lda_cols = sy->lda_cols;
   iv.nsel = sy->num_gselect; iv.triD = triD; iv.triR = triR; iv.min_post = (float)sy->min_post;
   iv.prior_offset = sy->prior_offset;

@@ -106,6 +106,7 @@ struct FbGmmDev {
   int mode, NK;
   const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
+  int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
 #define FB_GMM_MODE_F32 0
 #define FB_GMM_MODE_BX3 1
@@ -127,6 +128,7 @@ void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_
 struct FbIvDev {
   int C, Cpad, D, R, L, S, lda_cols, nsel, triD, triR;
   float min_post;
+  int text_scores;              // see fb_frontend_cfg
   double prior_offset;
   const float *fg_gconsts;      // [C]
   const float *fg_mic;          // [C][D]   means_invcovars

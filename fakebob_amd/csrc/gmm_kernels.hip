@@ -482,7 +482,9 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
   }
   if (threadIdx.x == 0) {
     const int tv = r1 - r0;
-    raw[(size_t)b * g.M + m] = tv > 0 ? red[0] / (double)tv : __longlong_as_double(0x7ff8000000000000ll);
+    double avg = tv > 0 ? red[0] / (double)tv : __longlong_as_double(0x7ff8000000000000ll);
+    if (g.text_scores && tv > 0) avg = fb_round6(avg);
+    raw[(size_t)b * g.M + m] = avg;
   }
 }
 

@@ -1061,8 +1061,10 @@ __global__ __launch_bounds__(256) void k_iv_backend(FbIvDev iv, const double *__
     }
     given = fb_block_sum(given, red);
     without = fb_block_sum(without, red);
-    if (tid == 0)
-      llr[(size_t)b * S + s] = -0.5 * (given + LOG2PI * L) - (-0.5 * (without + LOG2PI * L));
+    if (tid == 0) {
+      const double sc_ = -0.5 * (given + LOG2PI * L) - (-0.5 * (without + LOG2PI * L));
+      llr[(size_t)b * S + s] = iv.text_scores ? fb_round6(sc_) : sc_;  // ivector-plda-scoring writes text
+    }
   }
 }
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr) {

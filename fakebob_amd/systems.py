@@ -43,11 +43,14 @@ class _GmmSystem(object):
         self.n_speakers = len(spk_ids)
         self._engine = engine if engine is not None else Engine(default_device())
         conf = os.path.join(self.pre_model_dir, "conf")
+        over = {}
         if os.path.isdir(conf):
             from .config import frontend_from_kaldi_conf
             over = frontend_from_kaldi_conf(self.pre_model_dir)
-            if over:
-                self._engine.set_frontend(**over)
+        if os.environ.get("FB_TEXT_SCORES", "0") == "1":   # reproduce the 6-digit text round trip of Kaldi's scores
+            over = dict(over, text_scores=1)
+        if over:
+            self._engine.set_frontend(**over)
         self._engine.load_gmm(models)
         self._engine.set_system(self.task, z_means, z_stds)
 
@@ -178,11 +181,14 @@ class _IvSystem(object):
         enrolled = np.stack([read_ivector_location(x) for x in locs])
         if system is None:
             conf = os.path.join(self.pre_model_dir, "conf")
+            over = {}
             if os.path.isdir(conf):
                 from .config import frontend_from_kaldi_conf
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
-                if over:
-                    self._engine.set_frontend(**over)
+            if os.environ.get("FB_TEXT_SCORES", "0") == "1":
+                over = dict(over, text_scores=1)
+            if over:
+                self._engine.set_frontend(**over)
             d = load_ivector_pre_models(self.pre_model_dir)
             system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
         else:

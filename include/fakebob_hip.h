@@ -74,6 +74,11 @@ typedef struct {
   int delta_window;
   int delta_order;
   int cmn_window;
+  /* 0 (default): scores keep full precision.  1: emulate the text round trip of the reference -- Kaldi prints
+   * every score as a float with 6 significant digits (`ark,t` / score files) and the helpers parse that text
+   * (gmm_ubm_kaldiHelper.py:236-248, ivector_PLDA_kaldiHelper.py:310-338): raw scores are rounded to float32
+   * and then to 6 significant decimal digits before any post-processing. */
+  int text_scores;
 } fb_frontend_cfg;
 
 /* FakeBob hyper-parameters (FAKEBOB.py:21-37) + attack() arguments (:139) +

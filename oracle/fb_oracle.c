@@ -49,6 +49,7 @@ void fbo_default_cfg(fbo_frontend_cfg *c) {
   c->delta_window = 3;
   c->delta_order = 2;
   c->cmn_window = 300;
+  c->text_scores = 0;
 }
 
 /* --------------------------------------------------------------- Philox */
@@ -441,6 +442,26 @@ int fbo_frontend(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float
   return tv;
 }
 
+/* Kaldi text output of a float score (6 significant digits) read back by float(): identical arithmetic to
+ * fb_round6 in fakebob_amd/csrc/fb_device.h (table of exact powers of ten + one correctly rounded division) */
+double fbo_round6(double xin) {
+  const double x = (double)(float)xin;
+  if (x == 0.0 || !(x == x) || x - x != 0.0) return x;
+  static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const double ax = x < 0.0 ? -x : x;
+  int e = 0;
+  if (ax >= 1.0) { while (e < 21 && ax >= p10[e + 1]) ++e; }
+  else { while (e > -16 && ax * p10[-e] < 1.0) --e; }
+  const int k = 5 - e;
+  double scaled = k >= 0 ? ax * p10[k > 22 ? 22 : k] : ax / p10[-k];
+  double r = rint(scaled);
+  int kk = k;
+  if (r >= 1e6) { r = rint(r / 10.0); kk -= 1; }
+  const double v = kk >= 0 ? r / p10[kk > 22 ? 22 : kk] : r * p10[-kk];
+  return x < 0.0 ? -v : v;
+}
+
 /* -------------------------------------- gmm-global-get-frame-likes [EXT] */
 double fbo_diag_gmm_loglikes(const float *gc, const float *miv, const float *iv, int C, int D,
                              const float *feats, int Tv, float *ll_out) {
@@ -494,7 +515,7 @@ int fbo_gmm_score_batch(const fbo_frontend_cfg *c, const int16_t *wav, const int
       for (int m = 0; m < M; ++m) {
         double tot = fbo_diag_gmm_loglikes(gc + (size_t)m * C, miv + (size_t)m * C * D,
                                            iv + (size_t)m * C * D, C, D, feats, tv, NULL);
-        raw[(size_t)b * M + m] = tot / tv;
+        raw[(size_t)b * M + m] = c->text_scores ? fbo_round6(tot / tv) : tot / tv;
       }
     }
     free(feats);
@@ -1021,7 +1042,10 @@ int fbo_iv_score_batch(const fbo_iv_system *s, const int16_t *wav, const int64_t
       }
       if (ivecs_out) memcpy(ivecs_out + (size_t)b * R, iv, sizeof(double) * R);
       fbo_iv_backend(s, iv, y);
-      for (int j = 0; j < S; ++j) llr[(size_t)b * S + j] = fbo_plda_llr(s, s->train + (size_t)j * L, y);
+      for (int j = 0; j < S; ++j) {
+        const double v = fbo_plda_llr(s, s->train + (size_t)j * L, y);
+        llr[(size_t)b * S + j] = s->cfg.text_scores ? fbo_round6(v) : v;  /* ivector-plda-scoring writes text */
+      }
       free(gamma); free(X); free(iv); free(y);
     }
     free(feats);

@@ -58,7 +58,11 @@ typedef struct {
   int delta_window;         /* 3 */
   int delta_order;          /* 2 */
   int cmn_window;           /* 300, center=true, norm-vars=false */
+  int text_scores;          /* 0; 1 = scores through Kaldi's 6-significant-digit text output */
 } fbo_frontend_cfg;
+
+/* float32 value printed with 6 significant digits and parsed back (std::ostream << float; float(text)) */
+double fbo_round6(double x);
 
 void fbo_default_cfg(fbo_frontend_cfg *cfg);
 

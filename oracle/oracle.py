@@ -27,7 +27,7 @@ class FrontendCfg(C.Structure):
         ("use_energy", C.c_int), ("raw_energy", C.c_int), ("energy_floor", C.c_double),
         ("vad_energy_threshold", C.c_double), ("vad_energy_mean_scale", C.c_double),
         ("vad_proportion_threshold", C.c_double), ("vad_frames_context", C.c_int),
-        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int),
+        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int),
     ]
 
 
@@ -214,6 +214,11 @@ def map_update_means(means, occ, F, tau=10.0):
                                _p(np.ascontiguousarray(F, np.float64)), C.c_int(Cn), C.c_int(D),
                                C.c_double(tau), _p(out))
     return out
+
+
+def round6(x):
+    lib().fbo_round6.restype = C.c_double
+    return float(lib().fbo_round6(C.c_double(float(x))))
 
 
 def np_sum(a):

@@ -93,3 +93,29 @@ def test_attack_is_independent_of_the_queue_depth(monkeypatch, batch):
     assert np.array_equal(got[0], ref[0])            # int16 adversarial audio
     assert np.array_equal(got[2], ref[2])            # float64 adversarial audio (bit-identical)
     assert np.array_equal(got[3], ref[3])            # trace rows (bit-identical)
+
+
+def test_text_scores_option_matches_the_oracle_and_quantises(oracle):
+    """fb_frontend_cfg.text_scores: raw scores go through Kaldi's 6-significant-digit text output, as the
+    reference's helpers read them; the device rounding is bit-identical to the oracle's."""
+    cfg = oracle.default_cfg(text_scores=1)
+    e = Engine(0)
+    try:
+        e.set_frontend(text_scores=1)
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
+        e.load_gmm([ubm] + spk)
+        wavs = [_wav(0, 24000), _wav(1, 16000), _wav(2, 40000)]
+        raw_g, _ = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=4)
+        for v in raw_g.reshape(-1):
+            assert v == float("%.6g" % v)                       # 6 significant digits survive a text round trip
+        # both sides round the same way; a score within float rounding of a 6-digit tie may land on either side
+        assert np.mean(raw_g == raw_o) >= 0.8 and np.abs(raw_g - raw_o).max() <= 1.1e-3
+        e.set_frontend(text_scores=0)
+        e.load_gmm([ubm] + spk)
+        raw_full, _ = e.score_raw(wavs)
+        assert np.abs(raw_full - raw_g).max() <= 6e-4            # |scores| ~ 1e2 -> 3 decimals kept
+        assert np.any(raw_full != raw_g)
+    finally:
+        e.close()

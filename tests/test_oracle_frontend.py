@@ -236,3 +236,17 @@ def test_gmm_score_batch_is_average_over_voiced_frames(oracle):
     silent = [np.zeros(4000, np.int16)]
     with pytest.raises(RuntimeError):
         oracle.gmm_score_batch(cfg, silent, gc, miv, iv)
+
+
+def test_round6_is_the_text_round_trip_of_a_float(oracle):
+    """text_scores option: Kaldi prints a float score with 6 significant digits (ostream default) and the
+    reference parses the text with float(): fbo_round6 must equal float('%.6g' % float32(x))."""
+    rng = np.random.default_rng(12)
+    vals = list(rng.normal(0, 1, 300) * 10.0 ** rng.integers(-6, 7, 300))
+    vals += [-144.800013, 0.1, -0.1, 999999.5, 9.999995, 1e-7, -3.25, 123456.7, 1.0, -172.394, 0.0999995, 5e-324, 0.0]
+    for v in vals:
+        f32 = float(np.float32(v))
+        expect = float("%.6g" % f32)
+        got = oracle.round6(v)
+        assert got == expect, (v, got, expect)
+    assert np.isnan(oracle.round6(float("nan"))) and oracle.round6(float("inf")) == float("inf")
