@@ -27,6 +27,7 @@
 #include <float.h>
 
 #include "fb_device.h"
+#include <cstdlib>
 #include "fb_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -261,13 +262,26 @@ template <int NK, bool DUMP>
 __global__ __launch_bounds__(256, FB_BX_OCC) void k_gmm_bx3(FbGmmDev g, const float *__restrict__ feats,
                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
                                                     int rows_cap, float *__restrict__ part_m,
-                                                    float *__restrict__ part_s) {
+                                                    float *__restrict__ part_s, int xcd_map) {
   if (g.stop && *g.stop) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int IMG4 = 3 * NK * 64;  // 16-byte units per item
   constexpr int NST = (IMG4 + 255) / 256;
   const int n_rows = *n_rows_ptr;
-  const int strip0 = blockIdx.x * 128;
+  // XCD-aware tile mapping: workgroups go round-robin to the 8 XCDs by linear id; all workgroups of one
+  // component chunk are sent to the same XCD(s), so each XCD's L2 holds 1/n_chunks of the parameter images
+  // instead of all of them (xcd_map: n_chunks divides 8, see the launcher).
+  int strip_i, chunk_i;
+  if (xcd_map) {
+    const int lin = blockIdx.x, nch = xcd_map, per = 8 / nch;   // XCDs per chunk
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 128;
   if (strip0 >= n_rows) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256, FB_BX_OCC) void k_gmm_bx3(FbGmmDev g, const fl
   }
   for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
 
-  const int tile0 = blockIdx.y * tiles_per_chunk;
+  const int tile0 = chunk_i * tiles_per_chunk;
   const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
   const int total_items = (tile1 - tile0) * g.n_items;
   const u32x4 *gimg = g.images_bx + (size_t)tile0 * g.n_items * IMG4;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256, FB_BX_OCC) void k_gmm_bx3(FbGmmDev g, const fl
     const float mx = fmaxf(mm, m2);
     const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
     if (h == 0 && row < n_rows) {
-      const size_t o = ((size_t)blockIdx.y * g.M + m) * rows_cap + row;
+      const size_t o = ((size_t)chunk_i * g.M + m) * rows_cap + row;
       part_m[o] = mx;
       part_s[o] = sx;
     }
@@ -389,10 +403,18 @@ __global__ __launch_bounds__(256, FB_BX_OCC) void k_gmm_bx3(FbGmmDev g, const fl
 template <int NK, bool DUMP>
 static void launch_gmm_bx_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                             int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
-  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
+  const int strips = (rows_cap + 127) / 128;
+  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  int xcd_map = 0;
+  static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
+  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
+    const int per = 8 / n_chunks;  // XCDs serving one component chunk
+    grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
+    xcd_map = n_chunks;
+  }
   const size_t ldsb = (size_t)2 * 3 * NK * 64 * 16 + (size_t)2 * g.M * 256 * sizeof(float);
   hipLaunchKernelGGL((k_gmm_bx3<NK, DUMP>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap,
-                     part_m, part_s);
+                     part_m, part_s, xcd_map);
 }
 template <bool DUMP>
 static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
