@@ -1,0 +1,141 @@
+"""BASELINE.json configs[3] and configs[4] as parity cases (they are not bench lines):
+
+  configs[3]  GMM-UBM CSI untargeted, many concurrent utterances sharded over streams/ranks
+  configs[4]  i-vector-PLDA OSI, 10 enrolled speakers, samples_per_draw=200 (B = 201), threshold
+              estimation first (FAKEBOB.py:39-137), then the attack
+
+At oracle-sized models the device path is compared with the CPU oracle iteration by iteration; at the
+full sizes (C=2048, R=400, B=201) through size-independent properties: bit-determinism, the consistency
+of an NES iteration with plain scoring, and the threshold sweep's invariants."""
+import numpy as np
+import pytest
+
+from fakebob_amd.engine import Engine, nes_params
+from fakebob_amd.models import synthetic_audio, synthetic_gmm_system, synthetic_ivector_system
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4
+
+
+def _wav(utt, n=48000):
+    return (synthetic_audio(utt, n) * 32768.0).astype(np.int16)
+
+
+@pytest.fixture(scope="module")
+def iv10():
+    sy = synthetic_ivector_system(C=128, D=72, R=64, L=32, n_speakers=10, seed=23)
+    zm = np.linspace(-40.0, -20.0, 10)
+    zs = np.linspace(4.0, 9.0, 10)
+    return sy.with_enrolled(sy.enrolled, z_mean=list(zm), z_std=list(zs))
+
+
+def test_config4_iv_osi_10_speakers_spd200_get_grad_parity(engine, oracle, iv10):
+    engine.load_ivector(iv10, "OSI")
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), iv10, nthreads=8)
+    assert ctx.S == 10
+    audio = synthetic_audio(31, 16000)
+    s0 = ctx.score(audio[:, None])[0]
+    kw = dict(samples_per_draw=200, target=7, threshold=float(np.sort(s0)[-2]))
+    pg = nes_params("OSI", "targeted", seed=5, stream=2, **kw)
+    po = oracle.nes_params("OSI", "targeted", ctx.S, **kw)
+    flg, gg, alg, scg = engine.get_grad(pg, audio, it=1)
+    flo, go, alo, sco = oracle.get_grad(po, ctx.fn, ctx.ctx, audio, seed=5, it=1, stream=2)
+    assert abs(alg - alo) <= SCORE_TOL and abs(flg - flo) <= SCORE_TOL
+    assert np.abs(scg[:10] - sco).max() <= SCORE_TOL
+    assert np.abs(gg - go).max() <= SCORE_TOL * 6.0 / pg.sigma
+
+
+def test_config4_iv_osi_threshold_estimation_then_attack_parity(engine, oracle, iv10):
+    engine.load_ivector(iv10, "OSI")
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), iv10, nthreads=8)
+    audio = synthetic_audio(32, 16000)
+    s0 = float(ctx.score(audio[:, None])[0].max())
+    model_thr = s0 + 0.05
+    kw = dict(samples_per_draw=20, epsilon=0.002)
+    pg = nes_params("OSI", "targeted", seed=13, stream=4, **kw)
+    po = oracle.nes_params("OSI", "targeted", ctx.S, **kw)
+    rg = engine.estimate_threshold(pg, model_thr, audio, max_total_iters=30)
+    ro = oracle.estimate_threshold(po, model_thr, ctx.fn, ctx.ctx, audio, max_total_iters=30, seed=13, stream=4)
+    assert rg[1] == ro[1] and rg[2] == ro[2]
+    assert abs(rg[0] - ro[0]) <= SCORE_TOL and abs(rg[3] - ro[3]) <= SCORE_TOL
+    # ... then the attack proper with the estimated threshold (attackMain.py:393-397)
+    kw = dict(samples_per_draw=20, max_iter=4, target=3, threshold=float(ro[0]))
+    pg = nes_params("OSI", "targeted", seed=13, stream=5, **kw)
+    po = oracle.nes_params("OSI", "targeted", ctx.S, **kw)
+    adv_g, flag_g, _, tr_g = engine.attack(pg, audio)
+    adv_o, flag_o, _, tr_o = oracle.attack(po, ctx.fn, ctx.ctx, audio, seed=13, stream=5)
+    assert flag_g == flag_o and tr_g.shape == tr_o.shape
+    assert np.abs(tr_g - tr_o).max() <= SCORE_TOL
+    assert np.mean(adv_g != adv_o) < 1e-3
+
+
+def test_config4_full_size_b201_properties():
+    """C=2048, R=400, S=10, B=201, 3 s utterances: one NES iteration is bit-deterministic and its
+    unperturbed column equals plain scoring of the int16 audio."""
+    sy = synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=10)
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        audio = synthetic_audio(33, 48000)
+        p = nes_params("OSI", "untargeted", samples_per_draw=200, threshold=0.0, seed=9, stream=1)
+        a = e.get_grad(p, audio, it=0)
+        b = e.get_grad(p, audio, it=0)
+        assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+        assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
+        llr, tv = e.score_raw([(audio * 32768.0).astype(np.int16)])
+        sc = e.system_scores(llr)
+        assert tv[0] > 0 and np.abs(sc[0] - a[3][:10]).max() <= 1e-6
+        # untargeted OSI loss of the clean audio: threshold + kappa - max_j s_j   (FAKEBOB.py:265-269)
+        assert abs(a[2] - (0.0 - sc[0].max())) <= 1e-6
+        # the sweep: a finite estimate at or above the benign maximum, identical when repeated
+        r1 = e.estimate_threshold(p, float(sc[0].max()) + 0.01, audio, max_total_iters=12)
+        r2 = e.estimate_threshold(p, float(sc[0].max()) + 0.01, audio, max_total_iters=12)
+        assert r1[1] >= 1 and np.isfinite(r1[0]) and r1[0] >= float(sc[0].max())
+        assert r1[:4] == r2[:4] and np.array_equal(r1[4], r2[4])
+    finally:
+        e.close()
+
+
+def test_config3_gmm_csi_untargeted_concurrent_utterances_match_sequential():
+    """64 utterances in the baseline; 6 here, attacked on 3 engines driven by 3 host threads: every result
+    equals the one-at-a-time result bit for bit (Philox stream = utterance index, no shared state)."""
+    import threading
+    ubm, spk = synthetic_gmm_system(5, 2048, 72)
+    zm = np.full(5, -160.0)
+    zs = np.linspace(1.0, 2.0, 5)
+    audios = [synthetic_audio(40 + u, 32000 + 1600 * u) for u in range(6)]
+
+    def make():
+        e = Engine(0)
+        e.load_gmm(spk)
+        e.set_system("CSI", zm, zs)
+        return e
+
+    def run(e, u):
+        sc = e.system_scores(e.score_raw([(audios[u] * 32768.0).astype(np.int16)])[0])[0]
+        p = nes_params("CSI", "untargeted", samples_per_draw=50, max_iter=5, true=int(np.argmax(sc)), seed=77, stream=u + 1)
+        adv, flag, _, tr = e.attack(p, audios[u])
+        return adv, flag, tr
+
+    e0 = make()
+    try:
+        seq = [run(e0, u) for u in range(6)]
+    finally:
+        e0.close()
+    engines = [make() for _ in range(3)]
+    out = [None] * 6
+
+    def worker(k):
+        for u in range(k, 6, 3):
+            out[u] = run(engines[k], u)
+
+    try:
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    finally:
+        [e.close() for e in engines]
+    for u in range(6):
+        assert out[u] is not None and out[u][1] == seq[u][1]
+        assert np.array_equal(out[u][0], seq[u][0]) and np.array_equal(out[u][2], seq[u][2])
+        assert 1 <= out[u][2].shape[0] <= 5
