@@ -139,8 +139,8 @@ def bench_ivector(args, torch):
         e.close()
 
 
-GMM_BX3 = os.environ.get("FB_GMM_MODE", "bx3") != "f32"
-GMM_TRAFFIC_KEY = "k_gmm_bx3<5, false>" if GMM_BX3 else "k_gmm<36, false>"
+GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
+GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2<5, false>", "bx3": "k_gmm_bx3<5, false>", "f32": "k_gmm<36, false>"}[GMM_MODE]
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (MI355X_MICROARCH.md)
 # bf16 32x32x16 chain on random operands, this chip, scratch/bx_probe.hip: the clock drops to ~1.6 GHz
 # under a saturated bf16 matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
@@ -153,7 +153,17 @@ def _gmm_roofline(achieved, flops_launch, gmm_ms_avg):
     r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": gmm_ms_avg,
          "algorithmic_flops_per_launch": flops_launch}
-    if GMM_BX3:
+    if GMM_MODE == "fx2":
+        nk = (D_FEAT + 1 + 15) // 16
+        ex = flops_launch * shared * 3 * (16.0 * nk / D_FEAT)
+        ex_t = ex / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
+        r.update({"kernel": "k_gmm_fx2<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term "
+                            "f16 split accurate to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, "
+                            "f32 accumulate)",
+                  "executed_flops_per_launch": ex, "executed_tflops": ex_t, "executed_pipe": "f16 MFMA",
+                  "executed_frac": ex_t / PEAK_BF16_MFMA_TFLOPS,
+                  "executed_frac_of_power_limited_ceiling": ex_t / BF16_MFMA_POWER_LIMITED_TFLOPS})
+    elif GMM_MODE == "bx3":
         nk = (D_FEAT + 3 + 15) // 16
         ex = flops_launch * shared * 6 * (16.0 * nk / D_FEAT)
         ex_t = ex / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
@@ -257,7 +267,9 @@ def main():
             "metric": "NES iterations/sec (and scored-utts/sec) at samples_per_draw=50, 3 s@16 kHz",
             "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)" if GMM_BX3 else "f32 (MFMA f32 GMM; f64 front-end/NES)",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; f64 front-end/NES)",
+                                                                   "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)",
+                                                                   "f32": "f32 (MFMA f32 GMM; f64 front-end/NES)"}[GMM_MODE],
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS,
@@ -271,8 +283,9 @@ def main():
             # length-D dot products per component per model, as Kaldi evaluates them in float32).  The
             # kernel (a) shares the quadratic term across the 6 models (mean-only MAP adaptation):
             # (1 + M)/(2M) = 7/12 of those products are executed, and (b) by default evaluates each
-            # f32 product on the bf16 matrix pipe as 6 exact partial products of a 3-way bf16 split
-            # (k_gmm_bx3, f32-equivalent accuracy; FB_GMM_MODE=f32 selects the plain f32-MFMA kernel).
+            # f32 product on the f16 matrix pipe as 3 partial products of a two-term f16 split
+            # (k_gmm_fx2, f32-equivalent accuracy; FB_GMM_MODE=bx3 selects the exact 3-way bf16 split
+            # with 6 partial products, FB_GMM_MODE=f32 the plain f32-MFMA kernel).
             # `peak` is the MFMA peak of the path's arithmetic type (f32: 157.3 TF) so `frac` can
             # exceed 1; `executed_*` give the honest utilisation of the pipe the instructions run on.
             "roofline": dict(_gmm_roofline(achieved, flops_launch, gmm_ms_avg),

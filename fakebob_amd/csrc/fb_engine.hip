@@ -85,7 +85,7 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_images, gmm_items, gmm_images_bx;
+  DevBuf gmm_images, gmm_items, gmm_images_bx, gmm_images_fx;
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
@@ -149,7 +149,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
@@ -368,7 +368,68 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // bf16x3 images (k_gmm_bx3): exact 3-way bf16 split of every parameter, gconst in the K padding
   const int NK = (D + 3 + 15) / 16 < 3 ? 3 : (D + 3 + 15) / 16;  // kernels are instantiated for NK = 3..6 (zero padding is free)
   const char *mode_env = getenv("FB_GMM_MODE");
-  const int mode = (mode_env && strcmp(mode_env, "f32") == 0) ? FB_GMM_MODE_F32 : FB_GMM_MODE_BX3;
+  int mode = FB_GMM_MODE_FX2;
+  if (mode_env && strcmp(mode_env, "f32") == 0) mode = FB_GMM_MODE_F32;
+  else if (mode_env && strcmp(mode_env, "bx3") == 0) mode = FB_GMM_MODE_BX3;
+  else if (mode_env && *mode_env && strcmp(mode_env, "fx2") != 0)
+    return fb_fail(FB_E_ARG, "FB_GMM_MODE must be fx2, bx3 or f32 (got '%s')", mode_env);
+  // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
+  // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
+  const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
+  int sq_shift = 0;
+  if (mode == FB_GMM_MODE_FX2) {
+    const float lim = 32768.0f;
+    float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
+    bool finite = true;
+    for (size_t i = 0; i < (size_t)M * C * D; ++i) {
+      max_q = std::max(max_q, 0.5f * fabsf(iv[i]));
+      max_l = std::max(max_l, fabsf(miv[i]));
+      finite = finite && std::isfinite(iv[i]) && std::isfinite(miv[i]);
+    }
+    for (size_t i = 0; i < (size_t)M * C; ++i) {
+      max_g = std::max(max_g, fabsf(gconsts[i]));
+      finite = finite && std::isfinite(gconsts[i]);
+    }
+    if (!finite || max_l >= lim || max_g >= lim || max_q >= lim || NKF > 6) {
+      mode = FB_GMM_MODE_BX3;
+    } else {
+      while (sq_shift < 8 && max_q * (float)(2 << sq_shift) < lim) ++sq_shift;
+    }
+  }
+  if (mode == FB_GMM_MODE_FX2) {
+    const size_t per_item = (size_t)2 * NKF * 64 * 8;  // f16 values
+    std::vector<uint16_t> fx((size_t)n_tiles * n_items * per_item, 0);
+    auto split2 = [](float v, uint16_t out[2]) {
+      const _Float16 a = (_Float16)v;  // round to nearest even
+      const float r = (v - (float)a) * 4096.0f;  // exact
+      const _Float16 b = (_Float16)r;
+      memcpy(&out[0], &a, 2);
+      memcpy(&out[1], &b, 2);
+    };
+    const float qscale = -0.5f * (float)(1 << sq_shift);
+    for (int t = 0; t < n_tiles; ++t)
+      for (int it = 0; it < n_items; ++it) {
+        uint16_t *im = &fx[((size_t)t * n_items + it) * per_item];
+        const int im_model = item_model[it];
+        for (int cc = 0; cc < 32; ++cc) {
+          const int c = t * 32 + cc;
+          for (int k = 0; k < 16 * NKF; ++k) {
+            uint16_t sp[2] = {0, 0};
+            if (k < D) {
+              if (c < C)
+                split2(im_model < 0 ? qscale * iv[((size_t)group_rep[-1 - im_model] * C + c) * D + k]
+                                    : miv[((size_t)im_model * C + c) * D + k], sp);
+            } else if (k == D && im_model >= 0) {  // gconst against 1.0 in the frame operand
+              split2(c < C ? gconsts[(size_t)im_model * C + c] : -60000.0f, sp);  // padding components: exp() == 0
+            }
+            const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
+            for (int s2 = 0; s2 < 2; ++s2) im[(((size_t)s2 * NKF + ch) * 64 + lane) * 8 + i] = sp[s2];
+          }
+        }
+      }
+    FBCHK(e->gmm_images_fx.ensure(sizeof(uint16_t) * fx.size()));
+    HIPCHK(hipMemcpy(e->gmm_images_fx.p, fx.data(), sizeof(uint16_t) * fx.size(), hipMemcpyHostToDevice));
+  }
   if (mode == FB_GMM_MODE_BX3) {
     const size_t per_item = (size_t)3 * NK * 64 * 8;  // bf16 values
     std::vector<uint16_t> bx((size_t)n_tiles * n_items * per_item, 0);
@@ -421,6 +482,8 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.mode = mode; g.NK = NK;
   g.text_scores = e->cfg.text_scores;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
+  g.NKF = NKF; g.sq_shift = sq_shift;
+  g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.item_model = e->gmm_items.as<int>();
   e->n_groups = G;
   e->have_gmm = true;
@@ -518,7 +581,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
 static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   const int strips = (rows_cap + 127) / 128;
   const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
-  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_BX3 ? 512 : 1024);
+  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_F32 ? 1024 : 512);
   int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;
@@ -1381,6 +1444,12 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
 // i-vectors of the last scored batch (enrolment: build_spk_models.py:104-150 keeps the enrolment utterance's
 // i-vector as the speaker identity)
 extern "C" int fb_last_ivectors(fb_engine *e, int B, double *ivecs) { return fb_debug_ivectors(e, B, ivecs); }
+
+extern "C" int fb_gmm_kernel_mode(fb_engine *e) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  return e->gmm.mode;
+}
 
 extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T_out) {
   if (!mfcc) return fb_fail(FB_E_ARG, "mfcc is NULL");

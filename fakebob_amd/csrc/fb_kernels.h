@@ -105,11 +105,16 @@ struct FbGmmDev {
   // bf16x3 variant (k_gmm_bx3): K padded to 16*NK >= D + 3, images [n_tiles][n_items][3][NK][64] x 16 B
   int mode, NK;
   const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
+  // f16x2 variant (k_gmm_fx2): K padded to 16*NKF >= D + 1, images [n_tiles][n_items][2][NKF][64] x 16 B;
+  // x^2 is scaled by 2^-sq_shift and the quadratic parameters by 2^+sq_shift
+  int NKF, sq_shift;
+  const unsigned int __attribute__((ext_vector_type(4))) * images_fx;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
 #define FB_GMM_MODE_F32 0
 #define FB_GMM_MODE_BX3 1
+#define FB_GMM_MODE_FX2 2
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

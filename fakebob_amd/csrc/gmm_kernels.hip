@@ -428,6 +428,300 @@ static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gmm_fx2: the same computation on the f16 matrix pipe with a TWO-way split.
+// fl16 keeps 11 significant bits and the residual of a round-to-nearest split carries its own sign,
+// so  v = v1 + v2 + r,  v1 = fl16(v),  v2 = fl16(v - v1),  |r| <= 2^-24 |v|:  two f16 terms represent an
+// f32 value to within half an f32 ulp.  A product needs
+//     a1b1 + (a1b2 + a2b1)          (dropped: a2b2 <= 2^-24 |ab|, the size of one f32 rounding)
+// i.e. 3 MFMAs per 16 K instead of bx3's 6, at the same matrix rate.  Measured against float64 the
+// result is as close as the f32 MFMA kernel's (numpy model in scratch/fx2_emul.py).
+// f16's narrow exponent range is handled without data-dependent scaling:
+//   * residuals are stored multiplied by 2^12 (exact), so they occupy the same binades as the leading
+//     terms, and are accumulated in their own accumulator "mid"; value = hi + 2^-12 mid (one fma in
+//     the epilogue).  Leading terms below 2^-14 lose nothing: the scaled residual picks the bits up.
+//   * x^2 is scaled by 2^-sq_shift and -1/(2 sigma^2) by 2^+sq_shift (exact, chosen at load time so the
+//     largest parameter stays below 2^15): frames up to |x| < 255 * 2^(sq_shift/2) are representable.
+//   * fb_load_gmm selects this kernel only if every parameter fits f16's range; otherwise bx3 runs.
+// Image of one item: [2 terms][NK chunks][64 lanes][8 f16]; gconst sits at K position D (its two terms
+// against 1.0 / 0.0 in the frame operand).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define FB_FX_RES_SCALE 4096.0f
+#define FB_FX_RES_INV (1.0f / 4096.0f)
+
+__device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2 a, b;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float x = v[2 * i + u];
+      const _Float16 x1 = (_Float16)x;                                   // round to nearest even
+      const float r = __fmul_rn(__fsub_rn(x, (float)x1), FB_FX_RES_SCALE);  // exact
+      a[u] = x1;
+      b[u] = (_Float16)r;
+    }
+    f1[i] = __builtin_bit_cast(unsigned, a);
+    f2[i] = __builtin_bit_cast(unsigned, b);
+  }
+}
+
+#define FB_FX_MFMA(A, B, ACC) \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+
+// online logsumexp: fold 16 values into the (running max, sum of exp) pair at (stm, sts)
+__device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts) {
+#ifndef FB_ABL_NOEPI
+  float tm = FB_GMM_NEG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, pv[r]);
+  const float m_old = *stm, s_old = *sts;
+  const float m_new = fmaxf(m_old, tm);
+  float ssum = s_old * __expf(m_old - m_new);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ssum += __expf(pv[r] - m_new);
+  *stm = m_new;
+  *sts = ssum;
+#else
+  if (pv[3] == 1.2345f) *stm = pv[0];
+#endif
+}
+
+#ifndef FB_FX_VALU_PER_MFMA
+#define FB_FX_VALU_PER_MFMA 6
+#endif
+// One item of the k_gmm_fx2 loop.  The 3*NK MFMAs of this item are interleaved (sched_group_barrier) with the
+// logsumexp update of the PREVIOUS model item's values `pv` -- independent work, so the in-order wave issues
+// the VALU/transcendental stream into the shadow of its own MFMAs instead of after them.
+//   ISQ : quadratic item: accumulators start from zero and are kept in (hq, mq) for the models that follow
+//   PEND: `pv` holds the values of the previous model item (state of that model at stm/sts)
+template <int NK, bool ISQ, bool PEND>
+__device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int lane, const u32x4 (&b1)[NK],
+                                           const u32x4 (&b2)[NK], f32x16 &hq, f32x16 &mq, f32x16 &pv,
+                                           float *__restrict__ stm, float *__restrict__ sts) {
+  u32x4 a1[NK], a2[NK];
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+#ifndef FB_ABL_NOLDSREAD
+    a1[c] = cur4[(0 * NK + c) * 64 + lane];
+    a2[c] = cur4[(1 * NK + c) * 64 + lane];
+#else
+    a1[c] = b1[c]; a2[c] = b2[(c + 1) % NK];
+#endif
+  }
+  f32x16 hi, mid;
+  if constexpr (ISQ) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hi[r] = 0.0f; mid[r] = 0.0f; }
+  } else {
+    hi = hq;
+    mid = mq;
+  }
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+#ifndef FB_ABL_NOMFMA
+    FB_FX_MFMA(a2[c], b1[c], mid);
+    FB_FX_MFMA(a1[c], b1[c], hi);
+    FB_FX_MFMA(a1[c], b2[c], mid);
+#else
+    hi[c] += __uint_as_float(a1[c][0] ^ b1[c][1]); mid[c] += __uint_as_float(a2[c][0] ^ b2[c][1]);
+#endif
+  }
+  if constexpr (PEND) {
+    fb_lse_update16(pv, stm, sts);
+#pragma unroll
+    for (int c = 0; c < 3 * NK; ++c) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, FB_FX_VALU_PER_MFMA, 0);  // VALU of the pending update
+    }
+  }
+  if constexpr (ISQ) {
+    hq = hi;
+    mq = mid;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pv[r] = __fmaf_rn(mid[r], FB_FX_RES_INV, hi[r]);
+  }
+}
+
+#ifndef FB_FX_OCC
+#define FB_FX_OCC 2
+#endif
+#ifndef FB_FX_DEFER
+#define FB_FX_DEFER 0  // 1: software-pipelined update (measured slower: 144 vs 132 us)
+#endif
+template <int NK, bool DUMP>
+__global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const float *__restrict__ feats,
+                                                    const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                    int rows_cap, float *__restrict__ part_m,
+                                                    float *__restrict__ part_s, int xcd_map) {
+  if (g.stop && *g.stop) return;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
+  constexpr int NST = (IMG4 + 255) / 256;
+  const int n_rows = *n_rows_ptr;
+  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
+  if (xcd_map) {
+    const int lin = blockIdx.x, per = 8 / xcd_map;
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 128;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int row = strip0 + w * 32 + j;
+  u32x4 *slot0 = reinterpret_cast<u32x4 *>(lds), *slot1 = slot0 + IMG4;
+  float *st_m = lds + 2 * IMG4 * 4;        // [M][256]
+  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
+
+  // ---- frame fragments: chunk c of this lane = dims 16c + 8h + i, i < 8;  bx = x (1.0 at position D,
+  //      whose residual is 0), bq = fl(x*x) * 2^-sq_shift
+  u32x4 bx1[NK], bx2[NK], bq1[NK], bq2[NK];
+  {
+    const bool ok = row < n_rows;
+    const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
+    const float qs = __uint_as_float((unsigned)(127 - g.sq_shift) << 23);  // 2^-sq_shift
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      const int d0 = 16 * c + 8 * h;
+      float v[8], q[8];
+      if ((g.D & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d = d0 + 4 * u;
+          const float4 t = *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
+          const bool in = ok && d < g.D;
+          v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
+          v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (d0 + i == g.D) v[i] = 1.0f;
+      fb_split2_frag(v, bx1[c], bx2[c]);
+      fb_split2_frag(q, bq1[c], bq2[c]);
+    }
+  }
+  for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
+
+  const int tile0 = chunk_i * tiles_per_chunk;
+  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
+  const int total_items = (tile1 - tile0) * g.n_items;
+  const u32x4 *gimg = g.images_fx + (size_t)tile0 * g.n_items * IMG4;
+
+  u32x4 stage[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    const int q = min(tid + 256 * s, IMG4 - 1);
+    slot0[q] = gimg[q];
+  }
+  __syncthreads();
+
+  f32x16 hq, mq, pv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; mq[r] = 0.0f; pv[r] = 0.0f; }
+  int pend = -1;  // model whose values wait in pv (DUMP: never)
+
+  for (int it = 0; it < total_items; ++it) {
+    u32x4 *cur = (it & 1) ? slot1 : slot0;
+    u32x4 *nxt = (it & 1) ? slot0 : slot1;
+#ifndef FB_ABL_NOLOAD
+    {
+      const u32x4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
+    }
+#endif
+    const int item = it % g.n_items;
+    const int model = g.item_model[item];
+    float *stm = st_m + max(pend, 0) * 256 + tid, *sts = st_s + max(pend, 0) * 256 + tid;
+    if (model < 0) {
+      if (pend >= 0) fb_fx_step<NK, true, true>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts);
+      else fb_fx_step<NK, true, false>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts);
+      pend = -1;
+    } else {
+      if (pend >= 0) fb_fx_step<NK, false, true>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts);
+      else fb_fx_step<NK, false, false>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts);
+      if constexpr (DUMP) {
+        if (row < n_rows) {
+          const int tile = tile0 + it / g.n_items;
+          float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(pv[4 * rr], pv[4 * rr + 1], pv[4 * rr + 2], pv[4 * rr + 3]);
+        }
+      } else {
+#if FB_FX_DEFER
+        pend = model;  // the update runs in the shadow of the next item's MFMAs
+#else
+        fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid);
+#endif
+      }
+    }
+#ifndef FB_ABL_NOLOAD
+#pragma unroll
+    for (int s = 0; s < NST; ++s) nxt[min(tid + 256 * s, IMG4 - 1)] = stage[s];
+#endif
+#ifndef FB_ABL_NOBAR
+    __syncthreads();
+#endif
+  }
+  if (pend >= 0) fb_lse_update16(pv, st_m + pend * 256 + tid, st_s + pend * 256 + tid);  // the last model item
+
+  if constexpr (DUMP) return;
+  for (int m = 0; m < g.M; ++m) {
+    const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
+    const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
+    const float mx = fmaxf(mm, m2);
+    const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
+    if (h == 0 && row < n_rows) {
+      const size_t o = ((size_t)chunk_i * g.M + m) * rows_cap + row;
+      part_m[o] = mx;
+      part_s[o] = sx;
+    }
+  }
+}
+
+template <int NK, bool DUMP>
+static void launch_gmm_fx_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                            int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  const int strips = (rows_cap + 127) / 128;
+  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  int xcd_map = 0;
+  static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
+  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
+    const int per = 8 / n_chunks;
+    grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
+    xcd_map = n_chunks;
+  }
+  const size_t ldsb = (size_t)2 * 2 * NK * 64 * 16 + (size_t)2 * g.M * 256 * sizeof(float);
+  hipLaunchKernelGGL((k_gmm_fx2<NK, DUMP>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap,
+                     part_m, part_s, xcd_map);
+}
+template <bool DUMP>
+static void launch_gmm_fx(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                          int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  switch (g.NKF) {
+    case 2: launch_gmm_fx_t<2, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 3: launch_gmm_fx_t<3, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 4: launch_gmm_fx_t<4, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 5: launch_gmm_fx_t<5, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 6: launch_gmm_fx_t<6, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    default: break;  // fb_load_gmm only produces the NKF values above
+  }
+}
+
 static int fb_gmm_lds_bytes(const FbGmmDev &g) {
   const int imgf = 32 * (2 * g.KH + 4) + 32;
   return (2 * imgf + 2 * g.M * 256) * (int)sizeof(float);
@@ -451,6 +745,7 @@ void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, co
                         int rows_cap, int n_chunks, float *ll) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  if (g.mode == FB_GMM_MODE_FX2) { launch_gmm_fx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr); return; }
   if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr); return; }
   switch (g.KH) {
     case 20: launch_gmm_dump_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
@@ -465,6 +760,7 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
                    int rows_cap, int n_chunks, float *part_m, float *part_s) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  if (g.mode == FB_GMM_MODE_FX2) { launch_gmm_fx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   switch (g.KH) {
     case 20: launch_gmm_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;

@@ -62,7 +62,11 @@ class Engine(object):
         return self.cfg.num_ceps * (self.cfg.delta_order + 1)
 
     def load_gmm(self, models):
-        gc, miv, iv = stack_models(models)
+        self.load_gmm_arrays(*stack_models(models))
+
+    def load_gmm_arrays(self, gc, miv, iv):
+        """gconsts (M, C), means_invvars (M, C, D), inv_vars (M, C, D), float32 -- Kaldi's DiagGmm members."""
+        gc, miv, iv = (np.ascontiguousarray(a, np.float32) for a in (gc, miv, iv))
         M, Cn, D = miv.shape
         N.check(self._L.fb_load_gmm(self._h, C.c_int(M), C.c_int(Cn), C.c_int(D), N.ptr(gc),
                                     N.ptr(miv), N.ptr(iv)))
@@ -111,6 +115,14 @@ class Engine(object):
         out = np.empty((B, R), np.float64)
         N.check(self._L.fb_last_ivectors(self._h, C.c_int(B), N.ptr(out)))
         return out
+
+    @property
+    def gmm_kernel(self):
+        """'fx2' | 'bx3' | 'f32': the diagonal-GMM kernel the loaded model runs on (fb_gmm_kernel_mode)."""
+        rc = self._L.fb_gmm_kernel_mode(self._h)
+        if rc < 0:
+            N.check(rc)
+        return ("f32", "bx3", "fx2")[rc]
 
     def debug_iv_active(self):
         n = C.c_int()

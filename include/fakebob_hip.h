@@ -217,6 +217,12 @@ int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
 int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, double *occ, double *F, int *tv_out);
 int fb_last_ivectors(fb_engine *e, int B, double *ivecs);
 
+/* Which diagonal-GMM kernel the loaded model runs on: 2 = k_gmm_fx2 (two-term f16 split, default),
+ * 1 = k_gmm_bx3 (three-term bf16 split; FB_GMM_MODE=bx3, or chosen automatically when a parameter does not
+ * fit f16's exponent range), 0 = k_gmm (plain f32 MFMA; FB_GMM_MODE=f32).  Negative FB_E_* without a model.
+ * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
+int fb_gmm_kernel_mode(fb_engine *e);
+
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
 int fb_debug_iv_active(fb_engine *e, int *n_active);

@@ -49,12 +49,15 @@ def test_frontend_and_scores_for_other_configs(oracle, over):
         e.close()
 
 
-def test_f32_mfma_gmm_kernel_still_matches(oracle, monkeypatch):
-    monkeypatch.setenv("FB_GMM_MODE", "f32")
+@pytest.mark.parametrize("mode", ["f32", "bx3"])
+def test_other_gmm_kernels_still_match(oracle, monkeypatch, mode):
+    """The default is k_gmm_fx2; the exact bf16x3 kernel and the plain f32 MFMA kernel stay selectable."""
+    monkeypatch.setenv("FB_GMM_MODE", mode)
     e = Engine(0)
     try:
         ubm, spk = synthetic_gmm_system(n_speakers=3, C=256, D=72)
         e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel == mode
         wavs = [_wav(3, 30000), _wav(4, 16000)]
         raw_g, _ = e.score_raw(wavs)
         gc, miv, iv = stack_models([ubm] + spk)
@@ -117,5 +120,31 @@ def test_text_scores_option_matches_the_oracle_and_quantises(oracle):
         raw_full, _ = e.score_raw(wavs)
         assert np.abs(raw_full - raw_g).max() <= 6e-4            # |scores| ~ 1e2 -> 3 decimals kept
         assert np.any(raw_full != raw_g)
+    finally:
+        e.close()
+
+
+def test_model_outside_f16_range_runs_on_the_bf16_kernel(oracle):
+    """k_gmm_fx2 needs |mu/sigma^2|, 1/(2 sigma^2), |gconst| < 2^15; a model with a variance of 1e-5 does not
+    fit, is routed to k_gmm_bx3 at load time and still matches the oracle."""
+    import copy
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
+        e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel == "fx2"
+        gc, miv, iv = [np.array(a, copy=True) for a in stack_models([ubm] + spk)]
+        # one dimension of one component with variance 1e-5 in every model (variances stay shared)
+        var_old = 1.0 / iv[:, 7, 3]
+        mean = miv[:, 7, 3] * var_old
+        iv[:, 7, 3] = np.float32(1.0e5)
+        miv[:, 7, 3] = (mean * 1.0e5).astype(np.float32)
+        gc[:, 7] += (0.5 * (np.log(1.0e5) + np.log(var_old)) - 0.5 * mean * mean * (1.0e5 - 1.0 / var_old)).astype(np.float32)
+        e.load_gmm_arrays(gc, miv, iv)
+        assert e.gmm_kernel == "bx3"
+        wavs = [_wav(3, 30000), _wav(4, 16000)]
+        raw_g, _ = e.score_raw(wavs)
+        raw_o, _ = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=4)
+        assert np.abs(raw_g - raw_o).max() <= SCORE_TOL * max(1.0, np.abs(raw_o).max() / 200.0)
     finally:
         e.close()

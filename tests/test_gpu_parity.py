@@ -67,8 +67,9 @@ def test_score_parity_full_size(engine, oracle, full_system):
 
 
 def test_gmm_bf16_split_kernel_is_f32_equivalent(oracle, full_system, monkeypatch):
-    """The default GMM kernel evaluates every f32 product as 6 exact bf16 partial products on the bf16
-    matrix pipe (k_gmm_bx3).  Its error against the float64-accumulating oracle must be of the same
+    """The default GMM kernel evaluates every f32 product as 3 partial products of a two-term f16 split
+    on the f16 matrix pipe (k_gmm_fx2); FB_GMM_MODE=bx3 uses 6 exact partial products of a three-term
+    bf16 split (k_gmm_bx3).  Their error against the float64-accumulating oracle must be of the same
     size as that of the plain f32-MFMA kernel (FB_GMM_MODE=f32) -- i.e. no precision is given up."""
     from fakebob_amd.engine import Engine
     ubm, spk = full_system
@@ -77,7 +78,7 @@ def test_gmm_bf16_split_kernel_is_f32_equivalent(oracle, full_system, monkeypatc
     gc, miv, iv = stack_models([ubm] + spk)
     raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
     errs = {}
-    for mode in ("f32", "bx3"):
+    for mode in ("f32", "bx3", "fx2"):
         monkeypatch.setenv("FB_GMM_MODE", mode)
         e = Engine(0)
         try:
@@ -86,8 +87,9 @@ def test_gmm_bf16_split_kernel_is_f32_equivalent(oracle, full_system, monkeypatc
         finally:
             e.close()
         errs[mode] = float(np.abs(raw_g - raw_o).max())
-    assert errs["f32"] <= 2e-5 and errs["bx3"] <= 2e-5, errs
+    assert errs["f32"] <= 2e-5 and errs["bx3"] <= 2e-5 and errs["fx2"] <= 2e-5, errs
     assert errs["bx3"] <= 2.0 * errs["f32"] + 1e-6, errs
+    assert errs["fx2"] <= 2.0 * errs["f32"] + 1e-6, errs
 
 
 def test_score_float_input_and_ragged(engine, oracle, small_system):
