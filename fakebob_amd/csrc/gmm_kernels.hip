@@ -470,7 +470,13 @@ __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u
 #define FB_FX_MFMA(A, B, ACC) \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
 
-// online logsumexp: fold 16 values into the (running max, sum of exp) pair at (stm, sts)
+// online logsumexp of k_gmm_fx2: fold 16 values into the state (m, s) at (stm, sts).
+// The state lives in the log2 domain so that one value costs one (packed) fma, one v_exp_f32 and one (packed) add:
+//   m = running maximum (a value, exact),  r = fl(m * L),  s = sum 2^(v * L - r),   L = fl(log2 e)
+//   => logsumexp = ln2 * (r + log2 s); fb_lse_to_natural() converts to the (m, sum exp(v - m)) convention the
+//   chunk merge / k_gmm_finalize use.  The reference point r only has to be the same for every term of s.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define FB_LOG2E_F 1.44269502162933349609375f  // fl(log2 e)
 __device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts) {
 #ifndef FB_ABL_NOEPI
   float tm = FB_GMM_NEG;
@@ -478,14 +484,26 @@ __device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restr
   for (int r = 0; r < 16; ++r) tm = fmaxf(tm, pv[r]);
   const float m_old = *stm, s_old = *sts;
   const float m_new = fmaxf(m_old, tm);
-  float ssum = s_old * __expf(m_old - m_new);
+  const float r_new = __fmul_rn(m_new, FB_LOG2E_F), r_old = __fmul_rn(m_old, FB_LOG2E_F);  // r_old = -inf at the start
+  const f32x2 l2 = {FB_LOG2E_F, FB_LOG2E_F}, nr2 = {-r_new, -r_new};
+  f32x2 acc = {s_old * __builtin_amdgcn_exp2f(r_old - r_new), 0.0f};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ssum += __expf(pv[r] - m_new);
+  for (int r = 0; r < 8; ++r) {
+    const f32x2 v2 = {pv[2 * r], pv[2 * r + 1]};
+    const f32x2 t = __builtin_elementwise_fma(v2, l2, nr2);
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    acc += e;
+  }
   *stm = m_new;
-  *sts = ssum;
+  *sts = acc[0] + acc[1];
 #else
   if (pv[3] == 1.2345f) *stm = pv[0];
 #endif
+}
+// s (log2-domain state, see above) -> sum exp(v - m):  s * 2^(r - L m), evaluated in float64 (|r - L m| < 1e-4)
+__device__ __forceinline__ float fb_lse_to_natural(float m, float s) {
+  const double d = (double)__fmul_rn(m, FB_LOG2E_F) - (double)FB_LOG2E_F * (double)m;
+  return (float)((double)s * (1.0 + d * 0.6931471805599453 * (1.0 + d * 0.34657359027997264)));
 }
 
 #ifndef FB_FX_VALU_PER_MFMA
@@ -511,6 +529,9 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
 #endif
   }
   f32x16 hi, mid;
+#ifdef FB_FX_SETPRIO
+  __builtin_amdgcn_s_setprio(FB_FX_SETPRIO);
+#endif
   if constexpr (ISQ) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hi[r] = 0.0f; mid[r] = 0.0f; }
@@ -536,6 +557,9 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
       __builtin_amdgcn_sched_group_barrier(0x002, FB_FX_VALU_PER_MFMA, 0);  // VALU of the pending update
     }
   }
+#ifdef FB_FX_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if constexpr (ISQ) {
     hq = hi;
     mq = mid;
@@ -681,7 +705,7 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
 
   if constexpr (DUMP) return;
   for (int m = 0; m < g.M; ++m) {
-    const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
+    const float mm = st_m[m * 256 + tid], ss = fb_lse_to_natural(mm, st_s[m * 256 + tid]);
     const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
     const float mx = fmaxf(mm, m2);
     const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);

@@ -1,3 +1,5 @@
 #!/bin/bash
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py --steps 200 --warmup 20 2>&1 | tail -1 > gpurun_out/bench_fx2.json; cut -c1-300 gpurun_out/bench_fx2.json
+timeout 120 python scratch/gmm_only.py
+timeout 120 python scratch/bx_err.py 2>&1 | tail -3
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
