@@ -26,7 +26,7 @@ class FrontendCfg(C.Structure):
         ("use_energy", C.c_int), ("raw_energy", C.c_int), ("energy_floor", C.c_double),
         ("vad_energy_threshold", C.c_double), ("vad_energy_mean_scale", C.c_double),
         ("vad_proportion_threshold", C.c_double), ("vad_frames_context", C.c_int),
-        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int),
+        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int), ("compress_feats", C.c_int),
     ]
 
 

@@ -580,6 +580,123 @@ void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, co
   hipLaunchKernelGGL(k_vad, dim3(B), dim3(256), 0, s, fe, mfcc, frame_off, vrank, tv, B, counter, row_off);
 }
 
+// ------------------------------------------------------------------ compressed-feature round trip
+// fb_frontend_cfg.compress_feats: steps/make_mfcc.sh (gmm_ubm_kaldiHelper.py:138-140) writes the MFCC matrix with
+// `copy-feats --compress=true`, i.e. through Kaldi's lossy CompressedMatrix; every later stage reads that form.
+// Same arithmetic as fbo_compress_roundtrip (oracle/fb_oracle.c), every operation an explicitly rounded
+// intrinsic so that no fma contraction can change a code.  Bit-identical to the oracle on the same matrix.
+__device__ __forceinline__ int fb_cm_to_u16(float minv, float range, float v) {
+  float f = __fdiv_rn(__fsub_rn(v, minv), range);
+  f = f > 1.0f ? 1.0f : f;
+  f = f < 0.0f ? 0.0f : f;
+  return (int)__dadd_rn((double)__fmul_rn(f, 65535.0f), 0.499);
+}
+__device__ __forceinline__ float fb_cm_from_u16(float minv, float range, int v) {
+  return __fadd_rn(minv, __fmul_rn(__fmul_rn(range, 1.52590218966964e-05F), (float)v));
+}
+__device__ __forceinline__ int fb_cm_to_char(float p0, float p25, float p75, float p100, float v) {
+  if (v < p25) {
+    const float f = __fdiv_rn(__fsub_rn(v, p0), __fsub_rn(p25, p0));
+    return min(max((int)__dadd_rn((double)__fmul_rn(f, 64.0f), 0.5), 0), 64);
+  }
+  if (v < p75) {
+    const float f = __fdiv_rn(__fsub_rn(v, p25), __fsub_rn(p75, p25));
+    return min(max(64 + (int)__dadd_rn((double)__fmul_rn(f, 128.0f), 0.5), 64), 192);
+  }
+  const float f = __fdiv_rn(__fsub_rn(v, p75), __fsub_rn(p100, p75));
+  return min(max(192 + (int)__dadd_rn((double)__fmul_rn(f, 63.0f), 0.5), 192), 255);
+}
+__device__ __forceinline__ float fb_cm_from_char(float p0, float p25, float p75, float p100, int c) {
+  if (c <= 64) return __double2float_rn(__dadd_rn((double)p0, __dmul_rn((double)__fmul_rn(__fsub_rn(p25, p0), (float)c), 1 / 64.0)));
+  if (c <= 192)
+    return __double2float_rn(__dadd_rn((double)p25, __dmul_rn((double)__fmul_rn(__fsub_rn(p75, p25), (float)(c - 64)), 1 / 128.0)));
+  return __double2float_rn(__dadd_rn((double)p75, __dmul_rn((double)__fmul_rn(__fsub_rn(p100, p75), (float)(c - 192)), 1 / 63.0)));
+}
+__device__ __forceinline__ float fb_wave_min_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float fb_wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// global header: one workgroup per utterance -> mm[2b] = min, mm[2b+1] = max of its T x nc matrix
+__global__ __launch_bounds__(256) void k_feat_minmax(const float *__restrict__ mfcc, const int *__restrict__ frame_off,
+                                                     int nc, float *__restrict__ mm) {
+  const int b = blockIdx.x;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const float *m = mfcc + (size_t)base * nc;
+  __shared__ float s_lo[4], s_hi[4];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < T * nc; i += 256) { lo = fminf(lo, m[i]); hi = fmaxf(hi, m[i]); }
+  lo = fb_wave_min_f(lo);
+  hi = fb_wave_max_f(hi);
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[2 * b] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    mm[2 * b + 1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+  }
+}
+// one wave per (utterance, column): order statistics 0, T/4, 3(T/4), T-1 of the column by rank counting (stable
+// ranks are a permutation, so exactly one element has each rank), then every element -> byte -> float, in place
+__global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc, const int *__restrict__ frame_off,
+                                                       int nc, const float *__restrict__ mm) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (c >= nc) return;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  if (T <= 0) return;
+  float *col = mfcc + (size_t)base * nc + c;
+  float minv = mm[2 * b], maxv = mm[2 * b + 1];
+  if (maxv == minv) maxv = __fadd_rn(minv, __fadd_rn(1.0f, fabsf(minv)));
+  const float range = __fsub_rn(maxv, minv);
+  if (T <= 8) {  // kTwoByteAuto
+    if (lane < T) col[(size_t)lane * nc] = fb_cm_from_u16(minv, range, fb_cm_to_u16(minv, range, col[(size_t)lane * nc]));
+    return;
+  }
+  const int q = T / 4;
+  float lo = INFINITY, hi = -INFINITY, v25 = 0.0f, v75 = 0.0f;
+  for (int i0 = 0; i0 < T; i0 += 64) {
+    const int i = i0 + lane;
+    const float xi = col[(size_t)min(i, T - 1) * nc];
+    int cnt = 0;
+    for (int j = 0; j < T; ++j) {
+      const float xj = col[(size_t)j * nc];  // wave-uniform address
+      cnt += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+    }
+    if (i < T) {
+      lo = fminf(lo, xi);
+      hi = fmaxf(hi, xi);
+      if (cnt == q) v25 = xi;
+      if (cnt == 3 * q) v75 = xi;
+    }
+    // the lane that found a rank publishes it to the whole wave
+    const unsigned long long m25 = __ballot(i < T && cnt == q), m75 = __ballot(i < T && cnt == 3 * q);
+    if (m25) v25 = __shfl(v25, __ffsll((long long)m25) - 1, 64);
+    if (m75) v75 = __shfl(v75, __ffsll((long long)m75) - 1, 64);
+  }
+  lo = fb_wave_min_f(lo);
+  hi = fb_wave_max_f(hi);
+  const int u0 = min(fb_cm_to_u16(minv, range, lo), 65532);
+  const int u25 = min(max(fb_cm_to_u16(minv, range, v25), u0 + 1), 65533);
+  const int u75 = min(max(fb_cm_to_u16(minv, range, v75), u25 + 1), 65534);
+  const int u100 = max(fb_cm_to_u16(minv, range, hi), u75 + 1);
+  const float p0 = fb_cm_from_u16(minv, range, u0), p25 = fb_cm_from_u16(minv, range, u25),
+              p75 = fb_cm_from_u16(minv, range, u75), p100 = fb_cm_from_u16(minv, range, u100);
+  for (int i = lane; i < T; i += 64) {
+    float *x = col + (size_t)i * nc;
+    *x = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, *x));
+  }
+}
+void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B,
+                             float *mm) {
+  hipLaunchKernelGGL(k_feat_minmax, dim3(B), dim3(256), 0, s, mfcc, frame_off, fe.nc, mm);
+  hipLaunchKernelGGL(k_feat_compress, dim3(B, (fe.nc + 3) / 4), dim3(256), 0, s, mfcc, frame_off, fe.nc, mm);
+}
+
 // ------------------------------------------------------------------ deltas
 // One workgroup per 32-frame chunk of one utterance.  Besides add-deltas it leaves the per-chunk
 // column sums of the delta features (float64, fixed order) so that the whole-utterance CMVN mean

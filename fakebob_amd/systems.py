@@ -49,6 +49,8 @@ class _GmmSystem(object):
             over = frontend_from_kaldi_conf(self.pre_model_dir)
         if os.environ.get("FB_TEXT_SCORES", "0") == "1":   # reproduce the 6-digit text round trip of Kaldi's scores
             over = dict(over, text_scores=1)
+        if os.environ.get("FB_COMPRESS_FEATS", "0") == "1":  # make_mfcc.sh's lossy `copy-feats --compress=true`
+            over = dict(over, compress_feats=1)
         if over:
             self._engine.set_frontend(**over)
         self._engine.load_gmm(models)
@@ -187,6 +189,8 @@ class _IvSystem(object):
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
             if os.environ.get("FB_TEXT_SCORES", "0") == "1":
                 over = dict(over, text_scores=1)
+            if os.environ.get("FB_COMPRESS_FEATS", "0") == "1":
+                over = dict(over, compress_feats=1)
             if over:
                 self._engine.set_frontend(**over)
             d = load_ivector_pre_models(self.pre_model_dir)

@@ -79,6 +79,11 @@ typedef struct {
    * (gmm_ubm_kaldiHelper.py:236-248, ivector_PLDA_kaldiHelper.py:310-338): raw scores are rounded to float32
    * and then to 6 significant decimal digits before any post-processing. */
   int text_scores;
+  /* 0 (default): later stages read the MFCC matrix as computed.  1: emulate steps/make_mfcc.sh's default
+   * `copy-feats --compress=true` (gmm_ubm_kaldiHelper.py:138-140, ivector_PLDA_kaldiHelper.py:163-165): the
+   * matrix takes Kaldi's lossy CompressedMatrix round trip (8-bit codes between per-column 16-bit percentile
+   * anchors; 16-bit codes for <= 8 frames) before VAD, deltas and CMVN read it. */
+  int compress_feats;
 } fb_frontend_cfg;
 
 /* FakeBob hyper-parameters (FAKEBOB.py:21-37) + attack() arguments (:139) +

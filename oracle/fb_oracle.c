@@ -50,6 +50,7 @@ void fbo_default_cfg(fbo_frontend_cfg *c) {
   c->delta_order = 2;
   c->cmn_window = 300;
   c->text_scores = 0;
+  c->compress_feats = 0;
 }
 
 /* --------------------------------------------------------------- Philox */
@@ -346,6 +347,92 @@ int fbo_mfcc(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float *ou
 }
 
 /* --------------------------------------------------------------- VAD [EXT] */
+/* ---- Kaldi CompressedMatrix (matrix/compressed-matrix.{h,cc}, not part of the reference tree [EXT]).
+ * steps/make_mfcc.sh, which the reference calls with its defaults (gmm_ubm_kaldiHelper.py:138-140,
+ * ivector_PLDA_kaldiHelper.py:163-165), pipes compute-mfcc-feats into `copy-feats --compress=true`: the archive
+ * every later stage reads holds the lossy form.  Restated from the published algorithm:
+ *   global header: min, range = max - min of the whole matrix (max = min + 1 + |min| if they coincide)
+ *   T > 8  (kSpeechFeature): per column the order statistics at 0, T/4, 3(T/4), T-1 as uint16 fractions of the
+ *          global range (forced strictly increasing), every element as one byte: 0..64 | 64..192 | 192..255
+ *          linearly between consecutive anchors
+ *   T <= 8 (kTwoByteAuto): every element as a uint16 fraction of the global range
+ * Float/double promotion follows the C++ expressions literally (float operands, double literals). */
+static int fbo_cm_to_u16(float minv, float range, float value) {
+  float f = (value - minv) / range;
+  if (f > 1.0f) f = 1.0f;
+  if (f < 0.0f) f = 0.0f;
+  return (int)((double)(f * 65535.0f) + 0.499);
+}
+static float fbo_cm_from_u16(float minv, float range, int v) {
+  return minv + range * 1.52590218966964e-05F * (float)v;
+}
+static int fbo_cm_to_char(float p0, float p25, float p75, float p100, float value) {
+  int ans;
+  if (value < p25) {
+    float f = (value - p0) / (p25 - p0);
+    ans = (int)((double)(f * 64.0f) + 0.5);
+    if (ans < 0) ans = 0;
+    if (ans > 64) ans = 64;
+  } else if (value < p75) {
+    float f = (value - p25) / (p75 - p25);
+    ans = 64 + (int)((double)(f * 128.0f) + 0.5);
+    if (ans < 64) ans = 64;
+    if (ans > 192) ans = 192;
+  } else {
+    float f = (value - p75) / (p100 - p75);
+    ans = 192 + (int)((double)(f * 63.0f) + 0.5);
+    if (ans < 192) ans = 192;
+    if (ans > 255) ans = 255;
+  }
+  return ans;
+}
+static float fbo_cm_from_char(float p0, float p25, float p75, float p100, int v) {
+  if (v <= 64) return (float)((double)p0 + (double)((p25 - p0) * (float)v) * (1 / 64.0));
+  if (v <= 192) return (float)((double)p25 + (double)((p75 - p25) * (float)(v - 64)) * (1 / 128.0));
+  return (float)((double)p75 + (double)((p100 - p75) * (float)(v - 192)) * (1 / 63.0));
+}
+static int fbo_cmp_float(const void *a, const void *b) {
+  const float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+void fbo_compress_roundtrip(float *m, int T, int nc) {
+  if (T <= 0 || nc <= 0) return;
+  float minv = m[0], maxv = m[0];
+  for (size_t i = 0; i < (size_t)T * nc; ++i) {
+    if (m[i] < minv) minv = m[i];
+    if (m[i] > maxv) maxv = m[i];
+  }
+  if (maxv == minv) maxv = minv + (1.0f + fabsf(minv));
+  const float range = maxv - minv;
+  if (T <= 8) {
+    for (size_t i = 0; i < (size_t)T * nc; ++i) m[i] = fbo_cm_from_u16(minv, range, fbo_cm_to_u16(minv, range, m[i]));
+    return;
+  }
+  float *col = (float *)malloc(sizeof(float) * (size_t)T);
+  const int q = T / 4;
+  for (int c = 0; c < nc; ++c) {
+    for (int t = 0; t < T; ++t) col[t] = m[(size_t)t * nc + c];
+    qsort(col, (size_t)T, sizeof(float), fbo_cmp_float);  /* nth_element leaves the sorted-order values there */
+    int u0 = fbo_cm_to_u16(minv, range, col[0]);
+    if (u0 > 65532) u0 = 65532;
+    int u25 = fbo_cm_to_u16(minv, range, col[q]);
+    if (u25 < u0 + 1) u25 = u0 + 1;
+    if (u25 > 65533) u25 = 65533;
+    int u75 = fbo_cm_to_u16(minv, range, col[3 * q]);
+    if (u75 < u25 + 1) u75 = u25 + 1;
+    if (u75 > 65534) u75 = 65534;
+    int u100 = fbo_cm_to_u16(minv, range, col[T - 1]);
+    if (u100 < u75 + 1) u100 = u75 + 1;
+    const float p0 = fbo_cm_from_u16(minv, range, u0), p25 = fbo_cm_from_u16(minv, range, u25),
+                p75 = fbo_cm_from_u16(minv, range, u75), p100 = fbo_cm_from_u16(minv, range, u100);
+    for (int t = 0; t < T; ++t) {
+      float *x = &m[(size_t)t * nc + c];
+      *x = fbo_cm_from_char(p0, p25, p75, p100, fbo_cm_to_char(p0, p25, p75, p100, *x));
+    }
+  }
+  free(col);
+}
+
 void fbo_vad(const fbo_frontend_cfg *c, const float *mfcc, int T, uint8_t *voiced) {
   int nc = c->num_ceps;
   double sum = 0.0;
@@ -432,6 +519,7 @@ int fbo_frontend(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float
   float *df = (float *)malloc(sizeof(float) * (size_t)T * dim);
   uint8_t *v = (uint8_t *)malloc(T);
   fbo_mfcc(c, wav, n, mf);
+  if (c->compress_feats) fbo_compress_roundtrip(mf, T, nc);
   fbo_vad(c, mf, T, v);
   fbo_deltas(c, mf, T, df);
   fbo_cmvn_sliding(c, df, T, dim);

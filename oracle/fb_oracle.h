@@ -59,6 +59,8 @@ typedef struct {
   int delta_order;          /* 2 */
   int cmn_window;           /* 300, center=true, norm-vars=false */
   int text_scores;          /* 0; 1 = scores through Kaldi's 6-significant-digit text output */
+  int compress_feats;       /* 0; 1 = the MFCC matrix takes the lossy `copy-feats --compress=true` round trip of
+                               steps/make_mfcc.sh (its default), before VAD / deltas / CMVN read it */
 } fbo_frontend_cfg;
 
 /* float32 value printed with 6 significant digits and parsed back (std::ostream << float; float(text)) */
@@ -80,6 +82,9 @@ int fbo_num_frames(const fbo_frontend_cfg *cfg, int64_t n_samples);
 int fbo_feat_dim(const fbo_frontend_cfg *cfg); /* num_ceps*(delta_order+1) */
 /* MFCC: out[T*num_ceps] float32.  returns T. */
 int fbo_mfcc(const fbo_frontend_cfg *cfg, const int16_t *wav, int64_t n, float *out);
+/* Kaldi CompressedMatrix round trip of a T x ncols float matrix, in place (compressed-matrix.{h,cc} [EXT]:
+ * kSpeechFeature = per-column 8-bit codes between 16-bit percentile anchors for T > 8, kTwoByteAuto otherwise) */
+void fbo_compress_roundtrip(float *m, int T, int ncols);
 /* VAD on C0: voiced[T] in {0,1} */
 void fbo_vad(const fbo_frontend_cfg *cfg, const float *mfcc, int T, uint8_t *voiced);
 /* add-deltas: out[T*num_ceps*(order+1)] */

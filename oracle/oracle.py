@@ -27,7 +27,7 @@ class FrontendCfg(C.Structure):
         ("use_energy", C.c_int), ("raw_energy", C.c_int), ("energy_floor", C.c_double),
         ("vad_energy_threshold", C.c_double), ("vad_energy_mean_scale", C.c_double),
         ("vad_proportion_threshold", C.c_double), ("vad_frames_context", C.c_int),
-        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int),
+        ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int), ("compress_feats", C.c_int),
     ]
 
 
@@ -123,6 +123,13 @@ def mfcc(cfg, wav):
     out = np.empty((T, cfg.num_ceps), np.float32)
     lib().fbo_mfcc(C.byref(cfg), _p(wav), C.c_int64(wav.size), _p(out))
     return out
+
+
+def compress_roundtrip(mat):
+    """Kaldi CompressedMatrix round trip (copy-feats --compress=true) of a (T, ncols) float32 matrix."""
+    m = np.array(mat, np.float32, order="C", copy=True)
+    lib().fbo_compress_roundtrip(_p(m), C.c_int(m.shape[0]), C.c_int(m.shape[1]))
+    return m
 
 
 def vad(cfg, mf):

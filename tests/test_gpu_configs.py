@@ -148,3 +148,40 @@ def test_model_outside_f16_range_runs_on_the_bf16_kernel(oracle):
         assert np.abs(raw_g - raw_o).max() <= SCORE_TOL * max(1.0, np.abs(raw_o).max() / 200.0)
     finally:
         e.close()
+
+
+def test_compress_feats_option_is_bit_identical_to_the_oracle_round_trip(oracle):
+    """fb_frontend_cfg.compress_feats: the MFCC matrix takes Kaldi's CompressedMatrix round trip (make_mfcc.sh's
+    `copy-feats --compress=true`) on the device.  On the SAME matrix the device codes equal the oracle's bit for
+    bit; downstream stages then see exactly what the oracle's do."""
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
+        e.load_gmm([ubm] + spk)
+        cfg0, cfg1 = oracle.default_cfg(), oracle.default_cfg(compress_feats=1)
+        for utt, n in ((0, 48000), (1, 9000), (2, 1400), (3, 1000), (4, 100000)):   # T = 300, 56, 9, 6 (two-byte), 625
+            w = _wav(utt, n)
+            e.set_frontend(compress_feats=0)
+            raw = e.debug_mfcc(w)
+            e.set_frontend(compress_feats=1)
+            got = e.debug_mfcc(w)
+            want = oracle.compress_roundtrip(raw)
+            assert np.array_equal(got, want), (utt, n, np.abs(got - want).max())
+            assert not np.array_equal(got, raw)
+            fg, Tg = e.debug_feats(w)
+            v = oracle.vad(cfg0, want).astype(bool)
+            fo = oracle.cmvn_sliding(cfg0, oracle.deltas(cfg0, want))[v]
+            assert fg.shape == fo.shape and np.abs(fg.astype(np.float64) - fo).max() <= 2e-5
+        # whole path against the oracle's own compressed front-end: the 8-bit codes amplify the ~1e-6 differences
+        # of the two MFCC implementations wherever a value sits on a code boundary, so a handful of codes may differ
+        e.set_frontend(compress_feats=1)
+        wavs = [_wav(0, 48000), _wav(1, 20000), _wav(5, 30000)]
+        raw_g, tv_g = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, tv_o = oracle.gmm_score_batch(cfg1, wavs, gc, miv, iv, nthreads=4)
+        raw_u, _ = oracle.gmm_score_batch(cfg0, wavs, gc, miv, iv, nthreads=4)
+        assert np.abs(tv_g - tv_o).max() <= 2
+        assert np.abs(raw_g - raw_o).max() <= 0.02 * np.abs(raw_u - raw_o).max() + 1e-4
+        assert np.abs(raw_u - raw_o).max() > 1e-3          # the option matters: compression moves scores by far more
+    finally:
+        e.close()

@@ -250,3 +250,76 @@ def test_round6_is_the_text_round_trip_of_a_float(oracle):
         got = oracle.round6(v)
         assert got == expect, (v, got, expect)
     assert np.isnan(oracle.round6(float("nan"))) and oracle.round6(float("inf")) == float("inf")
+
+
+def test_compress_roundtrip_against_an_independent_numpy_restatement(oracle):
+    """compress_feats option: Kaldi's CompressedMatrix (copy-feats --compress=true, make_mfcc.sh's default).
+    The C restatement against a vectorised numpy one written from the same published description, plus the
+    properties of the format: 8-bit codes between 4 anchors per column, monotone, idempotent, error bound."""
+    f32, f64 = np.float32, np.float64
+
+    def to_u16(mn, rg, v):
+        f = np.clip(((v - mn) / rg).astype(f32), f32(0), f32(1))
+        return ((f * f32(65535)).astype(f32).astype(f64) + 0.499).astype(np.int64)
+
+    def from_u16(mn, rg, u):
+        return (mn + ((rg * f32(1.52590218966964e-05)).astype(f32) * u.astype(f32)).astype(f32)).astype(f32)
+
+    def np_roundtrip(m):
+        m = m.astype(f32)
+        T, nc = m.shape
+        mn, mx = m.min(), m.max()
+        if mx == mn:
+            mx = f32(mn + f32(f32(1) + abs(mn)))
+        rg = f32(mx - mn)
+        if T <= 8:
+            return from_u16(mn, rg, to_u16(mn, rg, m))
+        s = np.sort(m, axis=0)
+        q = T // 4
+        u0 = np.minimum(to_u16(mn, rg, s[0]), 65532)
+        u25 = np.minimum(np.maximum(to_u16(mn, rg, s[q]), u0 + 1), 65533)
+        u75 = np.minimum(np.maximum(to_u16(mn, rg, s[3 * q]), u25 + 1), 65534)
+        u100 = np.maximum(to_u16(mn, rg, s[T - 1]), u75 + 1)
+        p0, p25, p75, p100 = (from_u16(mn, rg, u)[None, :] for u in (u0, u25, u75, u100))
+
+        def seg(lo, hi, n, off, cap):
+            f = ((m - lo) / (hi - lo)).astype(f32)
+            return np.clip(off + ((f * f32(n)).astype(f32).astype(f64) + 0.5).astype(np.int64), off, cap)
+        code = np.where(m < p25, seg(p0, p25, 64, 0, 64), np.where(m < p75, seg(p25, p75, 128, 64, 192), seg(p75, p100, 63, 192, 255)))
+        a = p0.astype(f64) + ((p25 - p0) * code.astype(f32)).astype(f32).astype(f64) * (1 / 64.0)
+        b = p25.astype(f64) + ((p75 - p25) * (code - 64).astype(f32)).astype(f32).astype(f64) * (1 / 128.0)
+        c = p75.astype(f64) + ((p100 - p75) * (code - 192).astype(f32)).astype(f32).astype(f64) * (1 / 63.0)
+        return np.where(code <= 64, a, np.where(code <= 192, b, c)).astype(f32), code
+
+    rng = np.random.default_rng(5)
+    for T, nc in ((300, 24), (9, 5), (57, 13), (1000, 3)):
+        m = (rng.normal(size=(T, nc)) * rng.uniform(0.5, 20.0, size=nc) + rng.normal(size=nc) * 5).astype(f32)
+        got = oracle.compress_roundtrip(m)
+        want, code = np_roundtrip(m) if T > 8 else (np_roundtrip(m), np.zeros(1, np.int64))
+        assert np.array_equal(got, want)
+        assert code.min() >= 0 and code.max() <= 255 and len(np.unique(got[:, 0])) <= 256
+        span = m.max(0) - m.min(0) + (m.max() - m.min()) * 2.0 ** -14      # + the 16-bit anchors' own step
+        assert np.all(np.abs(got - m).max(0) <= span / 64.0)            # coarsest segment: 1/4 of the data on 63 codes
+        for c in range(nc):                                              # monotone per column
+            o = np.argsort(m[:, c], kind="stable")
+            assert np.all(np.diff(got[o, c]) >= 0)
+        again = oracle.compress_roundtrip(got)
+        assert np.abs(again - got).max() <= np.abs(got - m).max() + 1e-6  # re-coding moves values by at most one more step
+    small = (rng.normal(size=(6, 4)) * 3).astype(f32)                   # <= 8 rows: 16-bit codes of the global range
+    g2 = oracle.compress_roundtrip(small)
+    assert np.array_equal(g2, np_roundtrip(small))
+    assert np.abs(g2 - small).max() <= (small.max() - small.min()) / 65535.0
+    const = np.full((20, 3), 2.5, f32)                                  # degenerate range
+    assert np.all(np.isfinite(oracle.compress_roundtrip(const)))
+
+
+def test_compress_option_changes_the_frontend_only_through_the_mfcc_matrix(oracle):
+    cfg0, cfg1 = oracle.default_cfg(), oracle.default_cfg(compress_feats=1)
+    w = (synthetic_audio(3, 32000) * 32768.0).astype(np.int16)
+    mf = oracle.mfcc(cfg0, w)
+    assert np.array_equal(mf, oracle.mfcc(cfg1, w))                     # fbo_mfcc itself is the uncompressed matrix
+    mc = oracle.compress_roundtrip(mf)
+    v = oracle.vad(cfg0, mc).astype(bool)
+    d = oracle.cmvn_sliding(cfg0, oracle.deltas(cfg0, mc))
+    f1, T1 = oracle.frontend(cfg1, w)
+    assert T1 == mf.shape[0] and np.array_equal(f1, d[v])
