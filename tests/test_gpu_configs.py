@@ -185,3 +185,42 @@ def test_compress_feats_option_is_bit_identical_to_the_oracle_round_trip(oracle)
         assert np.abs(raw_u - raw_o).max() > 1e-3          # the option matters: compression moves scores by far more
     finally:
         e.close()
+
+
+def test_very_long_and_very_short_utterances_in_one_batch(oracle):
+    """Ragged extremes in one call: a 20 s utterance (T = 2000 frames: beyond the fused delta+CMVN kernel's
+    per-utterance limit, several sliding-CMVN windows), a 0.1 s one (T = 10) and ordinary ones."""
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
+        e.load_gmm([ubm] + spk)
+        wavs = [_wav(0, 320000), _wav(1, 1600), _wav(2, 48000), _wav(3, 24000)]
+        raw_g, tv_g = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, tv_o = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=4)
+        assert np.array_equal(tv_g, tv_o) and tv_o[0] > 1000 and tv_o[1] <= 10
+        assert np.abs(raw_g - raw_o).max() <= SCORE_TOL
+        # the same utterances one at a time (other launch shapes) agree with the batch
+        for i, w in enumerate(wavs):
+            r1, t1 = e.score_raw([w])
+            assert t1[0] == tv_g[i] and np.abs(r1[0] - raw_g[i]).max() <= 2e-6
+    finally:
+        e.close()
+
+
+def test_empty_and_degenerate_batches_are_errors_not_crashes():
+    from fakebob_amd._native import NativeError
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=1, C=64, D=72)
+        e.load_gmm([ubm] + spk)
+        with pytest.raises((NativeError, ValueError)):
+            e.score_raw([])
+        with pytest.raises((NativeError, ValueError)):
+            e.score_raw([np.zeros(0, np.int16)])
+        with pytest.raises(NativeError):
+            e.score_raw([np.zeros(16000, np.int16)])          # digital silence: no voiced frame
+        r, tv = e.score_raw([_wav(0, 16000)])                 # the engine is still usable afterwards
+        assert tv[0] > 0 and np.isfinite(r).all()
+    finally:
+        e.close()
