@@ -50,9 +50,28 @@ def cpu_baseline(audio, models, params_kw):
     t0 = time.perf_counter()
     O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=0, stream=0)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "NES iterations/s", "cores": 1, "kind": "port",
-            "sample": "1 full NES iteration (51 utterances x 3 s, 6 models) of the same workload, "
-                      "CPU oracle single thread, %.1f s" % dt}
+    out = {"value": 1.0 / dt, "unit": "NES iterations/s", "cores": 1, "kind": "port",
+           "sample": "1 full NES iteration (51 utterances x 3 s, 6 models) of the same workload, "
+                     "CPU oracle single thread, %.1f s" % dt}
+    # the same iteration with the oracle's utterance-parallel scoring on every host core (report
+    # the single-thread and the all-cores restatement separately; the reference's own default is n_jobs=1)
+    try:
+        nthr = max(1, len(os.sched_getaffinity(0)))
+        if nthr > 1:
+            ctx = O.GmmSystemCtx(O.default_cfg(), "OSI", gc, miv, iv, nthreads=nthr)
+            O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=0, stream=0)        # warm the thread pool / caches
+            t0 = time.perf_counter()
+            n = 0
+            while n < 3 and time.perf_counter() - t0 < 10.0:
+                O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=n + 1, stream=0)
+                n += 1
+            dta = (time.perf_counter() - t0) / n
+            out["all_cores"] = {"value": 1.0 / dta, "unit": "NES iterations/s", "cores": nthr, "kind": "port",
+                                "sample": "%d NES iterations, oracle with %d threads (utterances in parallel), "
+                                          "%.2f s each" % (n, nthr, dta)}
+    except Exception as ex:  # noqa: BLE001 -- the single-thread number above is the contract
+        out["all_cores"] = {"error": str(ex)[:200]}
+    return out
 
 
 def bench_ivector(args, torch):
