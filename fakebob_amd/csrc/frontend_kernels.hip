@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
       }
     }
     if (!fe.raw_energy) energy = fb_wave_sum(en2);
-    double log_energy = log(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
+    double log_energy = fb_log_f64(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
     if (log_energy < fe.log_energy_floor) log_energy = fe.log_energy_floor;
     fb_wave_sync();
     // ---- Stockham radix-2 complex FFT of size Nc (ping-pong A <-> Bf)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
       e += __shfl_xor(e, 1, 64);
       if (m < nb && part == 0) {
         if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
-        LM[m] = log(e);
+        LM[m] = fb_log_f64(e);
       }
     }
     fb_wave_sync();
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
       e += __shfl_xor(e, 1, 64);
       if (lane == 63) e = energy;
       if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
-      const double le = log(e);
+      const double le = fb_log_f64(e);
       if (m < nb && part == 0) LM[m] = le;
       if (lane == 63) LM[nb] = le < fe.log_energy_floor ? fe.log_energy_floor : le;
     }

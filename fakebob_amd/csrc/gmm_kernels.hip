@@ -551,6 +551,9 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
   }
   if constexpr (PEND) {
     fb_lse_update16(pv, stm, sts);
+#ifdef FB_FX_DS_FIRST
+    __builtin_amdgcn_sched_group_barrier(0x100, FB_FX_DS_FIRST, 0);  // A fragments first: no MFMA waits on LDS
+#endif
 #pragma unroll
     for (int c = 0; c < 3 * NK; ++c) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
