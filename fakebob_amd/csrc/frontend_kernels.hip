@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
 #ifndef FB_R4_OCC
 #define FB_R4_OCC 3
 #endif
+#ifndef R4_UNROLL
+#define R4_UNROLL 4  // mel / DCT tap loops: batches the LDS reads of 4 taps (41.7 -> 40.4 us)
+#endif
 #define FB_R4_XSLOTS 288  // 256 + 256/8 padded complex slots
 
 struct MfccR4Lds {  // offsets in doubles
@@ -432,6 +435,9 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
         const int first = s_mfirst[m], len = s_mlen[m];
         const int h0 = (len + 1) >> 1;
         const int i0 = part ? h0 : 0, i1 = part ? len : h0;
+#ifdef R4_UNROLL
+#pragma unroll R4_UNROLL
+#endif
         for (int i = i0; i < i1; ++i) e = fma((double)wm[i], PW[first + i], e);
       }
       e += __shfl_xor(e, 1, 64);
@@ -450,6 +456,9 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
         const float *dr = s_dct + c * nb;
         const int h0 = (nb + 1) >> 1;
         const int i0 = part ? h0 : 0, i1 = part ? nb : h0;
+#ifdef R4_UNROLL
+#pragma unroll R4_UNROLL
+#endif
         for (int m = i0; m < i1; ++m) acc = fma((double)dr[m], LM[m], acc);
       }
       acc += __shfl_xor(acc, 1, 64);
