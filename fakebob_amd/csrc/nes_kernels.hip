@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
     out->adver_loss = loss[0];
     auto el = [&](int i) { return D1{loss[1 + i]}; };
     const double lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
-    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : 0.0;  // np.mean :243
+    // np.mean :243 -- of an empty slice when samples_per_draw < 2: NaN, like NumPy
+    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
     for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
     double d = 0.0;
     for (int i = 0; i < n_dist_part; ++i) d = dist_part[i] > d ? dist_part[i] : d;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
     if (i >= half) z = -z;
     return D1{__dmul_rn(s_loss[i], z)};
   };
-  double g = 0.0;
+  double g = __longlong_as_double(0x7ff8000000000000ll);  // samples_per_draw < 2: np.mean over an empty axis (:244)
   if (spd > 0) {
     const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
     g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
