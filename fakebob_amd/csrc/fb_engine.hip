@@ -378,7 +378,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
-  int sq_shift = 0;
+  int sq_shift = 0, kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0;
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -394,21 +394,38 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
     }
     if (!finite || max_l >= lim || max_g >= lim || max_q >= lim || NKF > 6) {
       mode = FB_GMM_MODE_BX3;
+    } else if (FB_FX_SINGLE) {
+      // one accumulator, unscaled residuals: operands are moved up by exact powers of two so that the residuals
+      // of typical values are normal f16 numbers (subnormal ones keep an absolute precision of 2^-25):
+      //   linear:    (mu/sigma^2, gconst) * 2^kl  x  (x, 1) * 2^kx         kl <= 4, kx = 4
+      //   quadratic: -1/(2 sigma^2)      * 2^kq  x  x^2 * 2^kx2           kq + kx2 = kl + kx = kacc
+      auto headroom = [&](float mx) { int k = 0; while (k < 15 && mx * (float)(2 << k) < lim) ++k; return k; };
+      kl = std::min(4, headroom(std::max(max_l, max_g)));
+      kx = 4;
+      kacc = kl + kx;
+      kq = std::min(headroom(max_q), kacc + 2);  // x^2 * 2^-2 at most: keeps |x| < 511 and small squares precise
+      if (kq < kacc - 4) {
+        mode = FB_GMM_MODE_BX3;                   // would need x^2 * 2^5 or more: |x| < 45 is too tight
+      } else {
+        kx2 = kacc - kq;
+      }
     } else {
       while (sq_shift < 8 && max_q * (float)(2 << sq_shift) < lim) ++sq_shift;
+      kq = sq_shift; kx2 = -sq_shift;
     }
   }
   if (mode == FB_GMM_MODE_FX2) {
     const size_t per_item = (size_t)2 * NKF * 64 * 8;  // f16 values
     std::vector<uint16_t> fx((size_t)n_tiles * n_items * per_item, 0);
-    auto split2 = [](float v, uint16_t out[2]) {
+    const float res_scale = FB_FX_SINGLE ? 1.0f : 4096.0f;
+    auto split2 = [res_scale](float v, uint16_t out[2]) {
       const _Float16 a = (_Float16)v;  // round to nearest even
-      const float r = (v - (float)a) * 4096.0f;  // exact
+      const float r = (v - (float)a) * res_scale;  // exact
       const _Float16 b = (_Float16)r;
       memcpy(&out[0], &a, 2);
       memcpy(&out[1], &b, 2);
     };
-    const float qscale = -0.5f * (float)(1 << sq_shift);
+    const float qscale = -0.5f * ldexpf(1.0f, kq), lscale = ldexpf(1.0f, kl);
     for (int t = 0; t < n_tiles; ++t)
       for (int it = 0; it < n_items; ++it) {
         uint16_t *im = &fx[((size_t)t * n_items + it) * per_item];
@@ -420,9 +437,9 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
             if (k < D) {
               if (c < C)
                 split2(im_model < 0 ? qscale * iv[((size_t)group_rep[-1 - im_model] * C + c) * D + k]
-                                    : miv[((size_t)im_model * C + c) * D + k], sp);
-            } else if (k == D && im_model >= 0) {  // gconst against 1.0 in the frame operand
-              split2(c < C ? gconsts[(size_t)im_model * C + c] : -60000.0f, sp);  // padding components: exp() == 0
+                                    : lscale * miv[((size_t)im_model * C + c) * D + k], sp);
+            } else if (k == D && im_model >= 0) {  // gconst against 2^kx in the frame operand
+              split2(c < C ? lscale * gconsts[(size_t)im_model * C + c] : -60000.0f, sp);  // padding components: exp() == 0
             }
             const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
             for (int s2 = 0; s2 < 2; ++s2) im[(((size_t)s2 * NKF + ch) * 64 + lane) * 8 + i] = sp[s2];
@@ -485,6 +502,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.text_scores = e->cfg.text_scores;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
   g.NKF = NKF; g.sq_shift = sq_shift;
+  g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.item_model = e->gmm_items.as<int>();
   e->n_groups = G;
@@ -583,7 +601,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
 static int choose_chunks(const FbGmmDev &g, int rows_cap) {
   const int strips = (rows_cap + 127) / 128;
   const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
-  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_F32 ? 1024 : 512);
+  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_F32 ? 1024 : (g.mode == FB_GMM_MODE_FX2 ? 256 * FB_FX_OCC : 512));
   int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;

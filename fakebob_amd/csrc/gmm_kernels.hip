@@ -436,19 +436,29 @@ static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, 
 //     a1b1 + (a1b2 + a2b1)          (dropped: a2b2 <= 2^-24 |ab|, the size of one f32 rounding)
 // i.e. 3 MFMAs per 16 K instead of bx3's 6, at the same matrix rate.  Measured against float64 the
 // result is as close as the f32 MFMA kernel's (numpy model in scratch/fx2_emul.py).
-// f16's narrow exponent range is handled without data-dependent scaling:
-//   * residuals are stored multiplied by 2^12 (exact), so they occupy the same binades as the leading
-//     terms, and are accumulated in their own accumulator "mid"; value = hi + 2^-12 mid (one fma in
-//     the epilogue).  Leading terms below 2^-14 lose nothing: the scaled residual picks the bits up.
-//   * x^2 is scaled by 2^-sq_shift and -1/(2 sigma^2) by 2^+sq_shift (exact, chosen at load time so the
-//     largest parameter stays below 2^15): frames up to |x| < 255 * 2^(sq_shift/2) are representable.
-//   * fb_load_gmm selects this kernel only if every parameter fits f16's range; otherwise bx3 runs.
+// f16's narrow exponent range is handled without data-dependent scaling (FB_FX_SINGLE = 1, the default):
+//   * all three products go into ONE accumulator; residuals are stored unscaled.  The f16 matrix pipe keeps
+//     subnormal inputs (scratch/f16_denorm_probe.hip), so a residual below 2^-14 is still exact to 2^-25 absolute.
+//   * operands are moved up by exact powers of two chosen at load time (fb_load_gmm): (mu/sigma^2, gconst) * 2^kl
+//     against (x, 1) * 2^kx, and -1/(2 sigma^2) * 2^kq against x^2 * 2^kx2 with kl + kx = kq + kx2 = kacc, so
+//     that typical residuals are normal numbers and the largest operand stays below 2^15 (|x| < 4094, |x| < 511
+//     for the squares).  The accumulators hold ll * 2^kacc; the logsumexp update folds 2^-kacc into the
+//     multiplier of its fma, so the scaling costs nothing.
+//   * fb_load_gmm selects this kernel only if every parameter fits; otherwise bx3 runs.
+//   (FB_FX_SINGLE = 0 keeps the earlier form: residuals * 2^12 in a second accumulator, value = hi + 2^-12 mid:
+//    135 us instead of 129 us, 32 more VGPRs.)
 // Image of one item: [2 terms][NK chunks][64 lanes][8 f16]; gconst sits at K position D (its two terms
-// against 1.0 / 0.0 in the frame operand).
+// against 2^kx / 0 in the frame operand).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#if FB_FX_SINGLE
+#define FB_FX_RES_SCALE 1.0f
+#define FB_FX_RES_INV 1.0f
+#else
 #define FB_FX_RES_SCALE 4096.0f
 #define FB_FX_RES_INV (1.0f / 4096.0f)
+#endif
+__device__ __forceinline__ float fb_pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
 __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2) {
 #pragma unroll
@@ -477,15 +487,16 @@ __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u
 //   chunk merge / k_gmm_finalize use.  The reference point r only has to be the same for every term of s.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define FB_LOG2E_F 1.44269502162933349609375f  // fl(log2 e)
-__device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts) {
+__device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts,
+                                                float ls = FB_LOG2E_F) {  // ls = fl(log2 e) * 2^-kacc for scaled values
 #ifndef FB_ABL_NOEPI
   float tm = FB_GMM_NEG;
 #pragma unroll
   for (int r = 0; r < 16; ++r) tm = fmaxf(tm, pv[r]);
   const float m_old = *stm, s_old = *sts;
   const float m_new = fmaxf(m_old, tm);
-  const float r_new = __fmul_rn(m_new, FB_LOG2E_F), r_old = __fmul_rn(m_old, FB_LOG2E_F);  // r_old = -inf at the start
-  const f32x2 l2 = {FB_LOG2E_F, FB_LOG2E_F}, nr2 = {-r_new, -r_new};
+  const float r_new = __fmul_rn(m_new, ls), r_old = __fmul_rn(m_old, ls);  // r_old = -inf at the start
+  const f32x2 l2 = {ls, ls}, nr2 = {-r_new, -r_new};
   f32x2 acc = {s_old * __builtin_amdgcn_exp2f(r_old - r_new), 0.0f};
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -501,8 +512,8 @@ __device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restr
 #endif
 }
 // s (log2-domain state, see above) -> sum exp(v - m):  s * 2^(r - L m), evaluated in float64 (|r - L m| < 1e-4)
-__device__ __forceinline__ float fb_lse_to_natural(float m, float s) {
-  const double d = (double)__fmul_rn(m, FB_LOG2E_F) - (double)FB_LOG2E_F * (double)m;
+__device__ __forceinline__ float fb_lse_to_natural(float m, float s, float ls = FB_LOG2E_F) {
+  const double d = (double)__fmul_rn(m, ls) - (double)ls * (double)m;
   return (float)((double)s * (1.0 + d * 0.6931471805599453 * (1.0 + d * 0.34657359027997264)));
 }
 
@@ -517,17 +528,7 @@ __device__ __forceinline__ float fb_lse_to_natural(float m, float s) {
 template <int NK, bool ISQ, bool PEND>
 __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int lane, const u32x4 (&b1)[NK],
                                            const u32x4 (&b2)[NK], f32x16 &hq, f32x16 &mq, f32x16 &pv,
-                                           float *__restrict__ stm, float *__restrict__ sts) {
-  u32x4 a1[NK], a2[NK];
-#pragma unroll
-  for (int c = 0; c < NK; ++c) {
-#ifndef FB_ABL_NOLDSREAD
-    a1[c] = cur4[(0 * NK + c) * 64 + lane];
-    a2[c] = cur4[(1 * NK + c) * 64 + lane];
-#else
-    a1[c] = b1[c]; a2[c] = b2[(c + 1) % NK];
-#endif
-  }
+                                           float *__restrict__ stm, float *__restrict__ sts, float ls, float unscale) {
   f32x16 hi, mid;
 #ifdef FB_FX_SETPRIO
   __builtin_amdgcn_s_setprio(FB_FX_SETPRIO);
@@ -539,9 +540,48 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
     hi = hq;
     mid = mq;
   }
+#if FB_FX_JIT_A
+  // A fragments one K step ahead of their MFMAs (sched_barrier keeps the compiler from hoisting all 2*NK
+  // ds_read_b128 to the top, which costs 40 VGPRs and the third wave per SIMD)
+  u32x4 a1c = cur4[(0 * NK + 0) * 64 + lane], a2c = cur4[(1 * NK + 0) * 64 + lane];
 #pragma unroll
   for (int c = 0; c < NK; ++c) {
-#ifndef FB_ABL_NOMFMA
+    u32x4 a1n = a1c, a2n = a2c;
+    if (c + 1 < NK) {
+      a1n = cur4[(0 * NK + c + 1) * 64 + lane];
+      a2n = cur4[(1 * NK + c + 1) * 64 + lane];
+    }
+#if FB_FX_SINGLE
+    FB_FX_MFMA(a2c, b1[c], hi);
+    FB_FX_MFMA(a1c, b2[c], hi);
+    FB_FX_MFMA(a1c, b1[c], hi);
+#else
+    FB_FX_MFMA(a2c, b1[c], mid);
+    FB_FX_MFMA(a1c, b1[c], hi);
+    FB_FX_MFMA(a1c, b2[c], mid);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    a1c = a1n;
+    a2c = a2n;
+  }
+#else
+  u32x4 a1[NK], a2[NK];
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+#ifndef FB_ABL_NOLDSREAD
+    a1[c] = cur4[(0 * NK + c) * 64 + lane];
+    a2[c] = cur4[(1 * NK + c) * 64 + lane];
+#else
+    a1[c] = b1[c]; a2[c] = b2[(c + 1) % NK];
+#endif
+  }
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+#if !defined(FB_ABL_NOMFMA) && FB_FX_SINGLE
+    FB_FX_MFMA(a2[c], b1[c], hi);
+    FB_FX_MFMA(a1[c], b2[c], hi);
+    FB_FX_MFMA(a1[c], b1[c], hi);
+#elif !defined(FB_ABL_NOMFMA)
     FB_FX_MFMA(a2[c], b1[c], mid);
     FB_FX_MFMA(a1[c], b1[c], hi);
     FB_FX_MFMA(a1[c], b2[c], mid);
@@ -549,8 +589,9 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
     hi[c] += __uint_as_float(a1[c][0] ^ b1[c][1]); mid[c] += __uint_as_float(a2[c][0] ^ b2[c][1]);
 #endif
   }
+#endif
   if constexpr (PEND) {
-    fb_lse_update16(pv, stm, sts);
+    fb_lse_update16(pv, stm, sts, ls);
 #ifdef FB_FX_DS_FIRST
     __builtin_amdgcn_sched_group_barrier(0x100, FB_FX_DS_FIRST, 0);  // A fragments first: no MFMA waits on LDS
 #endif
@@ -567,13 +608,18 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
     hq = hi;
     mq = mid;
   } else {
+#if FB_FX_SINGLE
+    (void)unscale;
+    pv = hi;  // ll * 2^kacc: the logsumexp update folds the unscaling into its fma
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) pv[r] = __fmaf_rn(mid[r], FB_FX_RES_INV, hi[r]);
+#endif
   }
 }
 
-#ifndef FB_FX_OCC
-#define FB_FX_OCC 2
+#ifndef FB_FX_STAGGER_FROM
+#define FB_FX_STAGGER_FROM 256
 #endif
 #ifndef FB_FX_DEFER
 #define FB_FX_DEFER 0  // 1: software-pipelined update (measured slower: 144 vs 132 us)
@@ -600,6 +646,11 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   }
   const int strip0 = strip_i * 128;
   if (strip0 >= n_rows) return;
+#ifdef FB_FX_STAGGER
+  // the two workgroups of a CU start together and run identical phases (MFMA block, then logsumexp block) in
+  // lock-step; delaying the second resident by about half an item puts one's MFMAs beside the other's VALU
+  if ((int)(blockIdx.x + gridDim.x * blockIdx.y) >= FB_FX_STAGGER_FROM) __builtin_amdgcn_s_sleep(FB_FX_STAGGER);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int row = strip0 + w * 32 + j;
@@ -613,7 +664,7 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   {
     const bool ok = row < n_rows;
     const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
-    const float qs = __uint_as_float((unsigned)(127 - g.sq_shift) << 23);  // 2^-sq_shift
+    const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);  // exact power-of-two operand scalings
 #pragma unroll
     for (int c = 0; c < NK; ++c) {
       const int d0 = 16 * c + 8 * h;
@@ -634,8 +685,7 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
 #pragma unroll
       for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (d0 + i == g.D) v[i] = 1.0f;
+      for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
       fb_split2_frag(v, bx1[c], bx2[c]);
       fb_split2_frag(q, bq1[c], bq2[c]);
     }
@@ -655,6 +705,7 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   }
   __syncthreads();
 
+  const float unscale = fb_pow2f(-g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
   f32x16 hq, mq, pv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; mq[r] = 0.0f; pv[r] = 0.0f; }
@@ -674,25 +725,26 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
     const int model = g.item_model[item];
     float *stm = st_m + max(pend, 0) * 256 + tid, *sts = st_s + max(pend, 0) * 256 + tid;
     if (model < 0) {
-      if (pend >= 0) fb_fx_step<NK, true, true>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts);
-      else fb_fx_step<NK, true, false>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts);
+      if (pend >= 0) fb_fx_step<NK, true, true>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts, ls, unscale);
+      else fb_fx_step<NK, true, false>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts, ls, unscale);
       pend = -1;
     } else {
-      if (pend >= 0) fb_fx_step<NK, false, true>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts);
-      else fb_fx_step<NK, false, false>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts);
+      if (pend >= 0) fb_fx_step<NK, false, true>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts, ls, unscale);
+      else fb_fx_step<NK, false, false>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts, ls, unscale);
       if constexpr (DUMP) {
         if (row < n_rows) {
           const int tile = tile0 + it / g.n_items;
           float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(pv[4 * rr], pv[4 * rr + 1], pv[4 * rr + 2], pv[4 * rr + 3]);
+            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(pv[4 * rr] * unscale, pv[4 * rr + 1] * unscale,
+                                                                    pv[4 * rr + 2] * unscale, pv[4 * rr + 3] * unscale);
         }
       } else {
 #if FB_FX_DEFER
         pend = model;  // the update runs in the shadow of the next item's MFMAs
 #else
-        fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid);
+        fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid, ls);
 #endif
       }
     }
@@ -704,11 +756,12 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
     __syncthreads();
 #endif
   }
-  if (pend >= 0) fb_lse_update16(pv, st_m + pend * 256 + tid, st_s + pend * 256 + tid);  // the last model item
+  if (pend >= 0) fb_lse_update16(pv, st_m + pend * 256 + tid, st_s + pend * 256 + tid, ls);  // the last model item
 
   if constexpr (DUMP) return;
   for (int m = 0; m < g.M; ++m) {
-    const float mm = st_m[m * 256 + tid], ss = fb_lse_to_natural(mm, st_s[m * 256 + tid]);
+    const float ms = st_m[m * 256 + tid];  // maximum of ll * 2^kacc
+    const float mm = ms * unscale, ss = fb_lse_to_natural(ms, st_s[m * 256 + tid], ls);
     const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
     const float mx = fmaxf(mm, m2);
     const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
