@@ -1,6 +1,5 @@
 #!/bin/bash
-for i in 1 2; do timeout 120 python scratch/gmm_only.py; done
-timeout 120 python scratch/bx_err.py 2>&1 | tail -3
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
-timeout 300 python scratch/fuzz.py 11 120 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q -k "ivector or iv_ or config4 or enroll" 2>&1 | tail -5
+bash scratch/iv_prof.sh x 2>&1 | head -8
+FB_IV_SOLVE=right bash scratch/iv_prof.sh x 2>&1 | head -3
+timeout 300 python scratch/fuzz_iv.py 21 60 | tail -3
