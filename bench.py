@@ -129,7 +129,7 @@ def bench_ivector(args, torch):
            "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
                                   "%d attacks in flight" % K, "attacks_in_flight_per_gpu": K,
                       "voiced_rows_per_iter": rows, "model_load_s": t_load},
-           "roofline": {"kernel": "k_iv_contract_gemm<lin> + <quad> (T-matrix contraction, LDS-tiled float64 MFMA "
+           "roofline": {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
                                   "v_mfma_f64_16x16x4, active rows only)", "bound": "hbm",
                         "achieved": bytes_stream / (con_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_stream / (con_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,

@@ -95,6 +95,7 @@ struct fb_engine {
   DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_linv, iv_ivec, iv_fail, iv_active, iv_bws, iv_pairs, iv_llf;
   int iv_kchunks = 96;
   int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
+  int iv_zeroC = -1;  // ... for this component count (position of the zero rows)
   // system
   int task = FB_TASK_OSI;
   DevBuf zmean, zstd;
@@ -724,11 +725,13 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     const int Bpad = (B + 31) / 32 * 32;
     {
       const size_t cg = e->iv_gamma.cap, cx = e->iv_X.cap;
-      FBCHK(e->iv_gamma.ensure(sizeof(double) * (size_t)Bpad * iv.C));
-      FBCHK(e->iv_X.ensure(sizeof(double) * (size_t)Bpad * Q));
-      if (Bpad != e->iv_Bpad || cg != e->iv_gamma.cap || cx != e->iv_X.cap) {  // zero the padding columns once
-        HIPCHK(hipMemsetAsync(e->iv_gamma.p, 0, sizeof(double) * (size_t)Bpad * iv.C, s));
-        HIPCHK(hipMemsetAsync(e->iv_X.p, 0, sizeof(double) * (size_t)Bpad * Q, s));
+      // one extra, always-zero row behind each matrix: the DMA contraction points padding rows of its last K stage at it
+      FBCHK(e->iv_gamma.ensure(sizeof(double) * (size_t)Bpad * (iv.C + 1)));
+      FBCHK(e->iv_X.ensure(sizeof(double) * (size_t)Bpad * (Q + 1)));
+      if (Bpad != e->iv_Bpad || cg != e->iv_gamma.cap || cx != e->iv_X.cap || iv.C != e->iv_zeroC) {  // zero the padding once
+        HIPCHK(hipMemsetAsync(e->iv_gamma.p, 0, sizeof(double) * (size_t)Bpad * (iv.C + 1), s));
+        HIPCHK(hipMemsetAsync(e->iv_X.p, 0, sizeof(double) * (size_t)Bpad * (Q + 1), s));
+        e->iv_zeroC = iv.C;
         e->iv_Bpad = Bpad;
       }
     }

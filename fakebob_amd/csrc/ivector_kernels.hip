@@ -725,11 +725,135 @@ __global__ __launch_bounds__(256) void k_iv_contract_gemm(FbIvDev iv, const doub
   }
 }
 
+// LDS-DMA form of the same GEMM (default): the register-staged kernel above keeps one stage (8-16 KB per workgroup) in
+// flight, which is far too little to cover HBM latency -- 1.9 TB/s on the parameter stream (115 + 60 us; this
+// kernel: 80 + 44 us = 2.8 TB/s and 56 % of the f64 MFMA peak on the quadratic term).  Here every 1 KB row
+// segment goes straight into LDS with one global_load_lds_dwordx4 per wave, into a ring of FB_CD_S stages filled
+// FB_CD_S - 1 stages ahead and awaited with a counted s_waitcnt (hipcc does not see these loads).  Source addresses
+// are per lane, so the ragged last column block just clamps its column index (those columns are never stored), and
+// padding rows of the last K stage read the always-zero row the engine keeps behind gammaT / XT.  Coefficient rows
+// (64 utterances = 512 B) travel two per instruction: LDS row pair p holds K rows p and p + KC/2, which puts the 4
+// rows of one MFMA fragment in 4 different pairs, 1152 B apart (bank offset 32 of 64).
+#define FB_CD_KC 8
+#ifndef FB_CD_S
+#define FB_CD_S 3  // 41 KB of LDS: 3 workgroups per CU, all 627 column tiles of the quadratic term resident at once
+#endif
+#define FB_CD_LDP 144  // doubles per staged coefficient row PAIR (2 x 64 + 16)
+__device__ __forceinline__ void fb_iv_glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <bool IS_LIN>
+__global__ __launch_bounds__(256) void k_iv_contract_dma(FbIvDev iv, const double *__restrict__ AT, int ldA, size_t zero_row,
+                                                         const int *__restrict__ active,
+                                                         const int *__restrict__ n_active, int B, int n_kchunks,
+                                                         double *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double sA[FB_CD_S][(FB_CD_KC / 2) * FB_CD_LDP];
+  __shared__ __attribute__((aligned(16))) double sB[FB_CD_S][FB_CD_KC * FB_CG_LDB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = IS_LIN ? iv.R : iv.triR;
+  const int DK = IS_LIN ? iv.D : 1;
+  const double *P = IS_LIN ? iv.sim : iv.u;
+  const int n0 = blockIdx.x * FB_CG_NT;
+  const int b0 = blockIdx.z * 64;
+  const int na = *n_active;
+  int a0 = 0, a1 = na;
+  if (IS_LIN) {
+    const int per = (na + n_kchunks - 1) / n_kchunks;
+    a0 = blockIdx.y * per;
+    a1 = min(na, a0 + per);
+  }
+  const int nq = max(0, a1 - a0) * DK;
+  const int nst = (nq + FB_CD_KC - 1) / FB_CD_KC;
+  const unsigned sA_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)&sA[0][0];
+  const unsigned sB_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)&sB[0][0];
+  // per-lane column offsets (clamped: the ragged last block re-reads valid columns it never stores)
+  const int colB = min(n0 + 2 * lane, N - 2);
+  const int colA = min(b0 + 2 * (lane & 31), ldA - 2);
+  auto row_of = [&](int q, bool &valid) -> size_t {   // parameter / coefficient row of contraction index q (wave-uniform)
+    valid = q < nq;
+    const int qc = min(q, max(nq - 1, 0));
+    const int ai = a0 + (IS_LIN ? qc / DK : qc);
+    const int k = active[ai];
+    return IS_LIN ? (size_t)k * DK + (qc - (ai - a0) * DK) : (size_t)k;
+  };
+  // stage st -> ring slot st % S: this wave brings parameter rows w and w + 4 and coefficient row pair w
+  auto issue = [&](int st) {
+    const int slot = st % FB_CD_S, q0 = st * FB_CD_KC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bool ok;
+      const size_t prow = row_of(q0 + w + 4 * u, ok);
+      fb_iv_glds16(P + prow * N + colB, sB_lds + (unsigned)((slot * FB_CD_KC + w + 4 * u) * FB_CG_LDB * 8));
+    }
+    bool ok0, ok1;
+    const size_t r0 = row_of(q0 + w, ok0), r1 = row_of(q0 + w + FB_CD_KC / 2, ok1);
+    const size_t ra = ok0 ? r0 : zero_row, rb = ok1 ? r1 : zero_row;
+    const double *src = AT + (lane < 32 ? ra : rb) * ldA + colA;
+    fb_iv_glds16(src, sA_lds + (unsigned)((slot * (FB_CD_KC / 2) + w) * FB_CD_LDP * 8));
+  };
+  fb_d4 acc[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[c][t] = fb_d4{0.0, 0.0, 0.0, 0.0};
+  if (nst > 0) {
+#pragma unroll
+    for (int p = 0; p < FB_CD_S - 1; ++p) issue(p);     // stages beyond nst re-read clamped rows into unused slots
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (FB_CD_S - 2)) : "memory");  // stage 0 has landed (this wave's pieces)
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      const int slot = st % FB_CD_S;
+      issue(st + FB_CD_S - 1);  // its slot was read in iteration st - 1
+#pragma unroll
+      for (int ks = 0; ks < FB_CD_KC / 4; ++ks) {
+        const int kk = 4 * ks + (lane >> 4);
+        double af[4], bf[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = sA[slot][(kk & 3) * FB_CD_LDP + (kk >> 2) * 64 + 16 * t + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bf[c] = sB[slot][kk * FB_CG_LDB + 32 * w + 16 * c + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf[c], acc[c][t], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (FB_CD_S - 2)) : "memory");  // stage st + 1 has landed
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  double *o = IS_LIN ? out + (size_t)blockIdx.y * B * N : out;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int col = n0 + 32 * w + 16 * c + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = b0 + 16 * t + (lane >> 4) + 4 * i;
+        if (row < B && col < N) o[(size_t)row * N + col] = acc[c][t][i];
+      }
+  }
+}
+
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
                            double *quad) {
   hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
   const int bgroups = (B + 63) / 64;
+  static const bool reg_staged = getenv("FB_IV_CONTRACT") && strcmp(getenv("FB_IV_CONTRACT"), "reg") == 0;
+  const bool dma = !reg_staged && (iv.R % 2 == 0) && (iv.triR % 2 == 0) && iv.R >= 2;  // 16-byte aligned row segments
+  if (dma) {
+    hipLaunchKernelGGL((k_iv_contract_dma<true>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0, s,
+                       iv, XT, Bpad, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp);
+    hipLaunchKernelGGL((k_iv_contract_dma<false>), dim3((iv.triR + FB_CG_NT - 1) / FB_CG_NT, 1, bgroups), dim3(256), 0, s,
+                       iv, gammaT, Bpad, (size_t)iv.C, active, n_active, B, 1, quad);
+    return;
+  }
   hipLaunchKernelGGL((k_iv_contract_gemm<true, 16>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0,
                      s, iv, XT, Bpad, active, n_active, B, n_kchunks, linp);
   hipLaunchKernelGGL((k_iv_contract_gemm<false, 8>), dim3((iv.triR + FB_CG_NT - 1) / FB_CG_NT, 1, bgroups), dim3(256), 0, s,
