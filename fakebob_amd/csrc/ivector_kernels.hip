@@ -106,12 +106,17 @@ __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__re
   // per-lane candidates: the three best of the lane's registers, refilled (rarely) by a rescan
   float t0v, t1v, t2v;
   int t0j, t1j, t2j;
+  // values already handed out are not erased: a rescan only looks at entries that come after the last popped one in
+  // the (value descending, index descending) order -- (x, j) < (lim_v, lim_j)
+  float lim_v = FLT_MAX;
+  int lim_j = NJ;
 #define FB_TOP3()                                                                                  \
   {                                                                                                \
     t0v = t1v = t2v = -FLT_MAX;                                                                    \
     t0j = t1j = t2j = -1;                                                                          \
     _Pragma("unroll") for (int j = NJ - 1; j >= 0; --j) { /* descending index + strict '>': ties keep the larger index */ \
-      const float x = v[j];                                                                        \
+      const float x0 = v[j];                                                                       \
+      const float x = (x0 < lim_v || (x0 == lim_v && j < lim_j)) ? x0 : -FLT_MAX;                  \
       const bool g0 = x > t0v, g1 = x > t1v, g2 = x > t2v;                                         \
       t2v = g1 ? t1v : (g2 ? x : t2v); t2j = g1 ? t1j : (g2 ? j : t2j);                            \
       t1v = g0 ? t0v : (g1 ? x : t1v); t1j = g0 ? t0j : (g1 ? j : t1j);                            \
@@ -123,28 +128,48 @@ __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__re
   for (int s = 0; s < nsel; ++s) {
     float bv = t0v;
     int bi = lane + 64 * (t0j < 0 ? 0 : t0j);
+    // fast path: wave maximum of the VALUE alone (6 DPP steps of one v_max each); if exactly one lane holds it, that
+    // lane's candidate wins.  Equal maxima in two lanes (or an exhausted wave) take the full (value, index) arg-max.
+    float mv = bv;
+#define FB_MAX_STEP(CTRL, RM) \
+    mv = fmaxf(mv, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mv), __float_as_int(mv), CTRL, RM, 0xf, false)));
+    FB_MAX_STEP(0xb1, 0xf)
+    FB_MAX_STEP(0x4e, 0xf)
+    FB_MAX_STEP(0x141, 0xf)
+    FB_MAX_STEP(0x140, 0xf)
+    FB_MAX_STEP(0x142, 0xa)
+    FB_MAX_STEP(0x143, 0xc)
+#undef FB_MAX_STEP
+    const float top = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), 63));
+    const unsigned long long holders = __ballot(bv == top);
+    bool none;
+    int win;
+    if (__popcll(holders) == 1) {
+      none = false;
+      win = __builtin_amdgcn_readlane(bi, __ffsll((long long)holders) - 1);
+    } else {
 #define FB_ARGMAX_STEP(CTRL, RM)                                                              \
     {                                                                                         \
       const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv), __float_as_int(bv), CTRL, RM, 0xf, false)); \
       const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, RM, 0xf, false);               \
       if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }                             \
     }
-    FB_ARGMAX_STEP(0xb1, 0xf)   // quad_perm [1,0,3,2]
-    FB_ARGMAX_STEP(0x4e, 0xf)   // quad_perm [2,3,0,1]
-    FB_ARGMAX_STEP(0x141, 0xf)  // row_half_mirror
-    FB_ARGMAX_STEP(0x140, 0xf)  // row_mirror
-    FB_ARGMAX_STEP(0x142, 0xa)  // row_bcast15
-    FB_ARGMAX_STEP(0x143, 0xc)  // row_bcast31
+      FB_ARGMAX_STEP(0xb1, 0xf)   // quad_perm [1,0,3,2]
+      FB_ARGMAX_STEP(0x4e, 0xf)   // quad_perm [2,3,0,1]
+      FB_ARGMAX_STEP(0x141, 0xf)  // row_half_mirror
+      FB_ARGMAX_STEP(0x140, 0xf)  // row_mirror
+      FB_ARGMAX_STEP(0x142, 0xa)  // row_bcast15
+      FB_ARGMAX_STEP(0x143, 0xc)  // row_bcast31
 #undef FB_ARGMAX_STEP
-    // (fewer than nsel components: the remaining slots stay -1, as with an exhausted heap)
-    const bool none = __builtin_amdgcn_readlane(__float_as_int(bv), 63) == __float_as_int(-FLT_MAX);
-    const int win = none ? -1 : __builtin_amdgcn_readlane(bi, 63);
+      // (fewer than nsel components: the remaining slots stay -1, as with an exhausted heap)
+      none = __builtin_amdgcn_readlane(__float_as_int(bv), 63) == __float_as_int(-FLT_MAX);
+      win = none ? -1 : __builtin_amdgcn_readlane(bi, 63);
+    }
     if (lane == s) my_k = win;
     bool refill = false;
     if (!none && (win & 63) == lane) {  // the owner hands its best candidate out (and forgets the value)
-      const int wj = win >> 6;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) v[j] = (j == wj) ? -FLT_MAX : v[j];
+      lim_v = t0v;
+      lim_j = t0j;
       t0v = t1v; t0j = t1j; t1v = t2v; t1j = t2j; t2v = -FLT_MAX; t2j = -1;
       refill = t0j < 0;  // candidates exhausted: look at the registers again
     }
