@@ -1226,30 +1226,34 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
   const int npanel = (R + FB_IV_NB - 1) / FB_IV_NB;
   double *Q = quad + (size_t)b * iv.triR;
   double *aug = AugAll + (size_t)b * R;
-  auto rowp = [&](int r) -> double * { return r < R ? Q + (size_t)r * (r + 1) / 2 : aug; };
+  auto rowp = [&](int r) -> double * { return r < R ? Q + ((r * (r + 1)) >> 1) : aug; };  // R <= 2^15: 32-bit offsets
   double *Lg = LinvAll + (size_t)b * npanel * FB_IV_NB * FB_IV_NB;
   double *rhs = smd;                  // [R]
   double *Dg = rhs + ((R + 1) & ~1);  // [NB][LD]  L11
   double *Di = Dg + FB_IV_NB * LD;    // [NB][LD]  L11^-1
   constexpr int LDP = FB_IV_NB + 2;   // panel row stride: conflict-free for the MFMA fragment reads
   double *Lp = Di + FB_IV_NB * LD;    // [R+16][LDP] panel below the diagonal block
-  for (int r = tid; r < R; r += nt) Q[(size_t)r * (r + 1) / 2 + r] += 1.0;  // A = I + quad
-  {  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order
-    double *part = Lp;
-    for (int idx = tid; idx < 8 * R; idx += nt) {
-      const int sl = idx / R, r = idx - sl * R;
-      double acc = 0.0;
-      for (int ch = sl; ch < n_kchunks; ch += 8) acc += linp[((size_t)ch * B + b) * R + r];
-      part[sl * R + r] = acc;
+  for (int r = tid; r < R; r += nt) Q[((r * (r + 1)) >> 1) + r] += 1.0;  // A = I + quad
+  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order (thread = component:
+  // coalesced, 8 independent loads in flight)
+  for (int r = tid; r < R; r += nt) {
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double *lp = linp + (size_t)b * R + r;
+    int ch = 0;
+    for (; ch + 8 <= n_kchunks; ch += 8) {
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
     }
-    __syncthreads();
-    for (int r = tid; r < R; r += nt) {
-      double acc = 0.0;
-      for (int sl = 0; sl < 8; ++sl) acc += part[sl * R + r];
-      aug[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
-    }
+    for (int sl = 0; ch + sl < n_kchunks; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
+    double acc = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) acc += a8[sl];
+    aug[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
   }
   __syncthreads();
+#ifdef FB_SOLVE_PROBE_SETUP
+  if (R > 0) { for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = aug[r] * 1e-3; return; }  // timing probe only
+#endif
   // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
   // registers (lane = row for the factor, lane = column for the inverse; pivots and columns are broadcast
   // with v_readlane).  Leaves L11 in Dg and in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
@@ -1418,24 +1422,41 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
     }
     __syncthreads();
   }
+#ifdef FB_SOLVE_PROBE_CHOL
+  if (R > 0) { for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = aug[r] * 1e-3; return; }  // timing probe only
+#endif
   // ---- the augmented row now holds y = L^-1 rhs; L^T x = y panel by panel with the stored panel inverses
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
   for (int pi = npanel - 1; pi >= 0; --pi) {
     const int j0 = pi * FB_IV_NB, nb = min(FB_IV_NB, R - j0);
-    if (tid < FB_IV_NB) {
+    // the panel inverse through LDS (one coalesced pass) instead of 32 dependent global loads per lane
+    for (int idx = tid; idx < FB_IV_NB * FB_IV_NB; idx += nt)
+      Di[(idx >> 5) * LD + (idx & 31)] = Lg[(size_t)pi * FB_IV_NB * FB_IV_NB + idx];
+    __syncthreads();
+    if (tid < FB_IV_NB) {  // x = L11^-T y
       double x = 0.0;
-      if (tid < nb)
-        for (int q = tid; q < nb; ++q) x = fma(Lg[((size_t)pi * FB_IV_NB + q) * FB_IV_NB + tid], rhs[j0 + q], x);
-      if (tid < nb) Dg[tid] = x;
+#pragma unroll
+      for (int q = 0; q < FB_IV_NB; ++q) {
+        const double t = Di[q * LD + tid] * rhs[j0 + min(q, nb - 1)];
+        x += (q >= tid && q < nb) ? t : 0.0;
+      }
+      Dg[tid] = x;
     }
     __syncthreads();
     if (tid < nb) rhs[j0 + tid] = Dg[tid];
-    __syncthreads();
+    // rows above: rhs[i] -= sum_q L[j0+q][i] x[q]  (x from Dg; all 32 loads of a thread are in flight together)
     for (int i = tid; i < j0; i += nt) {
+      const double *lrow = rowp(j0) + i;
+      double lv[FB_IV_NB];
+#pragma unroll
+      for (int q = 0; q < FB_IV_NB; ++q) {
+        lv[q] = q < nb ? *lrow : 0.0;
+        if (q < nb) lrow += j0 + q + 1;  // next packed row
+      }
       double v = rhs[i];
-#pragma unroll 8
-      for (int q = 0; q < nb; ++q) v = fma(-rowp(j0 + q)[i], rhs[j0 + q], v);
+#pragma unroll
+      for (int q = 0; q < FB_IV_NB; ++q) v = fma(-lv[q], Dg[q], v);
       rhs[i] = v;
     }
     __syncthreads();
