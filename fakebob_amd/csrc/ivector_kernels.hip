@@ -205,26 +205,37 @@ __global__ __launch_bounds__(256) void k_iv_bucket_count(FbIvDev iv, const int *
 }
 // cnt[blk][k] -> pref[blk][k] = exclusive prefix over blk, hist[k] = total; then bstart[C+1] = exclusive scan of
 // hist and wstart[C+1] = exclusive scan of ceil(hist / FB_IV_CH); nz[0 .. nz[C]) = the non-empty buckets.
-// Single workgroup.
-__global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, int Cpad, int n_blk, const int *__restrict__ cnt,
-                                                         int *__restrict__ pref, int *__restrict__ hist,
-                                                         int *__restrict__ bstart, int *__restrict__ wstart,
-                                                         int *__restrict__ nz) {
-  __shared__ int sa[1024], sb[1024], sc[1024];
-  for (int k = threadIdx.x; k < C; k += 1024) {  // coalesced over k for every block; loads 8 blocks ahead
-    int run = 0;
-    int j = 0;
-    for (; j + 8 <= n_blk; j += 8) {
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = cnt[(size_t)(j + u) * Cpad + k];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { pref[(size_t)(j + u) * Cpad + k] = run; run += v[u]; }
-    }
-    for (; j < n_blk; ++j) { pref[(size_t)j * Cpad + k] = run; run += cnt[(size_t)j * Cpad + k]; }
-    hist[k] = run;
-  }
+// (a) per component: exclusive scan over the partition blocks.  Workgroup = 64 components x 16 block segments: every
+//     thread first sums its segment (all loads independent), the 16 segment sums are scanned through LDS, then the
+//     segment is walked again to write the prefixes -- instead of one thread walking all n_blk blocks of a component.
+__global__ __launch_bounds__(1024) void k_iv_bucket_scan_blocks(int C, int Cpad, int n_blk, const int *__restrict__ cnt,
+                                                                int *__restrict__ pref, int *__restrict__ hist) {
+  __shared__ int ssum[16][64];
+  const int kk = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kk;
+  const int per = (n_blk + 15) / 16;
+  const int j0 = seg * per, j1 = min(n_blk, j0 + per);
+  const bool kok = k < C;
+  int tot = 0;
+  if (kok)
+    for (int j = j0; j < j1; ++j) tot += cnt[(size_t)j * Cpad + k];
+  ssum[seg][kk] = tot;
   __syncthreads();
+  int run = 0;
+  for (int q = 0; q < seg; ++q) run += ssum[q][kk];
+  if (kok) {
+    for (int j = j0; j < j1; ++j) {
+      pref[(size_t)j * Cpad + k] = run;
+      run += cnt[(size_t)j * Cpad + k];
+    }
+    if (seg == 15) hist[k] = run;  // (empty trailing segments included: run = the component's total)
+  }
+}
+// (b) bstart[C+1] = exclusive scan of hist, wstart[C+1] = exclusive scan of ceil(hist / FB_IV_CH), nz[] = the non-empty
+//     buckets.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_iv_bucket_scan(int C, const int *__restrict__ hist, int *__restrict__ bstart,
+                                                         int *__restrict__ wstart, int *__restrict__ nz) {
+  __shared__ int sa[1024], sb[1024], sc[1024];
   const int per = (C + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(C, lo + per);
   int a = 0, bsum = 0, nzc = 0;
@@ -478,7 +489,8 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
   hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
-  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist, bstart, wstart, nz);
+  hipLaunchKernelGGL(k_iv_bucket_scan_blocks, dim3((C + 63) / 64), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
+  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, nz);
   hipLaunchKernelGGL(k_iv_bucket_fill, dim3(n_blk), dim3(64), lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
   const int n_pairs_cap = rows_cap * iv.nsel;
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
