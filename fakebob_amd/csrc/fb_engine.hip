@@ -379,7 +379,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
-  int sq_shift = 0, kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0;
+  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0;
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -395,7 +395,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
     }
     if (!finite || max_l >= lim || max_g >= lim || max_q >= lim || NKF > 6) {
       mode = FB_GMM_MODE_BX3;
-    } else if (FB_FX_SINGLE) {
+    } else {
       // one accumulator, unscaled residuals: operands are moved up by exact powers of two so that the residuals
       // of typical values are normal f16 numbers (subnormal ones keep an absolute precision of 2^-25):
       //   linear:    (mu/sigma^2, gconst) * 2^kl  x  (x, 1) * 2^kx         kl <= 4, kx = 4
@@ -410,18 +410,14 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
       } else {
         kx2 = kacc - kq;
       }
-    } else {
-      while (sq_shift < 8 && max_q * (float)(2 << sq_shift) < lim) ++sq_shift;
-      kq = sq_shift; kx2 = -sq_shift;
     }
   }
   if (mode == FB_GMM_MODE_FX2) {
     const size_t per_item = (size_t)2 * NKF * 64 * 8;  // f16 values
     std::vector<uint16_t> fx((size_t)n_tiles * n_items * per_item, 0);
-    const float res_scale = FB_FX_SINGLE ? 1.0f : 4096.0f;
-    auto split2 = [res_scale](float v, uint16_t out[2]) {
+    auto split2 = [](float v, uint16_t out[2]) {
       const _Float16 a = (_Float16)v;  // round to nearest even
-      const float r = (v - (float)a) * res_scale;  // exact
+      const float r = v - (float)a;    // exact; may be a subnormal f16 (kept by the matrix pipe)
       const _Float16 b = (_Float16)r;
       memcpy(&out[0], &a, 2);
       memcpy(&out[1], &b, 2);
@@ -502,7 +498,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.mode = mode; g.NK = NK;
   g.text_scores = e->cfg.text_scores;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
-  g.NKF = NKF; g.sq_shift = sq_shift;
+  g.NKF = NKF;
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.item_model = e->gmm_items.as<int>();

@@ -110,7 +110,7 @@ struct FbGmmDev {
   const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
   // f16x2 variant (k_gmm_fx2): K padded to 16*NKF >= D + 1, images [n_tiles][n_items][2][NKF][64] x 16 B;
   // x^2 is scaled by 2^-sq_shift and the quadratic parameters by 2^+sq_shift
-  int NKF, sq_shift;
+  int NKF;
   // power-of-two operand scalings (exact): frames x * 2^kx, x^2 * 2^kx2; the accumulators hold ll * 2^kacc
   int kx, kx2, kacc;
   const unsigned int __attribute__((ext_vector_type(4))) * images_fx;
@@ -122,12 +122,6 @@ struct FbGmmDev {
 #define FB_GMM_MODE_FX2 2
 #ifndef FB_FX_OCC
 #define FB_FX_OCC 2  // k_gmm_fx2 workgroups per CU (launch bound and the launch's target block count)
-#endif
-#ifndef FB_FX_JIT_A
-#define FB_FX_JIT_A 0
-#endif
-#ifndef FB_FX_SINGLE
-#define FB_FX_SINGLE 1  // k_gmm_fx2: 1 = one accumulator, unscaled f16 residuals, operands pre-scaled by 2^k (see gmm_kernels.hip)
 #endif
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,

@@ -436,7 +436,7 @@ static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, 
 //     a1b1 + (a1b2 + a2b1)          (dropped: a2b2 <= 2^-24 |ab|, the size of one f32 rounding)
 // i.e. 3 MFMAs per 16 K instead of bx3's 6, at the same matrix rate.  Measured against float64 the
 // result is as close as the f32 MFMA kernel's (numpy model in scratch/fx2_emul.py).
-// f16's narrow exponent range is handled without data-dependent scaling (FB_FX_SINGLE = 1, the default):
+// f16's narrow exponent range is handled without data-dependent scaling:
 //   * all three products go into ONE accumulator; residuals are stored unscaled.  The f16 matrix pipe keeps
 //     subnormal inputs (scratch/f16_denorm_probe.hip), so a residual below 2^-14 is still exact to 2^-25 absolute.
 //   * operands are moved up by exact powers of two chosen at load time (fb_load_gmm): (mu/sigma^2, gconst) * 2^kl
@@ -445,19 +445,12 @@ static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, 
 //     for the squares).  The accumulators hold ll * 2^kacc; the logsumexp update folds 2^-kacc into the
 //     multiplier of its fma, so the scaling costs nothing.
 //   * fb_load_gmm selects this kernel only if every parameter fits; otherwise bx3 runs.
-//   (FB_FX_SINGLE = 0 keeps the earlier form: residuals * 2^12 in a second accumulator, value = hi + 2^-12 mid:
-//    135 us instead of 129 us, 32 more VGPRs.)
+//   (An earlier form kept the residuals * 2^12 in a second accumulator, value = hi + 2^-12 mid: 135 us instead of
+//    129 us and 32 more VGPRs.)
 // Image of one item: [2 terms][NK chunks][64 lanes][8 f16]; gconst sits at K position D (its two terms
 // against 2^kx / 0 in the frame operand).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#if FB_FX_SINGLE
-#define FB_FX_RES_SCALE 1.0f
-#define FB_FX_RES_INV 1.0f
-#else
-#define FB_FX_RES_SCALE 4096.0f
-#define FB_FX_RES_INV (1.0f / 4096.0f)
-#endif
 __device__ __forceinline__ float fb_pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
 __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2) {
@@ -468,7 +461,7 @@ __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u
     for (int u = 0; u < 2; ++u) {
       const float x = v[2 * i + u];
       const _Float16 x1 = (_Float16)x;                                   // round to nearest even
-      const float r = __fmul_rn(__fsub_rn(x, (float)x1), FB_FX_RES_SCALE);  // exact
+      const float r = __fsub_rn(x, (float)x1);  // exact; possibly a subnormal f16, which the matrix pipe keeps
       a[u] = x1;
       b[u] = (_Float16)r;
     }
@@ -517,54 +510,21 @@ __device__ __forceinline__ float fb_lse_to_natural(float m, float s, float ls = 
   return (float)((double)s * (1.0 + d * 0.6931471805599453 * (1.0 + d * 0.34657359027997264)));
 }
 
-#ifndef FB_FX_VALU_PER_MFMA
-#define FB_FX_VALU_PER_MFMA 6
-#endif
-// One item of the k_gmm_fx2 loop.  The 3*NK MFMAs of this item are interleaved (sched_group_barrier) with the
-// logsumexp update of the PREVIOUS model item's values `pv` -- independent work, so the in-order wave issues
-// the VALU/transcendental stream into the shadow of its own MFMAs instead of after them.
-//   ISQ : quadratic item: accumulators start from zero and are kept in (hq, mq) for the models that follow
-//   PEND: `pv` holds the values of the previous model item (state of that model at stm/sts)
-template <int NK, bool ISQ, bool PEND>
+// One item of the k_gmm_fx2 loop: the 3*NK MFMAs of a 32-component x 32-frame tile.
+//   ISQ : quadratic item: the accumulator starts from zero and is kept in hq for the models that follow
+//   else: model item: continues from hq; the values (ll * 2^kacc) are left in pv
+// (Tried and measured slower, DESIGN.md §5: interleaving the previous item's logsumexp update into this MFMA chain with
+// sched_group_barrier, s_setprio around the chain, A fragments fetched one K step ahead to fit 3 waves per SIMD.)
+template <int NK, bool ISQ>
 __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int lane, const u32x4 (&b1)[NK],
-                                           const u32x4 (&b2)[NK], f32x16 &hq, f32x16 &mq, f32x16 &pv,
-                                           float *__restrict__ stm, float *__restrict__ sts, float ls, float unscale) {
-  f32x16 hi, mid;
-#ifdef FB_FX_SETPRIO
-  __builtin_amdgcn_s_setprio(FB_FX_SETPRIO);
-#endif
+                                           const u32x4 (&b2)[NK], f32x16 &hq, f32x16 &pv) {
+  f32x16 hi;
   if constexpr (ISQ) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hi[r] = 0.0f; mid[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) hi[r] = 0.0f;
   } else {
     hi = hq;
-    mid = mq;
   }
-#if FB_FX_JIT_A
-  // A fragments one K step ahead of their MFMAs (sched_barrier keeps the compiler from hoisting all 2*NK
-  // ds_read_b128 to the top, which costs 40 VGPRs and the third wave per SIMD)
-  u32x4 a1c = cur4[(0 * NK + 0) * 64 + lane], a2c = cur4[(1 * NK + 0) * 64 + lane];
-#pragma unroll
-  for (int c = 0; c < NK; ++c) {
-    u32x4 a1n = a1c, a2n = a2c;
-    if (c + 1 < NK) {
-      a1n = cur4[(0 * NK + c + 1) * 64 + lane];
-      a2n = cur4[(1 * NK + c + 1) * 64 + lane];
-    }
-#if FB_FX_SINGLE
-    FB_FX_MFMA(a2c, b1[c], hi);
-    FB_FX_MFMA(a1c, b2[c], hi);
-    FB_FX_MFMA(a1c, b1[c], hi);
-#else
-    FB_FX_MFMA(a2c, b1[c], mid);
-    FB_FX_MFMA(a1c, b1[c], hi);
-    FB_FX_MFMA(a1c, b2[c], mid);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    a1c = a1n;
-    a2c = a2n;
-  }
-#else
   u32x4 a1[NK], a2[NK];
 #pragma unroll
   for (int c = 0; c < NK; ++c) {
@@ -577,53 +537,17 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
   }
 #pragma unroll
   for (int c = 0; c < NK; ++c) {
-#if !defined(FB_ABL_NOMFMA) && FB_FX_SINGLE
+#ifndef FB_ABL_NOMFMA
     FB_FX_MFMA(a2[c], b1[c], hi);
     FB_FX_MFMA(a1[c], b2[c], hi);
     FB_FX_MFMA(a1[c], b1[c], hi);
-#elif !defined(FB_ABL_NOMFMA)
-    FB_FX_MFMA(a2[c], b1[c], mid);
-    FB_FX_MFMA(a1[c], b1[c], hi);
-    FB_FX_MFMA(a1[c], b2[c], mid);
 #else
-    hi[c] += __uint_as_float(a1[c][0] ^ b1[c][1]); mid[c] += __uint_as_float(a2[c][0] ^ b2[c][1]);
+    hi[c] += __uint_as_float(a1[c][0] ^ b1[c][1]) + __uint_as_float(a2[c][0] ^ b2[c][1]);
 #endif
   }
-#endif
-  if constexpr (PEND) {
-    fb_lse_update16(pv, stm, sts, ls);
-#ifdef FB_FX_DS_FIRST
-    __builtin_amdgcn_sched_group_barrier(0x100, FB_FX_DS_FIRST, 0);  // A fragments first: no MFMA waits on LDS
-#endif
-#pragma unroll
-    for (int c = 0; c < 3 * NK; ++c) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, FB_FX_VALU_PER_MFMA, 0);  // VALU of the pending update
-    }
-  }
-#ifdef FB_FX_SETPRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
-  if constexpr (ISQ) {
-    hq = hi;
-    mq = mid;
-  } else {
-#if FB_FX_SINGLE
-    (void)unscale;
-    pv = hi;  // ll * 2^kacc: the logsumexp update folds the unscaling into its fma
-#else
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pv[r] = __fmaf_rn(mid[r], FB_FX_RES_INV, hi[r]);
-#endif
-  }
+  if constexpr (ISQ) hq = hi; else pv = hi;
 }
 
-#ifndef FB_FX_STAGGER_FROM
-#define FB_FX_STAGGER_FROM 256
-#endif
-#ifndef FB_FX_DEFER
-#define FB_FX_DEFER 0  // 1: software-pipelined update (measured slower: 144 vs 132 us)
-#endif
 template <int NK, bool DUMP>
 __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const float *__restrict__ feats,
                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
@@ -646,11 +570,6 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   }
   const int strip0 = strip_i * 128;
   if (strip0 >= n_rows) return;
-#ifdef FB_FX_STAGGER
-  // the two workgroups of a CU start together and run identical phases (MFMA block, then logsumexp block) in
-  // lock-step; delaying the second resident by about half an item puts one's MFMAs beside the other's VALU
-  if ((int)(blockIdx.x + gridDim.x * blockIdx.y) >= FB_FX_STAGGER_FROM) __builtin_amdgcn_s_sleep(FB_FX_STAGGER);
-#endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int row = strip0 + w * 32 + j;
@@ -706,10 +625,9 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   __syncthreads();
 
   const float unscale = fb_pow2f(-g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
-  f32x16 hq, mq, pv;
+  f32x16 hq, pv;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; mq[r] = 0.0f; pv[r] = 0.0f; }
-  int pend = -1;  // model whose values wait in pv (DUMP: never)
+  for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; pv[r] = 0.0f; }
 
   for (int it = 0; it < total_items; ++it) {
     u32x4 *cur = (it & 1) ? slot1 : slot0;
@@ -723,14 +641,10 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
 #endif
     const int item = it % g.n_items;
     const int model = g.item_model[item];
-    float *stm = st_m + max(pend, 0) * 256 + tid, *sts = st_s + max(pend, 0) * 256 + tid;
     if (model < 0) {
-      if (pend >= 0) fb_fx_step<NK, true, true>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts, ls, unscale);
-      else fb_fx_step<NK, true, false>(cur, lane, bq1, bq2, hq, mq, pv, stm, sts, ls, unscale);
-      pend = -1;
+      fb_fx_step<NK, true>(cur, lane, bq1, bq2, hq, pv);
     } else {
-      if (pend >= 0) fb_fx_step<NK, false, true>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts, ls, unscale);
-      else fb_fx_step<NK, false, false>(cur, lane, bx1, bx2, hq, mq, pv, stm, sts, ls, unscale);
+      fb_fx_step<NK, false>(cur, lane, bx1, bx2, hq, pv);
       if constexpr (DUMP) {
         if (row < n_rows) {
           const int tile = tile0 + it / g.n_items;
@@ -741,11 +655,7 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
                                                                     pv[4 * rr + 2] * unscale, pv[4 * rr + 3] * unscale);
         }
       } else {
-#if FB_FX_DEFER
-        pend = model;  // the update runs in the shadow of the next item's MFMAs
-#else
         fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid, ls);
-#endif
       }
     }
 #ifndef FB_ABL_NOLOAD
@@ -756,7 +666,6 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
     __syncthreads();
 #endif
   }
-  if (pend >= 0) fb_lse_update16(pv, st_m + pend * 256 + tid, st_s + pend * 256 + tid, ls);  // the last model item
 
   if constexpr (DUMP) return;
   for (int m = 0; m < g.M; ++m) {
