@@ -911,7 +911,6 @@ __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
 }
-template <bool LEFT>
 __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__restrict__ quad,
                                                    const double *__restrict__ linp, int n_kchunks, int B,
                                                    double *__restrict__ Aall, double *__restrict__ LinvAll,
@@ -1017,70 +1016,8 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
   // inverts it -- the serial part runs in the shadow of the update.
   if (wv == 0) factor_block(0, min(FB_IV_NB, R), 0);
   __syncthreads();
-  // LEFT (left-looking) variant: panel j is brought up to date from the finished panels 0..j-1 right before it
-  // is factored -- A(j0:R, j0:j0+32) -= L(j0:R, 0:j0) L(j0:j0+32, 0:j0)^T -- instead of every panel updating
-  // the whole trailing matrix in place.  Same flops, but the factor is only ever read (R^3/6 doubles in total,
-  // a quarter of the right-looking read-modify-write traffic) and nothing is written twice.  The 32 rows of L
-  // that every tile of the panel needs are staged in LDS once; wave 0 updates and factors the diagonal block
-  // while the other waves update the rows below it.
-  const int ldc = ((R + 30) / 32) * 32 + 2;  // row stride of the staged rows: conflict-free fragment reads
   for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
     const int nb = min(FB_IV_NB, R - j0);
-    if (LEFT && j0 > 0) {
-      double *Lc = Lp;
-      for (int idx = tid; idx < FB_IV_NB * j0; idx += nt) {
-        const int r = idx / j0, c = idx - r * j0;
-        Lc[r * ldc + c] = r < nb ? A[(size_t)(j0 + r) * R + c] : 0.0;
-      }
-      __syncthreads();
-      const int mrows = R - j0, mt = (mrows + 15) / 16;
-      // tile row tr against both 16-column halves of the panel (ncj = 1: only the first half): the row fragment
-      // is loaded once per K chunk, the next chunk is in flight while the current one multiplies
-      auto left_tile = [&](int tr, int ncj) {
-        const int ri = 16 * tr + (lane & 15);
-        const bool rok = ri < mrows;
-        const double *arow = A + (size_t)(j0 + (rok ? ri : 0)) * R + (lane >> 4);
-        const double *brow0 = Lc + (size_t)(lane & 15) * ldc + (lane >> 4);
-        const double *brow1 = brow0 + (size_t)16 * ldc;
-        fb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        double av[8], an[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) av[q] = arow[4 * q];
-        for (int k0 = 0; k0 < j0; k0 += 32) {  // j0 is a multiple of 32
-          const int kn = k0 + 32 < j0 ? k0 + 32 : k0;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) an[q] = arow[kn + 4 * q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const double a = rok ? av[q] : 0.0;
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow0[k0 + 4 * q], acc0, 0, 0, 0);
-            if (ncj > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow1[k0 + 4 * q], acc1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) av[q] = an[q];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int rr2 = 16 * tr + (lane >> 4) + 4 * x, cc2 = lane & 15;
-          if (rr2 < mrows) {
-            double *ap = A + (size_t)(j0 + rr2) * R + j0;
-            if (cc2 < nb) ap[cc2] -= acc0[x];
-            if (ncj > 1 && 16 + cc2 < nb) ap[16 + cc2] -= acc1[x];
-          }
-        }
-      };
-      if (wv == 0) {
-        left_tile(0, 1);
-        if (mt > 1) left_tile(1, 2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        factor_block(j0, nb, pi);
-      } else {
-        for (int tr = 2 + (wv - 1); tr < mt; tr += nw - 1) left_tile(tr, 2);
-      }
-      __syncthreads();
-    }
     // (b) panel below: X = A21 * L11^-T on the float64 matrix cores.  Wave = 16 rows: A fragment straight
     //     from global A (lane l: row l % 16, column 4 q + l / 16), B fragment = L11^-1 from LDS (explicit
     //     zeros above its diagonal), 2 column tiles x 8 steps.  Rows past the end contribute zeros, so the
@@ -1160,9 +1097,7 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
           if (ok[u][x]) *cp[u][x] = cv[u][x] - acc[x];
       }
     };
-    if (LEFT) {
-      // nothing: the next panel pulls its own update
-    } else if (wv == 0) {
+    if (wv == 0) {
       if (m > 0) {  // tiles (0,0), (1,0), (1,1) = the next diagonal block, then its factorisation
         update_tiles(0, 0, 1);
         if (mt16 > 1) update_tiles(1, 0, 2);
@@ -1478,23 +1413,17 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
 void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                         int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
   const int R = iv.R;
-  const size_t ldc = (size_t)((R + 30) / 32) * 32 + 2;
-  const size_t panel = std::max((size_t)(R + 16) * (FB_IV_NB + 2), (size_t)FB_IV_NB * ldc);  // Lp / staged rows / rhs partials
+  const size_t panel = (size_t)(R + 17) * (FB_IV_NB + 2);  // Lp (incl. the right-hand-side row) / rhs partials
   size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + std::max(panel, (size_t)8 * R));
   static bool attr_set = false;
-  // FB_IV_SOLVE=dense: the same factorisation on an unpacked dense copy (585 us); =left: left-looking variant of it
-  // (a quarter of the traffic, but its K loops are L2-latency chains on the critical path: 726 us)
   if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   static const char *mode = getenv("FB_IV_SOLVE");
-  if (mode && strcmp(mode, "dense") == 0)
-    hipLaunchKernelGGL(k_iv_solve<false>, dim3(B), dim3(512), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
-  else if (mode && strcmp(mode, "left") == 0)
-    hipLaunchKernelGGL(k_iv_solve<true>, dim3(B), dim3(512), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
+  if (mode && strcmp(mode, "dense") == 0)  // predecessor: dense copy + separate forward substitution (585 us vs 455 us)
+    hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(512), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
   else  // default: in place on the packed triangle (quad is consumed), right-hand side carried as an extra row
     hipLaunchKernelGGL(k_iv_solve_packed, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
                        LinvAll, ivec, fail);

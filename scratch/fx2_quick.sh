@@ -1,6 +1,6 @@
 #!/bin/bash
-for i in 1 2; do timeout 120 python scratch/gmm_only.py; done
-timeout 120 python scratch/bx_err.py 2>&1 | tail -3
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
-timeout 300 python scratch/fuzz.py 61 150 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q -k "ivector or iv_ or config4 or enroll" 2>&1 | tail -3
+timeout 300 python scratch/fuzz_iv.py 71 100 | tail -2
+FB_IV_SOLVE=dense timeout 300 python scratch/fuzz_iv.py 72 40 | tail -2
+FB_IV_CONTRACT=reg timeout 300 python scratch/fuzz_iv.py 73 40 | tail -2
+timeout 300 python bench.py --arch iv --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-150
