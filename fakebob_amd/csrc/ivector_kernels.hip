@@ -995,13 +995,16 @@ __global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__re
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
-    double li[FB_IV_NB];
+    // (column updates: once li[q] is known it is subtracted from every later row at once -- 31 - q independent
+    //  fmas -- instead of one 496-long dependent chain; the operations and their order per entry are unchanged)
+    double li[FB_IV_NB], ac[FB_IV_NB];
 #pragma unroll
-    for (int r = 0; r < FB_IV_NB; ++r) {
-      double sacc = (r == rr) ? 1.0 : 0.0;
+    for (int r = 0; r < FB_IV_NB; ++r) ac[r] = (r == rr) ? 1.0 : 0.0;
 #pragma unroll
-      for (int q = 0; q < r; ++q) sacc = fma(-Dg[r * LD + q], li[q], sacc);
-      li[r] = sacc * fb_readlane_f64(rinv_mine, r);
+    for (int q = 0; q < FB_IV_NB; ++q) {
+      li[q] = ac[q] * fb_readlane_f64(rinv_mine, q);
+#pragma unroll
+      for (int r = q + 1; r < FB_IV_NB; ++r) ac[r] = fma(-Dg[r * LD + q], li[q], ac[r]);
     }
     if (lane < FB_IV_NB) {
 #pragma unroll
@@ -1248,13 +1251,16 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
-    double li[FB_IV_NB];
+    // (column updates: once li[q] is known it is subtracted from every later row at once -- 31 - q independent
+    //  fmas -- instead of one 496-long dependent chain; the operations and their order per entry are unchanged)
+    double li[FB_IV_NB], ac[FB_IV_NB];
 #pragma unroll
-    for (int r = 0; r < FB_IV_NB; ++r) {
-      double sacc = (r == rr) ? 1.0 : 0.0;
+    for (int r = 0; r < FB_IV_NB; ++r) ac[r] = (r == rr) ? 1.0 : 0.0;
 #pragma unroll
-      for (int q = 0; q < r; ++q) sacc = fma(-Dg[r * LD + q], li[q], sacc);
-      li[r] = sacc * fb_readlane_f64(rinv_mine, r);
+    for (int q = 0; q < FB_IV_NB; ++q) {
+      li[q] = ac[q] * fb_readlane_f64(rinv_mine, q);
+#pragma unroll
+      for (int r = q + 1; r < FB_IV_NB; ++r) ac[r] = fma(-Dg[r * LD + q], li[q], ac[r]);
     }
     if (lane < FB_IV_NB) {
 #pragma unroll
