@@ -1,4 +1,6 @@
 #!/bin/bash
-timeout 900 python -m pytest tests -m gpu -x -q -k "ivector or iv_ or config4 or enroll" 2>&1 | tail -3
-timeout 300 python scratch/fuzz_iv.py 101 100 | tail -2
-bash scratch/iv_prof.sh x 2>&1 | grep -E "solve|it/s"
+for f in "" "-DFB_FX_IPB=2" "-DFB_FX_IPB=3" "-DFB_FX_OCC=3" "-DFB_FX_IPB=2 -DFB_FX_OCC=3"; do
+  FB_EXTRA_HIPCC_FLAGS="$f" python -c "from fakebob_amd import build; build.build(force=True)" >/dev/null 2>&1
+  echo "== [$f]"; python scratch/gmm_only.py; python scratch/gmm_only.py
+  python scratch/bx_err.py 2>&1 | tail -1
+done
