@@ -142,6 +142,12 @@ def bench_ivector(args, torch):
                         "mfma_f64": {"executed_flops_per_launch": flops_exec,
                                      "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                      "frac": flops_exec / (con_ms * 1e-3) / 1e12 / 78.6}}}
+    try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as r:
+            out["roofline"]["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
+    except Exception:
+        pass
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         import numpy as np
