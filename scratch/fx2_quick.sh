@@ -1,6 +1,6 @@
 #!/bin/bash
-for f in "" "-DFB_FX_IPB=2" "-DFB_FX_IPB=3" "-DFB_FX_OCC=3" "-DFB_FX_IPB=2 -DFB_FX_OCC=3"; do
-  FB_EXTRA_HIPCC_FLAGS="$f" python -c "from fakebob_amd import build; build.build(force=True)" >/dev/null 2>&1
-  echo "== [$f]"; python scratch/gmm_only.py; python scratch/gmm_only.py
-  python scratch/bx_err.py 2>&1 | tail -1
-done
+timeout 900 python -m pytest tests -m gpu -x -q -k "ivector or iv_ or config4 or enroll or fuzz" 2>&1 | tail -3
+timeout 300 python scratch/fuzz_iv.py 111 120 | tail -2
+bash scratch/iv_prof.sh x 2>&1 | grep -E "stats|contract|it/s"
+bash scratch/pmc_iv.sh pf2 WRITE_SIZE 2>&1 | grep stats
+timeout 300 python bench.py --arch iv --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-150
