@@ -338,3 +338,27 @@ def test_fakebob_rejects_models_without_the_engine():
             return 0.0
     with pytest.raises(TypeError):
         FakeBob("SV", "targeted", Plain())
+
+
+def test_bench_roofline_object_and_traffic_file_follow_the_contract():
+    """bench.py's roofline object: the keys the measurement contract names, algorithmic flops of SURVEY.md 8(d),
+    and the committed PMC traffic file holds an entry for every GMM kernel variant and for the contraction."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fb_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    flops = (bench.S_SPK + 1) * bench.C_GAUSS * 4 * bench.D_FEAT * 15300
+    assert flops == 6 * 2048 * 288 * 15300 and 54.0e9 < flops < 54.2e9      # 54.1 GFLOP per NES batch
+    r = bench._gmm_roofline(achieved=flops / 115e-6 / 1e12, flops_launch=flops, gmm_ms_avg=0.115)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["executed_frac"] < 1.0                                 # utilisation of the pipe the MFMAs run on
+    with open(os.path.join(root, "profiles", "r01_traffic.json")) as f:
+        tr = json.load(f)["kernels"]
+    for key in ("k_gmm_fx2<5, false>", "k_gmm_bx3<5, false>", "k_gmm<36, false>", "k_iv_contract_dma<lin>+<quad>"):
+        assert tr[key]["hbm_bytes_per_launch"] > 0
+    assert bench.GMM_TRAFFIC_KEY in tr
