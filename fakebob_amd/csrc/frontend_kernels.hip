@@ -9,6 +9,9 @@
 // Precision policy = the oracle's: float64 between Kaldi's float32 storage points.
 #include <float.h>
 
+#include <cstring>
+#include <cstdlib>
+
 #include "fb_device.h"
 #include "fb_kernels.h"
 
@@ -473,6 +476,244 @@ __global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFront
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_mfcc_r16: P = 512 with FOUR frames per wave.  16 lanes own one frame and 16 complex points each, so the 256-point
+// complex FFT is two radix-16 passes held in registers with ONE transpose through LDS between them (k_mfcc_r4: three
+// exchanges per frame), and every LDS / DPP round trip of the remaining stages serves four frames.  Same arithmetic
+// (float64 between Kaldi's float32 storage points), different summation trees than k_mfcc_r4 -- both sit within 1e-6 of
+// the oracle.  16 lanes = one DPP row: the per-frame reductions are four row-local DPP steps.
+#define FB_R16_WAVES 8
+#define FB_R16_SLOTS 272  // complex slots per frame buffer: 256 + one pad per 16 (conflict-free 16 x 16 transpose)
+__device__ __forceinline__ int fb_r16_phys(int k) { return k + (k >> 4); }
+__device__ __forceinline__ int fb_row_sum_i32(int v) {  // total of the 16 lanes of a DPP row, in every lane
+  v += fb_dpp_i32<0xb1, 0xf>(v);
+  v += fb_dpp_i32<0x4e, 0xf>(v);
+  v += fb_dpp_i32<0x141, 0xf>(v);
+  v += fb_dpp_i32<0x140, 0xf>(v);
+  return v;
+}
+__device__ __forceinline__ double fb_row_sum_f64(double v) {
+  v += fb_dpp_f64<0xb1, 0xf>(v);
+  v += fb_dpp_f64<0x4e, 0xf>(v);
+  v += fb_dpp_f64<0x141, 0xf>(v);
+  v += fb_dpp_f64<0x140, 0xf>(v);
+  return v;
+}
+// forward 16-point DFT in registers, natural order in and out: 4 x dft4 over n1 (n = 4 n1 + n2), twiddles
+// W16^(n2 k1), 4 x dft4 over n2 (k = k1 + 4 k2)
+__device__ __forceinline__ void fb_dft16(double2 (&v)[16]) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) fb_dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);  // -> A[n2][k1] at v[4 k1 + n2]
+  constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;
+  // W16^m = (cos(pi m / 8), -sin(pi m / 8)), m = n2 * k1
+  const double2 W1 = make_double2(C1, -S1), W2 = make_double2(R2, -R2), W3 = make_double2(S1, -C1),
+                W4 = make_double2(0.0, -1.0), W6 = make_double2(-R2, -R2), W9 = make_double2(-C1, S1);
+  v[4 * 1 + 1] = fb_cmul(v[4 * 1 + 1], W1);
+  v[4 * 1 + 2] = fb_cmul(v[4 * 1 + 2], W2);
+  v[4 * 1 + 3] = fb_cmul(v[4 * 1 + 3], W3);
+  v[4 * 2 + 1] = fb_cmul(v[4 * 2 + 1], W2);
+  v[4 * 2 + 2] = fb_cmul(v[4 * 2 + 2], W4);
+  v[4 * 2 + 3] = fb_cmul(v[4 * 2 + 3], W6);
+  v[4 * 3 + 1] = fb_cmul(v[4 * 3 + 1], W3);
+  v[4 * 3 + 2] = fb_cmul(v[4 * 3 + 2], W6);
+  v[4 * 3 + 3] = fb_cmul(v[4 * 3 + 3], W9);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) fb_dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);  // X[k1 + 4 k2] at v[4 k1 + k2]
+  // natural order: out[k1 + 4 k2] <- v[4 k1 + k2]  (a 4 x 4 transpose of register names)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) { const double2 tmp = v[4 * i + j]; v[4 * i + j] = v[4 * j + i]; v[4 * j + i] = tmp; }
+}
+
+__global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev fe, int melw_n,
+                                                                   const int16_t *__restrict__ wav,
+                                                                   const int4 *__restrict__ frame_rec,
+                                                                   int total_frames, float *__restrict__ mfcc) {
+  if (fe.stop && *fe.stop) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NT = 64 * FB_R16_WAVES, Nc = 256;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = lane & 15, fq = lane >> 4;
+  const int L = fe.L, nb = fe.nb, nc = fe.nc;
+  const MfccR4Lds lo = fb_mfcc_r4_layout(L, nb, nc, melw_n);  // same table layout as k_mfcc_r4
+  double2 *s_tw = reinterpret_cast<double2 *>(smem + lo.tw);
+  double2 *s_twf = reinterpret_cast<double2 *>(smem + lo.twf);
+  float *s_win = reinterpret_cast<float *>(smem + lo.win);
+  float *s_melw = reinterpret_cast<float *>(smem + lo.melw);
+  float *s_dct = reinterpret_cast<float *>(smem + lo.dct);
+  float *s_lift = reinterpret_cast<float *>(smem + lo.lift);
+  int *s_mfirst = reinterpret_cast<int *>(smem + lo.melidx), *s_mlen = s_mfirst + nb, *s_moff = s_mlen + nb;
+  double2 *X = reinterpret_cast<double2 *>(smem + lo.wave0) + ((size_t)w * 4 + fq) * FB_R16_SLOTS;  // this frame's buffer
+  for (int i = tid; i < Nc; i += NT) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
+  for (int i = tid; i <= Nc; i += NT) s_twf[i] = reinterpret_cast<const double2 *>(fe.tw_full)[i];
+  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
+  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
+  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
+  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
+  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
+  __syncthreads();
+
+  const int n_groups = (total_frames + 3) >> 2;
+  const int w_glob = blockIdx.x * FB_R16_WAVES + w, w_step = gridDim.x * FB_R16_WAVES;
+  const int t_lane = t;
+  // samples of points p = 16 a + t of frame 4 g + fq: s0 = 32 a + 2 t and s0 + 1, packed into one register per point
+  // (the pre-emphasis neighbour s0 - 1 is the previous lane's second sample).  The next group's samples are requested
+  // before the current group is processed, so their L2 latency is off the critical path.
+  auto load_group = [&](int g, int tl, int (&xq)[16]) {
+    const int fl = 4 * g + fq;
+    const int4 rec = frame_rec[fl < total_frames ? fl : total_frames - 1];
+    const int64_t abs_start = ((int64_t)(unsigned)rec.x) | ((int64_t)rec.y << 32);
+    const int start = rec.z, n = rec.w;
+    const bool interior = start >= 0 && start + L <= n;
+    if (__all(interior)) {
+      const int16_t *fr = wav + abs_start;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {  // unconditional loads on clamped indices, masked afterwards
+        const int s0 = 32 * a + 2 * tl;
+        const int lo16 = fr[min(s0, L - 1)], hi16 = fr[min(s0 + 1, L - 1)];
+        xq[a] = (hi16 << 16) | (lo16 & 0xffff);
+      }
+    } else {
+      const int16_t *wv = wav + (abs_start - start);
+      auto sample = [&](int sidx) -> int {  // reflected at the utterance edges
+        int64_t k = (int64_t)start + sidx;
+        while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
+        return wv[k];
+      };
+#pragma unroll 1
+      for (int a = 0; a < 16; ++a) {
+        const int s0 = 32 * a + 2 * tl;
+        const int lo16 = sample(min(s0, L - 1)), hi16 = sample(min(s0 + 1, L - 1));
+        xq[a] = (hi16 << 16) | (lo16 & 0xffff);
+      }
+    }
+  };
+  int xn[16];
+  if (w_glob < n_groups) load_group(w_glob, t_lane, xn);
+  for (int g = w_glob; g < n_groups; g += w_step) {
+    // Everything below that depends only on the lane (clamped sample indices, window weights, twiddles: > 150
+    // registers) is loop-invariant; hoisted it spills, so the lane index is laundered through an empty asm per trip.
+    int t = t_lane;
+    asm volatile("" : "+v"(t));
+    const int f = 4 * g + fq;
+    const bool fvalid = f < total_frames;
+    int xp[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) xp[a] = xn[a];
+    if (g + w_step < n_groups) load_group(g + w_step, t, xn);
+    int isum = 0;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      const int s0 = 32 * a + 2 * t;
+      isum += (s0 < L ? (int)(short)xp[a] : 0) + (s0 + 1 < L ? (xp[a] >> 16) : 0);
+    }
+    // DC: the samples are integers, |sum| < 2^24: exact in int32 in any order
+    const double mean = fe.remove_dc ? (double)fb_row_sum_i32(isum) / (double)L : 0.0;
+    double en = 0.0, en2 = 0.0;
+    double2 v[16];
+    int prev_rot = 0;  // row-rotated second samples of point a - 1
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      const int s0 = 32 * a + 2 * t;
+      const int xa0 = (int)(short)xp[a], xa1 = xp[a] >> 16;
+      const int rot = fb_dpp_i32<0x121, 0xf>(xa1);  // row_ror:1: lane t gets lane (t - 1) & 15
+      const int xprev = t == 0 ? (a == 0 ? xa0 : prev_rot) : rot;  // Kaldi: sample 0 is pre-emphasised with itself
+      prev_rot = rot;
+      const float2 wq = *reinterpret_cast<const float2 *>(&s_win[min(s0, (L - 1) & ~1)]);  // L even: the pair exists
+      const double w0 = s0 < L ? (double)wq.x : 0.0, w1 = s0 + 1 < L ? (double)wq.y : 0.0;
+      const double m0 = s0 < L ? 1.0 : 0.0, m1 = s0 + 1 < L ? 1.0 : 0.0;
+      const double av = ((double)xa0 - mean) * m0, cv = ((double)xa1 - mean) * m1;
+      const double pm = (double)xprev - mean;
+      en = fma(av, av, en);
+      en = fma(cv, cv, en);
+      const double y0 = (av - fe.preemph * pm) * w0;
+      const double y1 = (cv - fe.preemph * av) * w1;
+      en2 = fma(y0, y0, en2);
+      en2 = fma(y1, y1, en2);
+      v[a] = make_double2(y0, y1);
+    }
+    const double energy = fb_row_sum_f64(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
+
+    // ---- 256-point FFT = radix-16 over a, twiddle W256^(t k1), transpose, radix-16 over b
+    fb_dft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+      v[k1] = fb_cmul(v[k1], s_tw[(t * k1) & (Nc - 1)]);
+      if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 twiddle loads in flight: bounds the live registers
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) X[fb_r16_phys(16 * k1 + t)] = v[k1];
+    fb_wave_sync();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = X[fb_r16_phys(16 * t + b)];
+    fb_dft16(v);  // v[k2] = Z[t + 16 k2]
+    fb_wave_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) X[fb_r16_phys(t + 16 * k2)] = v[k2];
+    fb_wave_sync();
+    // ---- real-FFT unpack + power spectrum of bins k = t + 16 k2 (and bin 256 in lane t = 0)
+    double pwv[17];
+#pragma unroll
+    for (int k2 = 0; k2 < 17; ++k2) {
+      const int kc = k2 < 16 ? t + 16 * k2 : Nc;
+      const double2 zk = k2 < 16 ? v[k2 & 15] : X[fb_r16_phys(0)];
+      const double2 zr = X[fb_r16_phys((Nc - kc) & (Nc - 1))];
+      const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);
+      const double dr = zk.x - zr.x, di = zk.y + zr.y;
+      const double orr = 0.5 * di, oi = -0.5 * dr;
+      const double2 wk = s_twf[kc];
+      const double xr = er + (wk.x * orr - wk.y * oi);
+      const double xi = ei + (wk.x * oi + wk.y * orr);
+      pwv[k2] = xr * xr + xi * xi;
+      if ((k2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    fb_wave_sync();
+    double *PW = reinterpret_cast<double *>(X);  // 257 doubles; LM behind it
+    double *LM = PW + 264;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) PW[t + 16 * k2] = pwv[k2];
+    if (t == 0) PW[Nc] = pwv[16];
+    fb_wave_sync();
+    // ---- mel filterbank + log: lane t takes filters t and t + 16; the free second slot of lane 15 (nb <= 31)
+    //      takes the log of the frame energy
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int m = t + 16 * half;
+      double e = 0.0;
+      if (m < nb) {
+        const float *wm = s_melw + s_moff[m];
+        const int first = s_mfirst[m], len = s_mlen[m];
+#pragma unroll 4
+        for (int i = 0; i < len; ++i) e = fma((double)wm[i], PW[first + i], e);
+      }
+      const bool is_energy = half == 1 && t == 15;
+      if (is_energy) e = energy;
+      if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
+      const double le = fb_log_f64(e);
+      if (m < nb) LM[m] = le;
+      if (is_energy) LM[nb] = le < fe.log_energy_floor ? fe.log_energy_floor : le;
+    }
+    fb_wave_sync();
+    // ---- DCT-II, lifter, C0 <- log energy: lane t takes coefficients t and t + 16
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c = t + 16 * half;
+      if (c < nc) {
+        const float *dr = s_dct + c * nb;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int m = 0; m < nb; ++m) acc = fma((double)dr[m], LM[m], acc);
+        acc *= (double)s_lift[c];
+        float o = (float)acc;
+        if (c == 0 && fe.use_energy) o = (float)LM[nb];
+        if (fvalid) mfcc[(size_t)f * nc + c] = o;
+      }
+    }
+    fb_wave_sync();
+  }
+}
+
 int fb_mfcc_layout_doubles(int P, int L, int nb, int nc, int melw_n) {
   const MfccLds lo = fb_mfcc_layout(P, L, nb, nc, melw_n);
   return lo.wave0 + 4 * lo.per_wave;
@@ -482,6 +723,25 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
                     const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
                     int total_frames, float *mfcc) {
   if (total_frames <= 0) return;
+  const char *mfcc_mode = getenv("FB_MFCC");  // r4: the one-frame-per-wave predecessor (read per launch: tests switch it)
+  const bool want_r4 = mfcc_mode && strcmp(mfcc_mode, "r4") == 0;
+  if (fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2 && !want_r4) {
+    const MfccR4Lds l16 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
+    const size_t shm16 = sizeof(double) * (size_t)l16.wave0 + sizeof(double2) * (size_t)FB_R16_WAVES * 4 * FB_R16_SLOTS;
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr16 = true;
+    }
+    if (shm16 <= 160 * 1024) {
+      const int n_groups = (total_frames + 3) / 4;
+      const int rounds = (n_groups + 256 * FB_R16_WAVES - 1) / (256 * FB_R16_WAVES);
+      const int blocks = (n_groups + rounds * FB_R16_WAVES - 1) / (rounds * FB_R16_WAVES);
+      hipLaunchKernelGGL(k_mfcc_r16, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
+                         reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
+      return;
+    }
+  }
   if (fe.P == 512 && fe.nb <= 31) {
     const MfccR4Lds l4 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
     const size_t shm4 = sizeof(double) * (size_t)(l4.wave0 + FB_R4_WAVES * l4.per_wave);

@@ -224,3 +224,27 @@ def test_empty_and_degenerate_batches_are_errors_not_crashes():
         assert tv[0] > 0 and np.isfinite(r).all()
     finally:
         e.close()
+
+
+def test_one_frame_per_wave_mfcc_kernel_still_matches(oracle, monkeypatch):
+    """k_mfcc_r16 (four frames per wave, radix-16 passes in registers) is the default for 512-point frames;
+    FB_MFCC=r4 selects its predecessor k_mfcc_r4.  Both against the oracle, and against each other."""
+    e = Engine(0)
+    try:
+        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
+        e.load_gmm([ubm] + spk)
+        cfg = oracle.default_cfg()
+        for utt, n in ((0, 48000), (1, 9000), (4, 100000)):
+            w = _wav(utt, n)
+            mo = oracle.mfcc(cfg, w)
+            monkeypatch.delenv("FB_MFCC", raising=False)
+            m16 = e.debug_mfcc(w)
+            monkeypatch.setenv("FB_MFCC", "r4")
+            m4 = e.debug_mfcc(w)
+            assert m16.shape == mo.shape == m4.shape
+            assert np.abs(m16.astype(np.float64) - mo).max() <= 2e-5
+            assert np.abs(m4.astype(np.float64) - mo).max() <= 2e-5
+            assert np.array_equal(m16[:, 0], m4[:, 0])            # C0 = log energy: no FFT involved
+            assert np.abs(m16 - m4).max() <= 2e-5
+    finally:
+        e.close()
