@@ -35,7 +35,80 @@ if ROOT not in sys.path:
 
 S_SPK, C_GAUSS, D_FEAT, SPD, N_SAMPLES = 5, 2048, 72, 50, 48000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (32x32x16)
+PEAK_F64_MFMA_TFLOPS = 78.6
+PEAK_HBM_GBPS = 8000.0
 README_GMM_ITS = 0.20         # reference README.md:113 (~5 s / iteration, unspecified CPU)
+
+
+class Workers(object):
+    """K persistent host threads, one per attack in flight (ctypes releases the GIL).  The threads exist before
+    the timed region starts: `run` only releases them, so no thread creation / start-up is timed."""
+
+    def __init__(self, K, fn):
+        import threading
+        self.K, self.fn = K, fn
+        self.go = threading.Barrier(K + 1)
+        self.done = threading.Barrier(K + 1)
+        self.job = None
+        self.err = [None] * K
+        self.threads = [threading.Thread(target=self._loop, args=(k,), daemon=True) for k in range(K)]
+        for t in self.threads:
+            t.start()
+
+    def _loop(self, k):
+        while True:
+            self.go.wait()
+            if self.job is None:
+                return
+            try:
+                self.fn(k, *self.job)
+            except BaseException as ex:  # noqa: BLE001 -- re-raised on the main thread
+                self.err[k] = ex
+            self.done.wait()
+
+    def run(self, *job):
+        self.job = job
+        self.go.wait()
+        self.done.wait()
+        for ex in self.err:
+            if ex is not None:
+                raise ex
+
+    def close(self):
+        self.job = None
+        self.go.wait()
+        for t in self.threads:
+            t.join()
+
+
+def emit(out):
+    """ONE JSON line, last on stdout: C-level stdio (RCCL / gloo banners) is flushed first."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run with one rank per GPU
+    (the contract's launch line), so the plain command measures N GPUs and prints n_gpus = N."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def cpu_baseline(audio, models, params_kw):
@@ -74,134 +147,212 @@ def cpu_baseline(audio, models, params_kw):
     return out
 
 
+def dist_setup(args, torch):
+    """(rank, world, device index, dist module or None).  One process per GPU under torchrun; RCCL only carries
+    the barrier, the max-over-ranks time and the final counter reduction."""
+    from fakebob_amd import parallel
+    rank, local_rank, world = parallel.dist_env()
+    dev_index = 0 if args.same_device else local_rank
+    if world > 1 and not args.same_device and dev_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d: --gpus %d but only %d GPUs are visible" % (rank, world, torch.cuda.device_count()))
+    dist = None
+    if world > 1 or args.force_dist:
+        if args.force_dist and world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            import torch.distributed as dist
+            if args.dist_backend == "nccl":
+                torch.cuda.set_device(dev_index)
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+        else:
+            if args.dist_backend == "nccl":
+                torch.cuda.set_device(dev_index)
+            dist = parallel.init_process_group(args.dist_backend)
+    if world > 1 and args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+    return rank, world, dev_index, dist
+
+
+def timed_region(args, torch, dist, workers, K):
+    """W untimed warm-up steps, then EXACTLY --steps steps of every attack in flight between two
+    (barrier + device synchronize) pairs; max over ranks.  Returns seconds."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        workers.run(args.warmup, False)
+    barrier()
+    barrier()                                               # the first collective of a communicator pays its lazy set-up
+    t0 = time.perf_counter()
+    workers.run(args.steps, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def bench_ivector(args, torch):
     """BASELINE.json configs[2]: i-vector-PLDA SV targeted attack, spd=50, C=2048, D=72, R=400, LDA 200
     (the T-matrix contraction path).  Not the headline metric: run with --arch iv."""
+    from fakebob_amd import parallel
     from fakebob_amd.engine import Engine, nes_params
     from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+    rank, world, dev_index, dist = dist_setup(args, torch)
     t0 = time.perf_counter()
     sy = synthetic_ivector_system(C=C_GAUSS, D=D_FEAT, R=400, L=200, n_speakers=1)
     sy = sy.with_enrolled(sy.enrolled, [-40.0], [10.0])
-    import threading
     K = max(1, args.streams)
     engs = []
     for k in range(K):
-        e = Engine(0)
+        e = Engine(dev_index)
         e.load_ivector(sy, "SV")
         engs.append(e)
     eng = engs[0]
     t_load = time.perf_counter() - t0
     kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_iter=1000, threshold=1.0)
-    auds = [synthetic_audio(k, N_SAMPLES) for k in range(K)]
-    prms = [nes_params("SV", "targeted", seed=42, stream=k, **kw) for k in range(K)]
-    audio, p = auds[0], prms[0]
+    auds = [synthetic_audio(rank * K + k, N_SAMPLES) for k in range(K)]
+    prms = [nes_params("SV", "targeted", seed=42, stream=rank * K + k, **kw) for k in range(K)]
     res = [None] * K
 
-    def run_all(n, timed):
-        def run(k):
-            res[k] = engs[k].bench_nes(prms[k], auds[k], 0, n, time_gmm=timed)
-        ths = [threading.Thread(target=run, args=(k,)) for k in range(K)]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
+    def run(k, n, timed):
+        res[k] = engs[k].bench_nes(prms[k], auds[k], 0, n, time_gmm=timed)
 
-    run_all(max(1, args.warmup), False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_all(args.steps, True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms_dev, ms_con, rows = res[0]
+    workers = Workers(K, run)
+    workers.run(max(2, args.precondition // 3), False)     # module load, first-touch allocations, clock ramp: outside everything
+    dt = timed_region(args, torch, dist, workers, K)
     ms_con = sum(r[1] for r in res) / K
-    its = K * args.steps / dt
-    tri = 400 * 401 // 2
-    bytes_stream = 8.0 * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)       # Sigma^-1 M + U, float64, read once
-    n_active = eng.debug_iv_active()
-    n_bgroups = (SPD + 1 + 63) // 64                                   # utterance groups of 64 -> passes over the rows
-    bytes_exec = 8.0 * n_active * (D_FEAT * 400 + tri) * n_bgroups
-    # f64 MFMA work actually issued: 64-row tiles (51 useful), only the active rows
-    flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * 400 + tri)
-    con_ms = ms_con / args.steps
-    out = {"metric": "NES iterations/sec (i-vector-PLDA SV, samples_per_draw=50, 3 s@16 kHz)", "value": its,
-           "unit": "NES iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64 (extractor/PLDA), f32 MFMA (gselect)", "data": "synthetic",
-           "vs_readme_nominal": its / 0.083,
-           "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
-                                  "%d attacks in flight" % K, "attacks_in_flight_per_gpu": K,
-                      "voiced_rows_per_iter": rows, "model_load_s": t_load},
-           "roofline": {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
-                                  "v_mfma_f64_16x16x4, active rows only)", "bound": "hbm",
-                        "achieved": bytes_stream / (con_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": bytes_stream / (con_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                        "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_stream,
-                        "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
-                        "executed_gbps": bytes_exec / (con_ms * 1e-3) / 1e9,
-                        "note": "algorithmic = both matrices streamed once (SURVEY.md 8(d)); the kernels stream only "
-                                "the rows of components with posterior mass, once per 64-utterance group",
-                        "flops_per_launch": 2.0 * (SPD + 1) * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri),
-                        "mfma_f64": {"executed_flops_per_launch": flops_exec,
-                                     "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
-                                     "frac": flops_exec / (con_ms * 1e-3) / 1e12 / 78.6}}}
-    try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as r:
-            out["roofline"]["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
-        out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
-    except Exception:
-        pass
-    if not args.no_cpu_baseline:
-        from oracle import oracle as O
-        import numpy as np
-        ctx = O.IvSystemCtx(O.default_cfg(), sy, nthreads=1)
-        n_s = SPD + 1                                        # one full NES batch (a few seconds of CPU work)
-        wavs = [(synthetic_audio(u, N_SAMPLES) * 32768).astype(np.int16) for u in range(n_s)]
-        t0 = time.perf_counter()
-        ctx.score_batch(wavs)
-        t8 = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / t8, "unit": "NES iterations/s", "cores": 1,
-                               "kind": "port", "sample": "the %d utterances of one NES batch (3 s each) scored by the CPU "
-                               "oracle, 1 thread, %.1f s" % (n_s, t8)}
-    print(json.dumps(out))
+    rows = res[0][2]
+    total_steps = args.steps * K
+    if dist is not None:
+        total_steps = parallel.reduce_counters([total_steps], dist)[0]
+        assert total_steps == world * args.steps * K
+    its = total_steps / dt
+    single = None
+    if rank == 0 and K > 1 and not args.no_single:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.bench_nes(prms[0], auds[0], 0, args.steps, time_gmm=False)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
+                  "note": "one attack in flight (a single launch chain), same workload"}
+    workers.close()
+    if rank == 0:
+        tri = 400 * 401 // 2
+        n_active = eng.debug_iv_active()
+        n_bgroups = (SPD + 1 + 63) // 64                                   # utterance groups of 64 -> passes over the rows
+        # ALGORITHMIC bytes of the T-matrix contraction: the float64 rows of Sigma^-1 M and U of every component with
+        # posterior mass, read once per launch pair -- Kaldi's own loop skips gamma == 0 components
+        # (IvectorExtractor::GetIvectorDistMean/Prior, SURVEY.md A.9); the kernels stream exactly these rows once per
+        # 64-utterance group (one group at spd=50)
+        bytes_alg = 8.0 * n_active * (D_FEAT * 400 + tri)
+        bytes_all = 8.0 * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)
+        bytes_exec = bytes_alg * n_bgroups
+        flops_alg = 2.0 * (SPD + 1) * n_active * (D_FEAT * 400 + tri)
+        flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * 400 + tri)   # 64-row MFMA tiles, 51 useful
+        con_ms = ms_con / args.steps
+        gbps = bytes_alg / (con_ms * 1e-3) / 1e9
+        out = {"metric": "NES iterations/sec (i-vector-PLDA SV, samples_per_draw=50, 3 s@16 kHz)", "value": its,
+               "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64 (extractor/PLDA), f32 (gselect: two-term f16 split on MFMA)", "data": "synthetic",
+               "vs_readme_nominal": its / 0.083,
+               "single_attack": single,
+               "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
+                                      "%d attacks in flight per GPU" % K, "attacks_in_flight_per_gpu": K,
+                          "voiced_rows_per_iter": rows, "model_load_s": t_load},
+               "roofline": {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
+                                      "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
+                            "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                            "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
+                            "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
+                            "all_components_bytes": bytes_all,
+                            "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
+                                    "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the two "
+                                    "contraction kernels, HIP events on the attack's stream (with several attacks in flight "
+                                    "it includes time shared with other attacks' kernels)",
+                            "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
+                                         "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,
+                                         "peak_tflops": PEAK_F64_MFMA_TFLOPS,
+                                         "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}}
+        try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
+                out["roofline"]["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
+        except Exception:
+            pass
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            import numpy as np
+            ctx = O.IvSystemCtx(O.default_cfg(), sy, nthreads=1)
+            n_s = SPD + 1                                        # one full NES batch (a few seconds of CPU work)
+            wavs = [(synthetic_audio(u, N_SAMPLES) * 32768).astype(np.int16) for u in range(n_s)]
+            t0 = time.perf_counter()
+            ctx.score_batch(wavs)
+            t8 = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": 1.0 / t8, "unit": "NES iterations/s", "cores": 1,
+                                   "kind": "port", "sample": "the %d utterances of one NES batch (3 s each) scored by the CPU "
+                                   "oracle, 1 thread, %.1f s" % (n_s, t8)}
+        emit(out)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     for e in engs:
         e.close()
 
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
 GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2<5, false>", "bx3": "k_gmm_bx3<5, false>", "f32": "k_gmm<36, false>"}[GMM_MODE]
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (MI355X_MICROARCH.md)
-# bf16 32x32x16 chain on random operands, this chip, scratch/bx_probe.hip: the clock drops to ~1.6 GHz
-# under a saturated bf16 matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
-BF16_MFMA_POWER_LIMITED_TFLOPS = 1660.0
+TRAFFIC_FILE = "r01_traffic.json"
+# bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip): the clock drops to ~1.6 GHz
+# under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
+MFMA16_POWER_LIMITED_TFLOPS = 1660.0
 
 
-def _gmm_roofline(achieved, flops_launch, gmm_ms_avg):
+def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows):
+    """Roofline of the dominant kernel.  `achieved` = ALGORITHMIC flops ((S+1)*C*4D per voiced frame,
+    two length-D dot products per component per model as Kaldi evaluates them) / average launch duration;
+    `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16/bf16: 2.5 PF; the plain-f32 kernel:
+    157.3 TF), so `frac` is a true fraction.  `executed_*`: the products the kernel really issues -- (1+M)/(2M) of
+    the algorithmic ones because the quadratic term is shared by the 6 models, times 3 (fx2) / 6 (bx3) partial
+    products per f32 product, times the K padding."""
     M = S_SPK + 1
     shared = (1 + M) / (2.0 * M)
-    r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": gmm_ms_avg,
-         "algorithmic_flops_per_launch": flops_launch}
+    per_s = 1.0 / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
+    achieved = flops_launch * per_s
     if GMM_MODE == "fx2":
         nk = (D_FEAT + 1 + 15) // 16
-        ex = flops_launch * shared * 3 * (16.0 * nk / D_FEAT)
-        ex_t = ex / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
-        r.update({"kernel": "k_gmm_fx2<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term "
-                            "f16 split accurate to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, "
-                            "f32 accumulate)",
-                  "executed_flops_per_launch": ex, "executed_tflops": ex_t, "executed_pipe": "f16 MFMA",
-                  "executed_frac": ex_t / PEAK_BF16_MFMA_TFLOPS,
-                  "executed_frac_of_power_limited_ceiling": ex_t / BF16_MFMA_POWER_LIMITED_TFLOPS})
+        ex, pipe, peak = flops_launch * shared * 3 * (16.0 * nk / D_FEAT), "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
+        name = ("k_gmm_fx2<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split accurate "
+                "to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, f32 accumulate)")
     elif GMM_MODE == "bx3":
         nk = (D_FEAT + 3 + 15) // 16
-        ex = flops_launch * shared * 6 * (16.0 * nk / D_FEAT)
-        ex_t = ex / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
-        r.update({"kernel": "k_gmm_bx3<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as an exact "
-                            "3-way bf16 split, 6 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate)",
-                  "executed_flops_per_launch": ex, "executed_tflops": ex_t, "executed_pipe": "bf16 MFMA",
-                  "executed_frac": ex_t / PEAK_BF16_MFMA_TFLOPS,
-                  "executed_frac_of_power_limited_ceiling": ex_t / BF16_MFMA_POWER_LIMITED_TFLOPS})
+        ex, pipe, peak = flops_launch * shared * 6 * (16.0 * nk / D_FEAT), "bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_F16_MFMA_TFLOPS
+        name = ("k_gmm_bx3<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as an exact 3-way bf16 split, "
+                "6 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")
     else:
-        r.update({"kernel": "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)",
-                  "executed_flops_per_launch": flops_launch * shared, "executed_tflops": achieved * shared,
-                  "executed_pipe": "f32 MFMA", "executed_frac": achieved * shared / PEAK_F32_MFMA_TFLOPS})
+        ex, pipe, peak = flops_launch * shared, "f32 MFMA (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS
+        name = "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)"
+    r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+         "traffic": None, "avg_launch_ms": gmm_ms_avg, "algorithmic_flops_per_launch": flops_launch,
+         "kernel": name, "peak_pipe": pipe,
+         "executed_flops_per_launch": ex, "executed_tflops": ex * per_s, "executed_frac": ex * per_s / peak}
+    if peak == PEAK_F16_MFMA_TFLOPS:
+        r["executed_frac_of_power_limited_ceiling"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS
+    if solo_ms and solo_ms > 0:
+        fl_solo = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows
+        r["solo_launch_ms"] = solo_ms
+        r["solo_achieved"] = fl_solo / (solo_ms * 1e-3) / 1e12
+        r["solo_frac"] = r["solo_achieved"] / peak
+        r["solo_executed_frac"] = r["solo_frac"] * ex / flops_launch
     return r
 
 
@@ -212,27 +363,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=3, help="attacks in flight per GPU (one engine/stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra one-attack-in-flight measurement")
     ap.add_argument("--arch", default="gmm", choices=["gmm", "iv"], help="gmm = headline (configs[1]); iv = configs[2]")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
+    ap.add_argument("--precondition", type=int, default=60,
+                    help="untimed iterations per attack run once before the declared warm-up (module load, first-touch "
+                         "allocations, clock ramp of a cold GPU); reported in config.precondition_steps")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even with one rank (exercises RCCL on a 1-GPU box)")
     args = ap.parse_args()
+    self_launch(args)
 
     import torch  # device sync + torch.distributed (RCCL); imported before the HIP library
     if args.arch == "iv":
         return bench_ivector(args, torch)
     from fakebob_amd import parallel
-    rank, local_rank, world = parallel.dist_env()
-    dev_index = 0 if args.same_device else local_rank
-    dist = None
-    if world > 1:
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(dev_index)
-        dist = parallel.init_process_group(args.dist_backend)
+    rank, world, dev_index, dist = dist_setup(args, torch)
     from fakebob_amd.engine import Engine, nes_params
     from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
 
-    import threading
     K = max(1, args.streams)
     ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
     models = [ubm] + spk
@@ -250,92 +401,83 @@ def main():
     audio = auds[0]
     results = [None] * K
 
+    windows = [None] * K
+
     def run(k, n, timed):
+        t_in = time.perf_counter()
         results[k] = engs[k].bench_nes(prms[k], auds[k], 0, n, time_gmm=timed)
+        windows[k] = (t_in, time.perf_counter())
 
-    def run_all(n, timed):
-        ths = [threading.Thread(target=run, args=(k, n, timed)) for k in range(K)]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.warmup > 0:
-        run_all(args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    run_all(args.steps, True)
-    barrier()
-    dt = time.perf_counter() - t0
+    # outside everything: module load, first-touch allocations, the clock ramp of a cold GPU, and the same GMM
+    # launch with the chip to itself
+    workers = Workers(K, run)
+    workers.run(max(2, args.precondition), False)
+    solo_ms, solo_rows = engs[0].bench_gmm_kernel(20)
+    dt = timed_region(args, torch, dist, workers, K)
     ms_dev = sum(r[0] for r in results) / K
     ms_gmm = sum(r[1] for r in results) / K                 # per attack: sum over its timed launches
     rows = int(sum(r[2] for r in results) / K)
     total_steps = args.steps * K
     if dist is not None:
-        tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # final counter reduction (mirrors success_cnt / total_cnt, attackMain.py:312,411): the only
         # data the ranks ever exchange
         total_steps, total_scored, _ = parallel.reduce_counters([args.steps * K, args.steps * K * (SPD + 1), rows], dist)
-        assert total_steps == world * args.steps * K
+        assert total_steps == world * args.steps * K, (total_steps, world, args.steps, K)
+        assert total_scored == total_steps * (SPD + 1)
     its = total_steps / dt
-    out = None
+    single = None
+    if rank == 0 and K > 1 and not args.no_single:
+        # the same K steps with ONE attack in flight (a single launch chain): the latency view of the same path
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r1 = engs[0].bench_nes(prms[0], auds[0], 0, args.steps, time_gmm=True)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
+                  "gmm_launch_ms": r1[1] / args.steps,
+                  "note": "one attack in flight (a single launch chain), same workload, same step count"}
+    workers.close()
     if rank == 0:
         gmm_ms_avg = ms_gmm / args.steps
         flops_launch = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * rows  # (S+1)*C*4D*F_voiced
-        achieved = flops_launch / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
         out = {
             "metric": "NES iterations/sec (and scored-utts/sec) at samples_per_draw=50, 3 s@16 kHz",
             "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; f64 front-end/NES)",
-                                                                   "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)",
-                                                                   "f32": "f32 (MFMA f32 GMM; f64 front-end/NES)"}[GMM_MODE],
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; f64 front-end/NES)",
+                      "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)",
+                      "f32": "f32 (MFMA f32 GMM; f64 front-end/NES)"}[GMM_MODE],
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS,
+            "single_attack": single,
+            "per_attack": [{"host_ms": 1e3 * (b - a), "device_ms": r[0], "gmm_ms": r[1]} for (a, b), r in zip(windows, results)],
             "config": {"workload": "GMM-UBM OSI targeted, 5 speakers+UBM, C=2048, D=72, spd=50, "
                                    "N=48000 (3 s @ 16 kHz), %d attacks in flight per GPU "
                                    "(1 step = 1 NES iteration of each)" % K,
-                       "attacks_in_flight_per_gpu": K,
+                       "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
-            # `achieved` uses the ALGORITHMIC flops of SURVEY.md 8(d): (S+1)*C*4D per voiced frame (two
-            # length-D dot products per component per model, as Kaldi evaluates them in float32).  The
-            # kernel (a) shares the quadratic term across the 6 models (mean-only MAP adaptation):
-            # (1 + M)/(2M) = 7/12 of those products are executed, and (b) by default evaluates each
-            # f32 product on the f16 matrix pipe as 3 partial products of a two-term f16 split
-            # (k_gmm_fx2, f32-equivalent accuracy; FB_GMM_MODE=bx3 selects the exact 3-way bf16 split
-            # with 6 partial products, FB_GMM_MODE=f32 the plain f32-MFMA kernel).
-            # `peak` is the MFMA peak of the path's arithmetic type (f32: 157.3 TF) so `frac` can
-            # exceed 1; `executed_*` give the honest utilisation of the pipe the instructions run on.
-            "roofline": dict(_gmm_roofline(achieved, flops_launch, gmm_ms_avg),
+            "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows),
                              gmm_share_of_stream_time=ms_gmm / ms_dev if ms_dev > 0 else None,
-                             note="launch durations are HIP-event times on each attack's own stream; with "
-                                  "several attacks in flight they include time shared with other attacks' "
-                                  "kernels (solo launch: see solo_launch_ms)"),
+                             note="avg_launch_ms: HIP events around every launch of the timed region on each attack's own "
+                                  "stream; with several attacks in flight a launch shares the chip with other attacks' "
+                                  "kernels (the rocprofv3 average of the same command agrees: profiles/); solo_*: the same "
+                                  "launch with the chip to itself, measured before the warm-up"),
         }
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable in-process)
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as r:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
                 tr = json.load(r)["kernels"][GMM_TRAFFIC_KEY]
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
+            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
         except Exception:
             pass
-        solo_ms, solo_rows = engs[0].bench_gmm_kernel(20)   # same kernel, same data, chip to itself
-        out["roofline"]["solo_launch_ms"] = solo_ms
-        out["roofline"]["solo_achieved"] = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows / (solo_ms * 1e-3) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             ckw = dict(kw)
             out["cpu_baseline"] = cpu_baseline(audio, models, ckw)
             out["gpu_over_cpu_port"] = its / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -120,9 +120,74 @@ struct fb_engine {
   FbNesDev *h_out = nullptr;  // pinned
   int *h_tv = nullptr;        // pinned, grows
   size_t h_tv_cap = 0;
+  // pinned staging arena: every host<->device copy of the API goes through it.  (An async copy from / to pageable
+  // memory makes the runtime pin the pages on the fly; with other engines' kernels in flight on the same GPU that
+  // driver call was observed to stall the calling thread for milliseconds.)
+  char *pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
+  struct PendingD2H { void *dst; const void *src; size_t n; };
+  std::vector<PendingD2H> pin_pending;
   // stats
   int64_t scored_utts = 0, scored_frames = 0, voiced_frames = 0, nes_iters = 0;
 };
+
+// ------------------------------------------------------------ pinned staging
+static const size_t FB_PIN_MAX = (size_t)256 << 20;  // larger copies take the runtime's own pageable path
+
+// stream synchronize + completion of the staged device->host copies
+static int sync_stream(fb_engine *e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (const fb_engine::PendingD2H &q : e->pin_pending) memcpy(q.dst, q.src, q.n);
+  e->pin_pending.clear();
+  e->pin_off = 0;
+  return FB_OK;
+}
+static int pin_reserve(fb_engine *e, size_t n, char **out) {
+  const size_t need = (n + 255) & ~(size_t)255;
+  if (e->pin_off + need > e->pin_cap) {
+    FBCHK(sync_stream(e));  // arena empty from here on
+    if (need > e->pin_cap) {
+      if (e->pin) (void)hipHostFree(e->pin);
+      e->pin = nullptr;
+      e->pin_cap = 0;
+      const size_t want = need + need / 2 + ((size_t)1 << 20);
+      hipError_t er = hipHostMalloc((void **)&e->pin, want, hipHostMallocDefault);
+      if (er != hipSuccess) return fb_fail(FB_E_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(er));
+      e->pin_cap = want;
+    }
+  }
+  *out = e->pin + e->pin_off;
+  e->pin_off += need;
+  return FB_OK;
+}
+// host -> device on the engine's stream; `src` may be reused as soon as this returns
+static int h2d(fb_engine *e, void *dst_dev, const void *src, size_t n) {
+  if (n == 0) return FB_OK;
+  if (n > FB_PIN_MAX) {
+    HIPCHK(hipMemcpyAsync(dst_dev, src, n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FB_OK;
+  }
+  char *st = nullptr;
+  FBCHK(pin_reserve(e, n, &st));
+  memcpy(st, src, n);
+  HIPCHK(hipMemcpyAsync(dst_dev, st, n, hipMemcpyHostToDevice, e->stream));
+  return FB_OK;
+}
+// device -> host on the engine's stream; `dst` is valid after the next sync_stream()
+static int d2h(fb_engine *e, void *dst, const void *src_dev, size_t n) {
+  if (n == 0) return FB_OK;
+  if (n > FB_PIN_MAX) {
+    HIPCHK(hipMemcpyAsync(dst, src_dev, n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FB_OK;
+  }
+  char *st = nullptr;
+  FBCHK(pin_reserve(e, n, &st));
+  HIPCHK(hipMemcpyAsync(st, src_dev, n, hipMemcpyDeviceToHost, e->stream));
+  e->pin_pending.push_back({dst, st, n});
+  return FB_OK;
+}
 
 // ------------------------------------------------------------------ create
 extern "C" int fb_engine_create(int device, fb_engine **out) {
@@ -164,6 +229,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   for (hipEvent_t ev : e->evg_ring) if (ev) (void)hipEventDestroy(ev);
   if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+  if (e->pin) (void)hipHostFree(e->pin);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return FB_OK;
@@ -278,7 +344,7 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   memcpy(&host[o_dct], dct.data(), sizeof(double) * dct.size());
   memcpy(&host[o_lift], lifter.data(), sizeof(double) * lifter.size());
   memcpy(&host[o_ds], dscale.data(), sizeof(double) * dscale.size());
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   FBCHK(e->fe_tables.ensure(off));
   HIPCHK(hipMemcpy(e->fe_tables.p, host.data(), off, hipMemcpyHostToDevice));
   char *base = e->fe_tables.as<char>();
@@ -365,7 +431,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         if (im_model >= 0) im[32 * ROWF + cc] = c < C ? gconsts[(size_t)im_model * C + c] : -1.0e30f;
       }
     }
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
   HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
   // bf16x3 images (k_gmm_bx3): exact 3-way bf16 split of every parameter, gconst in the K padding
@@ -530,7 +596,7 @@ extern "C" int fb_set_system(fb_engine *e, int task, const double *z_mean, const
     e->h_zmean[m] = (task == FB_TASK_CSI && z_mean) ? z_mean[m] : 0.0;
     e->h_zstd[m] = (task == FB_TASK_CSI && z_std) ? z_std[m] : 1.0;
   }
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   HIPCHK(hipMemcpy(e->zmean.p, e->h_zmean.data(), sizeof(double) * M, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->zstd.p, e->h_zstd.data(), sizeof(double) * M, hipMemcpyHostToDevice));
   return FB_OK;
@@ -579,16 +645,14 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
       }
     }
     FBCHK(e->frame_rec.ensure(sizeof(int32_t) * 4 * (size_t)(total > 0 ? total : 1)));
-    HIPCHK(hipMemcpyAsync(e->frame_rec.p, e->h_frame_rec.data(), sizeof(int32_t) * 4 * (size_t)total, hipMemcpyHostToDevice, e->stream));
+    FBCHK(h2d(e, e->frame_rec.p, e->h_frame_rec.data(), sizeof(int32_t) * 4 * (size_t)total));
   }
   FBCHK(e->chunk_off.ensure(sizeof(int) * (B + 1)));
-  HIPCHK(hipMemcpyAsync(e->chunk_off.p, e->h_chunk_off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->chunk_off.p, e->h_chunk_off.data(), sizeof(int) * (B + 1)));
   FBCHK(e->wav_off.ensure(sizeof(int64_t) * (B + 1)));
   FBCHK(e->frame_off.ensure(sizeof(int) * (B + 1)));
-  HIPCHK(hipMemcpyAsync(e->wav_off.p, e->h_wav_off.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->frame_off.p, e->h_frame_off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, e->stream));
-  // the host vectors must outlive the async copies: they are members, and the next overwrite
-  // happens only after a stream sync in the callers.
+  FBCHK(h2d(e, e->wav_off.p, e->h_wav_off.data(), sizeof(int64_t) * (B + 1)));
+  FBCHK(h2d(e, e->frame_off.p, e->h_frame_off.data(), sizeof(int) * (B + 1)));
   return FB_OK;
 }
 
@@ -637,7 +701,7 @@ static int time_collect(fb_engine *e) {
 static int time_begin(fb_engine *e) {
   if (!e->time_gmm) return FB_OK;
   if (e->evg_n >= 16) {  // ring full: drain (never happens with the batch sizes used)
-    HIPCHK(hipStreamSynchronize(e->stream));
+    FBCHK(sync_stream(e));
     FBCHK(time_collect(e));
   }
   HIPCHK(hipEventRecord(e->evg_ring[2 * e->evg_n], e->stream));
@@ -784,9 +848,9 @@ static int ensure_host_tv(fb_engine *e, int B) {
 
 static int finish_score(fb_engine *e, int B, double *raw, int *tv) {
   FBCHK(ensure_host_tv(e, B));
-  HIPCHK(hipMemcpyAsync(raw, e->raw.p, sizeof(double) * (size_t)B * e->n_out, hipMemcpyDeviceToHost, e->stream));
+  FBCHK(d2h(e, raw, e->raw.p, sizeof(double) * (size_t)B * e->n_out));
   HIPCHK(hipMemcpyAsync(e->h_tv, e->tv.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   if (e->kind == 1) {
     int fail = 0;
     HIPCHK(hipMemcpy(&fail, e->iv_fail.p, sizeof(int), hipMemcpyDeviceToHost));
@@ -806,11 +870,11 @@ extern "C" int fb_score_i16(fb_engine *e, const int16_t *wav, const int64_t *off
   if (!e || !wav || !off || !raw || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   const int64_t total = off[B] - off[0];
   if (off[0] != 0) return fb_fail(FB_E_ARG, "off[0] must be 0");
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)total));
-  HIPCHK(hipMemcpyAsync(e->wav.p, wav, sizeof(int16_t) * (size_t)total, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->wav.p, wav, sizeof(int16_t) * (size_t)total));
   FBCHK(prepare_batch(e, off, B));
   e->cached_B = -1;
   FBCHK(run_scoring(e, B, e->h_frame_off[B]));
@@ -823,12 +887,12 @@ extern "C" int fb_score_f64(fb_engine *e, const double *audio, const int64_t *of
   if (bits < 2 || bits > 16) return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported", bits);
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   if (off[0] != 0) return fb_fail(FB_E_ARG, "off[0] must be 0");
   const int64_t total = off[B];
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)total));
   FBCHK(e->stage_f64.ensure(sizeof(double) * (size_t)total));
-  HIPCHK(hipMemcpyAsync(e->stage_f64.p, audio, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->stage_f64.p, audio, sizeof(double) * (size_t)total));
   fb_launch_quantize(e->stream, e->stage_f64.as<double>(), total, bits, e->wav.as<int16_t>());
   FBCHK(prepare_batch(e, off, B));
   e->cached_B = -1;
@@ -929,7 +993,7 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
       !sy->z_mean || !sy->z_std)
     return fb_fail(FB_E_ARG, "null array in fb_ivector_system");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   const int triD = D * (D + 1) / 2, triR = R * (R + 1) / 2;
   // ---- fgmm-global-to-gmm (DiagGmm::CopyFromFullGmm) + FullGmm::ComputeGconsts, float64 on host
   std::vector<float> dg_gc(C), dg_miv((size_t)C * D), dg_iv((size_t)C * D), fg_gc(C);
@@ -1011,7 +1075,7 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
     HIPCHK(hipMemcpy(dM.p, sy->ie_M, sizeof(double) * nM, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dS.p, sy->ie_sigma_inv, sizeof(double) * (size_t)C * triD, hipMemcpyHostToDevice));
     fb_launch_iv_derive(e->stream, C, D, R, dM.as<double>(), dS.as<double>(), e->iv_sim.as<double>(), e->iv_u.as<double>());
-    HIPCHK(hipStreamSynchronize(e->stream));
+    FBCHK(sync_stream(e));
     dM.release();
     dS.release();
     e->iv.sim = e->iv_sim.as<double>();
@@ -1066,7 +1130,7 @@ extern "C" int fb_debug_iv_active(fb_engine *e, int *n_active) {
   if (!e || !n_active) return fb_fail(FB_E_ARG, "bad argument");
   if (e->kind != 1 || e->last_B <= 0) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   HIPCHK(hipMemcpy(n_active, e->iv_active.as<int>() + e->iv.C, sizeof(int), hipMemcpyDeviceToHost));
   return FB_OK;
 }
@@ -1075,7 +1139,7 @@ extern "C" int fb_debug_ivectors(fb_engine *e, int B, double *ivecs) {
   if (!e || !ivecs || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (e->kind != 1 || e->last_B < B) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   HIPCHK(hipMemcpy(ivecs, e->iv_ivec.p, sizeof(double) * (size_t)B * e->iv.R, hipMemcpyDeviceToHost));
   return FB_OK;
 }
@@ -1101,12 +1165,12 @@ static int check_params(fb_engine *e, const fb_nes_params *p, int64_t N) {
 // (re)builds the equal-length batch layout of B utterances of N samples
 static int prepare_nes_batch(fb_engine *e, int64_t N, int B) {
   if (e->cached_B == B && e->cached_N == N) return FB_OK;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   std::vector<int64_t> off(B + 1);
   for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N * B));
   FBCHK(prepare_batch(e, off.data(), B));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   e->cached_B = B;
   e->cached_N = N;
   return FB_OK;
@@ -1177,7 +1241,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     h.disable_stop = disable_stop ? 1 : 0;
     *e->h_ctl = h;
     HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // h_ctl is reused for the read-back below
+    FBCHK(sync_stream(e));  // h_ctl is reused for the read-back below
   }
   const double one_minus_m = 1.0 - p->momentum;
   const int K = attack_batch_size(e);
@@ -1188,8 +1252,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       const int it = it_base + done + k;
       const double *noise_dev = nullptr;
       if (noise_all && half > 0) {
-        HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half,
-                              hipMemcpyHostToDevice, e->stream));
+        FBCHK(h2d(e, e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half));
         noise_dev = e->noise.as<double>();
       }
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
@@ -1200,7 +1263,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
                             e->grad_m.as<double>(), e->adver.as<double>(), ctl);
     }
     HIPCHK(hipMemcpyAsync(e->h_ctl, ctl, sizeof(FbCtlDev), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    FBCHK(sync_stream(e));
     if (e->gmm_pending) FBCHK(time_collect(e));
     if (e->h_ctl->err != 0)
       return fb_fail(FB_E_NO_VOICED, "NES sample %d has no voiced frames", e->h_ctl->err - 1);
@@ -1212,7 +1275,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
 
 static int fetch_out(fb_engine *e) {
   HIPCHK(hipMemcpyAsync(e->h_out, e->nes_out.p, sizeof(FbNesDev), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   if (e->gmm_pending) FBCHK(time_collect(e));
   if (e->h_out->err != 0)
     return fb_fail(FB_E_NO_VOICED, "NES sample %d has no voiced frames", e->h_out->err - 1);
@@ -1228,17 +1291,17 @@ extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *a
   const int half = p->samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
   FBCHK(prepare_nes_batch(e, N, B));
   FBCHK(ensure_nes_buffers(e, N, B));
-  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->adver.p, audio, sizeof(double) * (size_t)N));
   const double *noise_dev = nullptr;
   if (noise_pos && half > 0) {
     FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
-    HIPCHK(hipMemcpyAsync(e->noise.p, noise_pos, sizeof(double) * (size_t)N * half, hipMemcpyHostToDevice, e->stream));
+    FBCHK(h2d(e, e->noise.p, noise_pos, sizeof(double) * (size_t)N * half));
     noise_dev = e->noise.as<double>();
   }
   FBCHK(enqueue_get_grad(e, p, N, iter, noise_dev, false));
   fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
                         e->grad.as<double>(), 0, 0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr);
-  if (grad) HIPCHK(hipMemcpyAsync(grad, e->grad.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
+  if (grad) FBCHK(d2h(e, grad, e->grad.p, sizeof(double) * (size_t)N));
   FBCHK(fetch_out(e));
   e->nes_iters += 1;
   if (final_loss) *final_loss = e->h_out->final_loss;
@@ -1270,8 +1333,8 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
   const int half = p->samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
   FBCHK(prepare_nes_batch(e, N, B));
   FBCHK(ensure_nes_buffers(e, N, B));
-  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
+  HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));  // grad = 0 (:157)
   if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
   double *trace_dev = nullptr;
@@ -1285,16 +1348,16 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
   const int it = e->h_ctl->stop_iter;
   e->nes_iters += rows;
   if (trace && rows > 0)
-    HIPCHK(hipMemcpyAsync(trace, trace_dev, sizeof(double) * (size_t)rows * (3 + S), hipMemcpyDeviceToHost, e->stream));
+    FBCHK(d2h(e, trace, trace_dev, sizeof(double) * (size_t)rows * (3 + S)));
   const int last_iter = broke ? it : p->max_iter - 1;
   *success_flag = (last_iter < p->max_iter - 1) ? 1 : -1;  // :219
   if (n_trace) *n_trace = rows;
   // adver -> int16 (:220)
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N * B));
   fb_launch_quantize(e->stream, e->adver.as<double>(), N, 16, e->wav.as<int16_t>());
-  HIPCHK(hipMemcpyAsync(adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
-  if (adver_f64) HIPCHK(hipMemcpyAsync(adver_f64, e->adver.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(d2h(e, adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N));
+  if (adver_f64) FBCHK(d2h(e, adver_f64, e->adver.p, sizeof(double) * (size_t)N));
+  FBCHK(sync_stream(e));
   return FB_OK;
 }
 
@@ -1312,8 +1375,8 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
   const int half = q.samples_per_draw / 2, B = 2 * half + 1, S = fb_num_speakers(e);
   FBCHK(prepare_nes_batch(e, N, B));
   FBCHK(ensure_nes_buffers(e, N, B));
-  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
+  HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
   if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
   // Column 0 of every NES batch is the clean adver (noise 0), i.e. exactly what
@@ -1331,8 +1394,7 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
     const double *noise_dev = nullptr;
     if (noise_all && half > 0) {
       if (n_iters >= max_total_iters) { rc = fb_fail(FB_E_LIMIT, "max_total_iters %d reached", max_total_iters); break; }
-      HIPCHK(hipMemcpyAsync(e->noise.p, noise_all + (size_t)n_iters * N * half, sizeof(double) * (size_t)N * half,
-                            hipMemcpyHostToDevice, e->stream));
+      FBCHK(h2d(e, e->noise.p, noise_all + (size_t)n_iters * N * half, sizeof(double) * (size_t)N * half));
       noise_dev = e->noise.as<double>();
     }
     // the loss depends on q.threshold, which may change below; scores do not.  Score first
@@ -1375,8 +1437,8 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
   if (n_iters_out) *n_iters_out = n_iters;
   if (n_outer_out) *n_outer_out = n_outer;
   if (thr_final) *thr_final = q.threshold;
-  if (adver_f64) HIPCHK(hipMemcpyAsync(adver_f64, e->adver.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (adver_f64) FBCHK(d2h(e, adver_f64, e->adver.p, sizeof(double) * (size_t)N));
+  FBCHK(sync_stream(e));
   return rc;
 }
 
@@ -1399,24 +1461,24 @@ extern "C" int fb_debug_quantize(fb_engine *e, const double *x, int64_t n, int b
   if (!e || !x || !q || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (bits < 2 || bits > 16) return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported", bits);
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   e->cached_B = -1;
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)n));
   FBCHK(e->stage_f64.ensure(sizeof(double) * (size_t)n));
-  HIPCHK(hipMemcpyAsync(e->stage_f64.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->stage_f64.p, x, sizeof(double) * (size_t)n));
   fb_launch_quantize(e->stream, e->stage_f64.as<double>(), n, bits, e->wav.as<int16_t>());
-  HIPCHK(hipMemcpyAsync(q, e->wav.p, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(d2h(e, q, e->wav.p, sizeof(int16_t) * (size_t)n));
+  FBCHK(sync_stream(e));
   return FB_OK;
 }
 
 static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   if (!e || !wav || n <= 0) return fb_fail(FB_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   int64_t off[2] = {0, n};
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)n));
-  HIPCHK(hipMemcpyAsync(e->wav.p, wav, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->wav.p, wav, sizeof(int16_t) * (size_t)n));
   FBCHK(prepare_batch(e, off, 1));
   e->cached_B = -1;
   const int T = e->h_frame_off[1];
@@ -1454,10 +1516,10 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
   fb_launch_gmm_post_stats(s, g.C, ld, g.D, e->enr_ll.as<float>(), e->feats.as<float>(), n_rows_ptr, T,
                            e->enr_aux.as<float>(), e->enr_aux.as<float>() + T, d_occ, d_F);
   int tv = 0;
-  HIPCHK(hipMemcpyAsync(&tv, e->tv.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(occ, d_occ, sizeof(double) * (size_t)g.C, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(F, d_F, sizeof(double) * (size_t)g.C * g.D, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  FBCHK(d2h(e, &tv, e->tv.p, sizeof(int)));
+  FBCHK(d2h(e, occ, d_occ, sizeof(double) * (size_t)g.C));
+  FBCHK(d2h(e, F, d_F, sizeof(double) * (size_t)g.C * g.D));
+  FBCHK(sync_stream(e));
   HIPCHK(hipGetLastError());
   if (tv_out) *tv_out = tv;
   if (tv <= 0) return fb_fail(FB_E_NO_VOICED, "enrolment utterance has no voiced frames");
@@ -1478,8 +1540,8 @@ extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float 
   if (!mfcc) return fb_fail(FB_E_ARG, "mfcc is NULL");
   FBCHK(debug_frontend(e, wav, n));
   const int T = e->h_frame_off[1];
-  HIPCHK(hipMemcpyAsync(mfcc, e->mfcc.p, sizeof(float) * (size_t)T * e->fe.nc, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(d2h(e, mfcc, e->mfcc.p, sizeof(float) * (size_t)T * e->fe.nc));
+  FBCHK(sync_stream(e));
   if (T_out) *T_out = T;
   return FB_OK;
 }
@@ -1489,8 +1551,8 @@ extern "C" int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float
   FBCHK(debug_frontend(e, wav, n));
   const int T = e->h_frame_off[1];
   int tv = 0;
-  HIPCHK(hipMemcpyAsync(&tv, e->tv.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(d2h(e, &tv, e->tv.p, sizeof(int)));
+  FBCHK(sync_stream(e));
   if (tv > 0)
     HIPCHK(hipMemcpy(feats, e->feats.p, sizeof(float) * (size_t)tv * e->fe.dim, hipMemcpyDeviceToHost));
   *Tv = tv;
@@ -1513,7 +1575,7 @@ extern "C" int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64
   if (!e->have_gmm || e->last_total_frames <= 0) return fb_fail(FB_E_STATE, "score a batch first");
   HIPCHK(hipSetDevice(e->device));
   const int B = e->last_B, tf = e->last_total_frames;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   fb_launch_gmm(e->stream, e->gmm, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
                 e->part_m.as<float>(), e->part_s.as<float>());
   HIPCHK(hipEventRecord(e->ev0, e->stream));
@@ -1541,14 +1603,14 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
   const int half = p->samples_per_draw / 2, B = 2 * half + 1;
   FBCHK(prepare_nes_batch(e, N, B));
   FBCHK(ensure_nes_buffers(e, N, B));
-  HIPCHK(hipMemcpyAsync(e->audio.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->adver.p, audio, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+  FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
+  HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
   double gmm_ms = 0.0;
   int64_t vrows = 0;
   // identical work to fb_attack's loop (early stop disabled for timing)
   FBCHK(run_attack_core(e, p, N, nullptr, 0, warmup > 0 ? warmup : 0, true, true, nullptr));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  FBCHK(sync_stream(e));
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   e->time_gmm = time_gmm != 0;
   e->gmm_ms_acc = 0.0;

@@ -351,13 +351,18 @@ def test_bench_roofline_object_and_traffic_file_follow_the_contract():
     spec.loader.exec_module(bench)
     flops = (bench.S_SPK + 1) * bench.C_GAUSS * 4 * bench.D_FEAT * 15300
     assert flops == 6 * 2048 * 288 * 15300 and 54.0e9 < flops < 54.2e9      # 54.1 GFLOP per NES batch
-    r = bench._gmm_roofline(achieved=flops / 115e-6 / 1e12, flops_launch=flops, gmm_ms_avg=0.115)
+    r = bench._gmm_roofline(flops_launch=flops, gmm_ms_avg=0.115, solo_ms=0.110, solo_rows=15300)
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert 0.0 < r["executed_frac"] < 1.0                                 # utilisation of the pipe the MFMAs run on
-    with open(os.path.join(root, "profiles", "r01_traffic.json")) as f:
+    # the peak is that of the pipe the kernel issues on: dense f16/bf16 MFMA for the default fx2 kernel (and bx3),
+    # the f32 MFMA / vector rate only for FB_GMM_MODE=f32 -- so `frac` is a true fraction
+    want_peak = 157.3 if bench.GMM_MODE == "f32" else 2500.0
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == want_peak
+    assert abs(r["achieved"] - flops / 115e-6 / 1e12) < 1e-6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
+    assert r["frac"] < r["executed_frac"] < 1.0                           # utilisation of the pipe the MFMAs run on
+    assert abs(r["solo_frac"] - flops / 110e-6 / 1e12 / want_peak) < 1e-9
+    with open(os.path.join(root, "profiles", bench.TRAFFIC_FILE)) as f:
         tr = json.load(f)["kernels"]
     for key in ("k_gmm_fx2<5, false>", "k_gmm_bx3<5, false>", "k_gmm<36, false>", "k_iv_contract_dma<lin>+<quad>"):
         assert tr[key]["hbm_bytes_per_launch"] > 0
