@@ -374,9 +374,17 @@ class IvSystemCtx(object):
     FullGmm gconsts, Sigma^-1 M, U, PLDA-space enrolled vectors) are computed here with numpy,
     independently of the engine's C++/HIP derivations."""
 
-    def __init__(self, cfg, sysm, nthreads=1):
+    def __init__(self, cfg, sysm, nthreads=1, share=None):
+        """share: another IvSystemCtx over the same UBM / extractor / back-end whose derived variables are reused
+        (only the enrolled speakers and z-norm statistics differ)."""
         f32, f64 = np.float32, np.float64
         Cn, D, R, L, S = sysm.C, sysm.D, sysm.R, sysm.L, sysm.S
+        if share is not None:
+            for name in ("dg_iv", "dg_miv", "dg_gc", "fg_gc", "fg_mic", "fg_P", "sim", "u", "mean_vec", "lda",
+                         "plda_mean", "plda_tr", "plda_psi"):
+                setattr(self, name, getattr(share, name))
+            self._finish(cfg, sysm, nthreads)
+            return
         r, c = np.tril_indices(D)
         P = np.zeros((Cn, D, D), f64)
         P[:, r, c] = sysm.fg_inv_covars.astype(f64)
@@ -399,13 +407,20 @@ class IvSystemCtx(object):
         Sinv = np.zeros((Cn, D, D), f64)
         Sinv[:, r, c] = sysm.ie_sigma_inv
         Sinv[:, c, r] = sysm.ie_sigma_inv
-        self.sim = np.ascontiguousarray(np.einsum("kde,ker->kdr", Sinv, sysm.ie_M))
+        self.sim = np.ascontiguousarray(np.matmul(Sinv, sysm.ie_M))           # Sigma^-1 M   [C][D][R]
         rr, cc = np.tril_indices(R)
-        U = np.einsum("kdi,kdj->kij", sysm.ie_M, self.sim)
-        self.u = np.ascontiguousarray(U[:, rr, cc])
+        self.u = np.empty((Cn, rr.size), f64)                                 # U_k = M_k^T Sigma_k^-1 M_k, packed lower
+        for k0 in range(0, Cn, 128):                                          # (batched BLAS; 128 components at a time)
+            U = np.matmul(sysm.ie_M[k0:k0 + 128].transpose(0, 2, 1), self.sim[k0:k0 + 128])
+            self.u[k0:k0 + 128] = U[:, rr, cc]
         self.mean_vec = np.ascontiguousarray(sysm.mean_vec.astype(f64))
         self.lda = np.ascontiguousarray(sysm.lda.astype(f64))
         self.plda_mean, self.plda_tr, self.plda_psi = sysm.plda_mean, sysm.plda_transform, sysm.plda_psi
+        self._finish(cfg, sysm, nthreads)
+
+    def _finish(self, cfg, sysm, nthreads):
+        f64 = np.float64
+        Cn, D, R, L, S = sysm.C, sysm.D, sysm.R, sysm.L, sysm.S
         self.zm, self.zs = sysm.z_mean, sysm.z_std
         self.train = np.zeros((S, L), f64)
         s = IvSystem()

@@ -66,7 +66,9 @@ def test_config4_iv_osi_threshold_estimation_then_attack_parity(engine, oracle, 
     adv_o, flag_o, _, tr_o = oracle.attack(po, ctx.fn, ctx.ctx, audio, seed=13, stream=5)
     assert flag_g == flag_o and tr_g.shape == tr_o.shape
     assert np.abs(tr_g - tr_o).max() <= SCORE_TOL
-    assert np.mean(adv_g != adv_o) < 1e-3
+    # observed on MI355X: 0 differing samples (the update is sign(momentum gradient); a flip needs a gradient
+    # entry within the 1e-4-scale score error of zero) -- asserted exactly, not as a rate
+    assert int(np.sum(adv_g != adv_o)) == 0
 
 
 def test_config4_full_size_b201_properties():

@@ -76,4 +76,6 @@ def test_ivector_attack_trajectory(engine, oracle, small_iv):
     adv_o, flag_o, advf_o, tr_o = oracle.attack(po, ctx.fn, ctx.ctx, audio, seed=11, stream=0)
     assert flag_g == flag_o and tr_g.shape == tr_o.shape
     assert np.abs(tr_g - tr_o).max() <= SCORE_TOL
-    assert np.mean(adv_g != adv_o) < 1e-3
+    # observed on MI355X: 0 differing samples (the update is sign(momentum gradient); a flip needs a gradient
+    # entry within the 1e-4-scale score error of zero) -- asserted exactly, not as a rate
+    assert int(np.sum(adv_g != adv_o)) == 0

@@ -195,7 +195,9 @@ def test_attack_trajectory_parity(engine, oracle, small_system):
     assert flag_g == flag_o and tr_g.shape == tr_o.shape  # same decision, same iteration count
     assert np.abs(tr_g - tr_o).max() <= SCORE_TOL
     # sign flips can only happen where the momentum gradient is ~0: essentially never
-    assert np.mean(adv_g != adv_o) < 1e-3
+    # observed on MI355X: 0 differing samples (the update is sign(momentum gradient); a flip needs a gradient
+    # entry within the 1e-4-scale score error of zero) -- asserted exactly, not as a rate
+    assert int(np.sum(adv_g != adv_o)) == 0
     assert np.abs(advf_g - advf_o).max() <= 2 * pg.max_lr * pg.max_iter
 
 
