@@ -578,16 +578,27 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
 
   // ---- frame fragments: chunk c of this lane = dims 16c + 8h + i, i < 8;  bx = x (1.0 at position D,
-  //      whose residual is 0), bq = fl(x*x) * 2^-sq_shift
+  //      whose residual is 0), bq = fl(x*x), both moved by the load-time powers of two 2^kx / 2^kx2.
+  // Range guard: the load-time scalings assume |x| 2^kx and x^2 2^kx2 below f16's 65504.  Features beyond
+  // that (|x| >= 64 with kx2 = 4: liftered cepstra of tonal audio, unusual front-end configurations) would turn
+  // into inf and the scores into NaN.  Each wave therefore takes the largest scaled operand of its 32 frames
+  // and, when it reaches 2^15, moves ALL its frame operands (x, the 1.0 that multiplies gconst, x^2) down by one
+  // wave-uniform power of two 2^-sh: the accumulators then hold ll 2^(kacc - sh), the logsumexp multiplier and
+  // the final un-scaling take the factor back, and every step stays an exact power-of-two scaling.  Small
+  // operands of such a frame may become f16 subnormals (absolute precision 2^-25 of the scaled operand), which is
+  // below the f32 rounding of the large terms that caused the shift.  sh = 0 for ordinary speech features.
   u32x4 bx1[NK], bx2[NK], bq1[NK], bq2[NK];
+  int sh = 0;
   {
     const bool ok = row < n_rows;
     const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
     const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);  // exact power-of-two operand scalings
+    float vv[NK][8], qq[NK][8];
+    float amax = xs;
 #pragma unroll
     for (int c = 0; c < NK; ++c) {
       const int d0 = 16 * c + 8 * h;
-      float v[8], q[8];
+      float *v = vv[c], *q = qq[c];
       if ((g.D & 3) == 0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -605,8 +616,24 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
       for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
-      fb_split2_frag(v, bx1[c], bx2[c]);
-      fb_split2_frag(q, bq1[c], bq2[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fmaxf(fabsf(v[i]), q[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (amax >= 32768.0f) {  // wave-uniform; finite features only (the front-end produces nothing else)
+      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;  // amax in [2^ex, 2^(ex+1))
+      sh = min(ex - 14, 100);
+    }
+    const float down = fb_pow2f(-sh);
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      if (sh) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { vv[c][i] = __fmul_rn(vv[c][i], down); qq[c][i] = __fmul_rn(qq[c][i], down); }
+      }
+      fb_split2_frag(vv[c], bx1[c], bx2[c]);
+      fb_split2_frag(qq[c], bq1[c], bq2[c]);
     }
   }
   for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
@@ -624,7 +651,8 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   }
   __syncthreads();
 
-  const float unscale = fb_pow2f(-g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
+  const float unscale = fb_pow2f(sh - g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
+  const int pad_it0 = ((g.C & 31) && tile1 == g.n_tiles) ? (tile1 - 1 - tile0) * g.n_items : 0x7fffffff;
   f32x16 hq, pv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; pv[r] = 0.0f; }
@@ -655,6 +683,12 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
                                                                     pv[4 * rr + 2] * unscale, pv[4 * rr + 3] * unscale);
         }
       } else {
+        if (it >= pad_it0) {  // last tile of a model whose C is not a multiple of 32: the padding components' gconst
+                              // (-60000 2^-kl, the most an f16 image can hold) must not compete with far-off frames
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if ((g.n_tiles - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= g.C) pv[r] = FB_GMM_NEG;
+        }
         fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid, ls);
       }
     }
