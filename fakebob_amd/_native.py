@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfakebob_hip.so")
 
 FB_OK = 0
-FB_E_ARG, FB_E_HIP, FB_E_STATE, FB_E_NO_VOICED, FB_E_NOMEM, FB_E_LIMIT = -1, -2, -3, -4, -5, -6
+FB_E_ARG, FB_E_HIP, FB_E_STATE, FB_E_NO_VOICED, FB_E_NOMEM, FB_E_LIMIT, FB_E_CALLBACK = -1, -2, -3, -4, -5, -6, -7
 TASK = {"OSI": 0, "CSI": 1, "SV": 2}
 ATTACK = {"untargeted": 0, "targeted": 1}
 
@@ -55,10 +55,13 @@ class IvectorSystem(C.Structure):
     ]
 
 
+# fb_score_cb: int (*)(void *ctx, const double *audios, int64_t N, int B, double *scores)
+SCORE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double))
+
 EXPORTS = [
     "fb_last_error", "fb_version", "fb_device_count", "fb_engine_create", "fb_engine_destroy",
     "fb_default_frontend", "fb_set_frontend", "fb_load_gmm", "fb_load_ivector", "fb_set_system", "fb_num_speakers",
-    "fb_score_i16", "fb_score_f64", "fb_system_scores", "fb_get_grad", "fb_attack",
+    "fb_score_i16", "fb_score_f64", "fb_system_scores", "fb_get_grad", "fb_attack", "fb_get_grad_ext", "fb_attack_ext",
     "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_ivectors", "fb_debug_iv_active", "fb_stats", "fb_gmm_acc_stats", "fb_last_ivectors", "fb_gmm_kernel_mode",
     "fb_bench_gmm_kernel", "fb_bench_nes",
 ]

@@ -116,7 +116,7 @@ struct fb_engine {
   int64_t cached_N = -1;
   int last_total_frames = 0, last_B = 0, last_chunks = 1;
   // NES state
-  DevBuf audio, adver, grad_m, grad, noise, zbuf, scores, loss, dist_part, nes_out, stage_f64;
+  DevBuf audio, adver, grad_m, grad, noise, zbuf, scores, loss, dist_part, nes_out, stage_f64, ext_x, ext_z;
   FbNesDev *h_out = nullptr;  // pinned
   int *h_tv = nullptr;        // pinned, grows
   size_t h_tv_cap = 0;
@@ -219,7 +219,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
-                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
+                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
                     &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
@@ -1176,8 +1176,8 @@ static int prepare_nes_batch(fb_engine *e, int64_t N, int B) {
   return FB_OK;
 }
 
-static int ensure_nes_buffers(fb_engine *e, int64_t N, int B) {
-  const int S = fb_num_speakers(e);
+static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
+  if (S < 0) S = fb_num_speakers(e);
   FBCHK(e->audio.ensure(sizeof(double) * (size_t)N));
   FBCHK(e->adver.ensure(sizeof(double) * (size_t)N));
   FBCHK(e->grad_m.ensure(sizeof(double) * (size_t)N));
@@ -1307,6 +1307,167 @@ extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *a
   if (final_loss) *final_loss = e->h_out->final_loss;
   if (adver_loss) *adver_loss = e->h_out->adver_loss;
   if (score0) for (int s = 0; s < S; ++s) score0[s] = e->h_out->score0[s];
+  return FB_OK;
+}
+
+
+// ------------------------------------------------- foreign models (plugin API)
+// The reference's FakeBob accepts ANY `model` with score / make_decisions (README.md:136; FAKEBOB.py:53,89,250).
+// For a model that is not one of this library's systems the scores come from a host callback; everything else of
+// the NES iteration stays on the device: Philox noise + perturbation (k_perturb_f64), loss + loop control (k_loss),
+// gradient estimate + momentum sign step (k_grad_update).  One host round trip per iteration is inherent.
+static int check_params_ext(fb_engine *e, const fb_nes_params *p, int64_t N, int S, fb_score_cb cb) {
+  if (!e || !p || !cb) return fb_fail(FB_E_ARG, "null argument");
+  if (N <= 0) return fb_fail(FB_E_ARG, "empty audio");
+  if (p->task != FB_TASK_OSI && p->task != FB_TASK_CSI && p->task != FB_TASK_SV) return fb_fail(FB_E_ARG, "bad task");
+  if (S <= 0 || S > 62) return fb_fail(FB_E_ARG, "number of speakers must be in [1, 62] (got %d)", S);
+  if (p->task == FB_TASK_SV && S != 1) return fb_fail(FB_E_ARG, "SV scores one speaker (got S = %d)", S);
+  if (p->samples_per_draw < 0 || p->samples_per_draw > 4094) return fb_fail(FB_E_ARG, "bad samples_per_draw");
+  if (p->task != FB_TASK_SV && p->attack_type == FB_TARGETED && (p->target < 0 || p->target >= S))
+    return fb_fail(FB_E_ARG, "target %d out of range", p->target);
+  if (p->task == FB_TASK_CSI && p->attack_type == FB_UNTARGETED && (p->true_label < 0 || p->true_label >= S))
+    return fb_fail(FB_E_ARG, "true label %d out of range", p->true_label);
+  if (!(p->sigma > 0.0) && p->samples_per_draw >= 2) return fb_fail(FB_E_ARG, "sigma must be > 0");
+  return FB_OK;
+}
+
+static int ensure_ext_buffers(fb_engine *e, int64_t N, int B, int S) {
+  FBCHK(ensure_nes_buffers(e, N, B, S));
+  FBCHK(e->ext_x.ensure(sizeof(double) * (size_t)N * B));
+  FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * S));
+  const size_t had = e->ext_z.cap;
+  FBCHK(e->ext_z.ensure(sizeof(double) * 2 * 64));
+  if (e->ext_z.cap != had) {  // z-norm of the identity: (s - 0) / 1 == s bit for bit
+    double z[128];
+    for (int i = 0; i < 64; ++i) { z[i] = 0.0; z[64 + i] = 1.0; }
+    FBCHK(h2d(e, e->ext_z.p, z, sizeof(z)));
+  }
+  return FB_OK;
+}
+
+// perturb -> float64 batch to the host -> callback -> scores to the device -> loss (+ loop control)
+static int enqueue_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx, int64_t N,
+                                uint32_t iter, const double *noise_dev, bool with_dist, FbCtlDev *ctl = nullptr,
+                                double *trace_dev = nullptr, int trace_row = 0) {
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1;
+  int ndp = 0;
+  fb_launch_perturb_f64(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
+                        p->sigma, p->seed, iter, p->stream, noise_dev, e->ext_x.as<double>(),
+                        e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>());
+  const size_t xb = sizeof(double) * (size_t)N * B;
+  std::vector<double> sc((size_t)B * S);
+  if (xb <= FB_PIN_MAX) {  // the callback reads the pinned staging area directly
+    char *xh = nullptr;
+    FBCHK(pin_reserve(e, xb, &xh));
+    HIPCHK(hipMemcpyAsync(xh, e->ext_x.p, xb, hipMemcpyDeviceToHost, e->stream));
+    FBCHK(sync_stream(e));
+    const int rc = cb(cb_ctx, reinterpret_cast<const double *>(xh), N, B, sc.data());
+    if (rc != 0) return fb_fail(FB_E_CALLBACK, "score callback failed (rc %d)", rc);
+  } else {
+    std::vector<double> xh((size_t)N * B);
+    FBCHK(sync_stream(e));
+    HIPCHK(hipMemcpy(xh.data(), e->ext_x.p, xb, hipMemcpyDeviceToHost));
+    const int rc = cb(cb_ctx, xh.data(), N, B, sc.data());
+    if (rc != 0) return fb_fail(FB_E_CALLBACK, "score callback failed (rc %d)", rc);
+  }
+  FBCHK(h2d(e, e->raw.p, sc.data(), sizeof(double) * sc.size()));
+  fb_launch_loss(e->stream, e->raw.as<double>(), nullptr, B, S, p->task, 1, p->attack_type, e->ext_z.as<double>(),
+                 e->ext_z.as<double>() + 64, p->threshold, p->adver_thresh, p->target, p->true_label,
+                 e->dist_part.as<double>(), with_dist ? ndp : 0, e->scores.as<double>(), e->loss.as<double>(),
+                 e->nes_out.as<FbNesDev>(), ctl, trace_dev, trace_row);
+  return FB_OK;
+}
+
+extern "C" int fb_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
+                               const double *audio, int64_t N, uint32_t iter, const double *noise_pos,
+                               double *final_loss, double *grad, double *adver_loss, double *score0) {
+  if (!audio) return fb_fail(FB_E_ARG, "audio is NULL");
+  FBCHK(check_params_ext(e, p, N, S, cb));
+  HIPCHK(hipSetDevice(e->device));
+  FBCHK(sync_stream(e));
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1;
+  FBCHK(ensure_ext_buffers(e, N, B, S));
+  FBCHK(h2d(e, e->adver.p, audio, sizeof(double) * (size_t)N));
+  const double *noise_dev = nullptr;
+  if (noise_pos && half > 0) {
+    FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
+    FBCHK(h2d(e, e->noise.p, noise_pos, sizeof(double) * (size_t)N * half));
+    noise_dev = e->noise.as<double>();
+  }
+  FBCHK(enqueue_get_grad_ext(e, p, S, cb, cb_ctx, N, iter, noise_dev, false));
+  fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
+                        e->grad.as<double>(), 0, 0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr);
+  if (grad) FBCHK(d2h(e, grad, e->grad.p, sizeof(double) * (size_t)N));
+  HIPCHK(hipMemcpyAsync(e->h_out, e->nes_out.p, sizeof(FbNesDev), hipMemcpyDeviceToHost, e->stream));
+  FBCHK(sync_stream(e));
+  e->nes_iters += 1;
+  if (final_loss) *final_loss = e->h_out->final_loss;
+  if (adver_loss) *adver_loss = e->h_out->adver_loss;
+  if (score0) for (int s = 0; s < S; ++s) score0[s] = e->h_out->score0[s];
+  return FB_OK;
+}
+
+extern "C" int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
+                             const double *audio, int64_t N, const double *noise_all, int16_t *adv_i16,
+                             double *adver_f64, double *trace, int *n_trace, int *success_flag) {
+  if (!audio || !adv_i16 || !success_flag) return fb_fail(FB_E_ARG, "null argument");
+  FBCHK(check_params_ext(e, p, N, S, cb));
+  if (p->max_iter <= 0) return fb_fail(FB_E_ARG, "max_iter must be > 0");
+  HIPCHK(hipSetDevice(e->device));
+  FBCHK(sync_stream(e));
+  const int half = p->samples_per_draw / 2, B = 2 * half + 1;
+  FBCHK(ensure_ext_buffers(e, N, B, S));
+  FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
+  HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));  // grad = 0 (FAKEBOB.py:157)
+  if (noise_all && half > 0) FBCHK(e->noise.ensure(sizeof(double) * (size_t)N * half));
+  double *trace_dev = nullptr;
+  if (trace) {
+    FBCHK(e->trace_dev.ensure(sizeof(double) * (size_t)p->max_iter * (3 + S)));
+    trace_dev = e->trace_dev.as<double>();
+  }
+  // device loop control exactly as in fb_attack; the host looks at it after every iteration
+  FBCHK(e->ctl.ensure(sizeof(FbCtlDev)));
+  FBCHK(e->ctl_ls.ensure(sizeof(double) * (size_t)(p->plateau_length > 0 ? p->plateau_length : 1)));
+  FbCtlDev *ctl = e->ctl.as<FbCtlDev>();
+  {
+    FbCtlDev h;
+    memset(&h, 0, sizeof(h));
+    h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;
+    h.ls = e->ctl_ls.as<double>();
+    h.plateau_length = p->plateau_length;
+    *e->h_ctl = h;
+    HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
+    FBCHK(sync_stream(e));
+  }
+  const double one_minus_m = 1.0 - p->momentum;
+  for (int it = 0; it < p->max_iter; ++it) {
+    const double *noise_dev = nullptr;
+    if (noise_all && half > 0) {
+      FBCHK(h2d(e, e->noise.p, noise_all + (size_t)it * N * half, sizeof(double) * (size_t)N * half));
+      noise_dev = e->noise.as<double>();
+    }
+    FBCHK(enqueue_get_grad_ext(e, p, S, cb, cb_ctx, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it));
+    fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev, nullptr,
+                          1, p->momentum, one_minus_m, 0.0, p->epsilon, e->audio.as<double>(), e->grad_m.as<double>(),
+                          e->adver.as<double>(), ctl);
+    HIPCHK(hipMemcpyAsync(e->h_ctl, ctl, sizeof(FbCtlDev), hipMemcpyDeviceToHost, e->stream));
+    FBCHK(sync_stream(e));
+    if (e->h_ctl->stop) break;
+  }
+  const int rows = e->h_ctl->iters_done;
+  const bool broke = e->h_ctl->broke != 0;
+  e->nes_iters += rows;
+  if (trace && rows > 0) FBCHK(d2h(e, trace, trace_dev, sizeof(double) * (size_t)rows * (3 + S)));
+  const int last_iter = broke ? e->h_ctl->stop_iter : p->max_iter - 1;
+  *success_flag = (last_iter < p->max_iter - 1) ? 1 : -1;  // FAKEBOB.py:219
+  if (n_trace) *n_trace = rows;
+  FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N));
+  e->cached_B = -1;  // the scoring batch layout no longer describes e->wav
+  fb_launch_quantize(e->stream, e->adver.as<double>(), N, 16, e->wav.as<int16_t>());
+  FBCHK(d2h(e, adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N));
+  if (adver_f64) FBCHK(d2h(e, adver_f64, e->adver.p, sizeof(double) * (size_t)N));
+  FBCHK(sync_stream(e));
   return FB_OK;
 }
 

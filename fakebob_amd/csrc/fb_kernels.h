@@ -36,6 +36,9 @@ void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, 
                        const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part,
                        float *zbuf /* nullable: float32 normals [half][N] for the gradient kernel */,
                        const int *stop = nullptr /* nullable: device flag, != 0 -> the launch does nothing */);
+void fb_launch_perturb_f64(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
+                           double sigma, uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
+                           double *x, double *dist_part, int *n_dist_part, float *zbuf);
 // plain quantisation of float64 audio (model.score on float input)
 void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q);
 // noise dump (tests)
@@ -122,7 +125,21 @@ struct FbGmmDev {
 #define FB_GMM_MODE_FX2 2
 #ifndef FB_FX_OCC
 #define FB_FX_OCC 2  // k_gmm_fx2 workgroups per CU (launch bound and the launch's target block count)
+
 #endif
+
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) is per DEVICE: a process that creates engines on several
+// GPUs must repeat it on each.  One bit per device; the calls are idempotent, so a race between two host threads
+// on the same device only repeats them.
+#include <atomic>
+static inline bool fb_device_needs_optin(std::atomic<unsigned long long> &mask, unsigned long long *bit) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  *bit = 1ull << (dev & 63);
+  return (mask.load(std::memory_order_acquire) & *bit) == 0;
+}
+
+
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

@@ -728,12 +728,14 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
   if (fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2 && !want_r4) {
     const MfccR4Lds l16 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
     const size_t shm16 = sizeof(double) * (size_t)l16.wave0 + sizeof(double2) * (size_t)FB_R16_WAVES * 4 * FB_R16_SLOTS;
-    static bool attr16 = false;
-    if (!attr16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr16 = true;
+    static std::atomic<unsigned long long> optin16{0};
+    unsigned long long bit16 = 0;
+    bool ok16 = true;
+    if (fb_device_needs_optin(optin16, &bit16)) {
+      ok16 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      if (ok16) optin16.fetch_or(bit16, std::memory_order_release);
     }
-    if (shm16 <= 160 * 1024) {
+    if (ok16 && shm16 <= 160 * 1024) {
       const int n_groups = (total_frames + 3) / 4;
       const int rounds = (n_groups + 256 * FB_R16_WAVES - 1) / (256 * FB_R16_WAVES);
       const int blocks = (n_groups + rounds * FB_R16_WAVES - 1) / (rounds * FB_R16_WAVES);
@@ -1206,13 +1208,14 @@ bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *m
   if (t_max > fe.cmn_window) return false;
   const size_t shm = fb_delta_cmvn_lds_bytes(fe, t_max);
   if (shm > 150 * 1024) return false;
-  static bool configured = false;  // raise the dynamic-LDS limit once per process
-  if (!configured) {
+  static std::atomic<unsigned long long> optin{0};  // raise the dynamic-LDS limit once per device
+  unsigned long long bit = 0;
+  if (fb_device_needs_optin(optin, &bit)) {
     const void *fns[] = {reinterpret_cast<const void *>(k_delta_cmvn<2, 3>), reinterpret_cast<const void *>(k_delta_cmvn<2, 2>),
                          reinterpret_cast<const void *>(k_delta_cmvn<-1, 0>)};
     for (const void *fn : fns)
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;
-    configured = true;
+    optin.fetch_or(bit, std::memory_order_release);
   }
   if (fe.order == 2 && fe.dwin == 3)
     hipLaunchKernelGGL((k_delta_cmvn<2, 3>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);

@@ -1439,11 +1439,12 @@ void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, co
   const int R = iv.R;
   const size_t panel = (size_t)(R + 17) * (FB_IV_NB + 2);  // Lp (incl. the right-hand-side row) / rhs partials
   size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + std::max(panel, (size_t)8 * R));
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (fb_device_needs_optin(optin, &bit)) {  // > 64 KiB of dynamic LDS needs the opt-in, once per device
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (ok) optin.fetch_or(bit, std::memory_order_release);  // a failed opt-in surfaces as a launch error (hipGetLastError in run_scoring)
   }
   static const char *mode = getenv("FB_IV_SOLVE");
   if (mode && strcmp(mode, "dense") == 0)  // predecessor: dense copy + separate forward substitution (585 us vs 455 us)

@@ -92,6 +92,66 @@ void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, 
                      noise_pos, q, dist_part, zbuf, stop);
 }
 
+// Foreign-model path (the reference's plugin API, README.md:136: any `model` with score / make_decisions): the
+// perturbed batch leaves the device as float64 -- the model does its own int16 cast -- utterance-major:
+// x[0] = adver, x[1+j] = adver + sigma z_j, x[1+half+j] = adver - sigma z_j, exactly FAKEBOB.py:234-237.
+__global__ __launch_bounds__(256) void k_perturb_f64(const double *__restrict__ adver,
+                                                     const double *__restrict__ audio, int64_t N, int half,
+                                                     double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
+                                                     const double *__restrict__ noise_pos, double *__restrict__ x,
+                                                     double *__restrict__ dist_part, float *__restrict__ zbuf) {
+  const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  const int64_t n0 = n4 * 4;
+  double dmax = 0.0;
+  if (n0 < N) {
+    const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
+    double a[4];
+    for (int k = 0; k < 4; ++k) a[k] = (k < cnt) ? adver[n0 + k] : 0.0;
+    if (half > 0) {
+      double z[4];
+      if (noise_pos) {
+        for (int k = 0; k < 4; ++k) z[k] = (k < cnt) ? noise_pos[(n0 + k) * half + j] : 0.0;
+      } else {
+        float zf[4];
+        fb_noise4(seed, iter, stream, (uint32_t)n4, (uint32_t)j, zf);
+        for (int k = 0; k < 4; ++k) z[k] = (double)zf[k];
+        if (zbuf) for (int k = 0; k < cnt; ++k) zbuf[(int64_t)j * N + n0 + k] = zf[k];
+      }
+      for (int k = 0; k < cnt; ++k) {
+        x[(int64_t)(1 + j) * N + n0 + k] = __dadd_rn(__dmul_rn(sigma, z[k]), a[k]);
+        x[(int64_t)(1 + half + j) * N + n0 + k] = __dadd_rn(__dmul_rn(sigma, -z[k]), a[k]);
+      }
+    }
+    if (j == 0) {
+      for (int k = 0; k < cnt; ++k) {
+        x[n0 + k] = a[k];
+        if (audio) { double d = fabs(__dsub_rn(audio[n0 + k], a[k])); dmax = d > dmax ? d : dmax; }
+      }
+    }
+  }
+  if (blockIdx.y == 0 && dist_part) {
+    __shared__ double red[4];
+    double m = fb_wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = red[0];
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = red[w] > r ? red[w] : r;
+      dist_part[blockIdx.x] = r;
+    }
+  }
+}
+void fb_launch_perturb_f64(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
+                           double sigma, uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
+                           double *x, double *dist_part, int *n_dist_part, float *zbuf) {
+  int64_t n4 = (N + 3) / 4;
+  dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)(half > 0 ? half : 1));
+  if (n_dist_part) *n_dist_part = (int)grid.x;
+  hipLaunchKernelGGL(k_perturb_f64, grid, dim3(256), 0, s, adver, audio, N, half, sigma, seed, iter, stream,
+                     noise_pos, x, dist_part, zbuf);
+}
+
 __global__ __launch_bounds__(256) void k_quantize(const double *__restrict__ x, int64_t n, double scale,
                                                   int16_t *__restrict__ q) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -198,6 +198,67 @@ class Engine(object):
                                   N.ptr(trace), C.byref(nt), C.byref(flag)))
         return adv, flag.value, adv_f, trace[:nt.value]
 
+    # ---- NES with a foreign model (the reference's plugin API): scores come from `score_fn`
+    @staticmethod
+    def _score_cb(score_fn, S, err):
+        """score_fn(audios (N, B) float64) -> (B, S) scores, wrapped as an fb_score_cb.  An exception raised by the
+        model is kept in err[0] and re-raised by the caller (a ctypes callback cannot propagate it)."""
+        def _cb(_ctx, aud, n, b, out):
+            try:
+                a = np.ctypeslib.as_array(aud, shape=(b, n)).T          # (N, B) view, columns = utterances
+                sc = np.asarray(score_fn(a), np.float64).reshape(b, S)
+                np.ctypeslib.as_array(out, shape=(b, S))[...] = sc
+                return 0
+            except BaseException as ex:  # noqa: BLE001
+                err[0] = ex
+                return 1
+        return N.SCORE_CB(_cb)
+
+    @staticmethod
+    def _raise_cb(err, ex):
+        if getattr(ex, "code", None) == N.FB_E_CALLBACK and err[0] is not None:
+            raise err[0]
+        raise ex
+
+    def get_grad_ext(self, params, S, score_fn, audio, it=0, noise_pos=None):
+        """fb_get_grad_ext: one NES gradient estimate at `audio` scored by score_fn."""
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        n = audio.size
+        npz = None if noise_pos is None else np.ascontiguousarray(noise_pos, np.float64)
+        if npz is not None and npz.shape != (n, params.samples_per_draw // 2):
+            raise ValueError("noise_pos must be (N, samples_per_draw//2)")
+        grad = np.empty(n, np.float64)
+        fl, al = C.c_double(), C.c_double()
+        sc = np.empty(S, np.float64)
+        err = [None]
+        cb = self._score_cb(score_fn, S, err)
+        try:
+            N.check(self._L.fb_get_grad_ext(self._h, C.byref(params), C.c_int(S), cb, None, N.ptr(audio),
+                                            C.c_int64(n), C.c_uint32(it), None if npz is None else N.ptr(npz),
+                                            C.byref(fl), N.ptr(grad), C.byref(al), N.ptr(sc)))
+        except N.NativeError as ex:
+            self._raise_cb(err, ex)
+        return fl.value, grad, al.value, sc
+
+    def attack_ext(self, params, S, score_fn, audio, noise_all=None):
+        """fb_attack_ext: the whole attack loop with a foreign scorer -> (int16 adv, flag, float64 adv, trace)."""
+        audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
+        n = audio.size
+        na = None if noise_all is None else np.ascontiguousarray(noise_all, np.float64)
+        adv = np.empty(n, np.int16)
+        adv_f = np.empty(n, np.float64)
+        trace = np.zeros((max(params.max_iter, 1), 3 + S), np.float64)
+        nt, flag = C.c_int(), C.c_int()
+        err = [None]
+        cb = self._score_cb(score_fn, S, err)
+        try:
+            N.check(self._L.fb_attack_ext(self._h, C.byref(params), C.c_int(S), cb, None, N.ptr(audio), C.c_int64(n),
+                                          None if na is None else N.ptr(na), N.ptr(adv), N.ptr(adv_f), N.ptr(trace),
+                                          C.byref(nt), C.byref(flag)))
+        except N.NativeError as ex:
+            self._raise_cb(err, ex)
+        return adv, flag.value, adv_f, trace[:nt.value]
+
     def estimate_threshold(self, params, model_threshold, audio, noise_all=None, max_total_iters=100000):
         audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
         n = audio.size

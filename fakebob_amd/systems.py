@@ -60,6 +60,12 @@ class _GmmSystem(object):
     def engine(self):
         return self._engine
 
+    def score_utterance(self, audio, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
+        """One utterance -> its score(s): the name BASELINE.json's north_star uses for the scoring surface.  The
+        reference has no such symbol (its surface is model.score, README.md:136); this is score() for one audio."""
+        return self.score(np.asarray(audio).reshape(-1), fs=fs, bits_per_sample=bits_per_sample, debug=debug,
+                          n_jobs=n_jobs)
+
     def _raw(self, audios, bits_per_sample):
         lst = _to_audio_list(audios)
         raw, _tv = self._engine.score_raw(lst, bits_per_sample=bits_per_sample)
@@ -202,6 +208,12 @@ class _IvSystem(object):
     @property
     def engine(self):
         return self._engine
+
+    def score_utterance(self, audio, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
+        """One utterance -> its score(s): the name BASELINE.json's north_star uses for the scoring surface.  The
+        reference has no such symbol (its surface is model.score, README.md:136); this is score() for one audio."""
+        return self.score(np.asarray(audio).reshape(-1), fs=fs, bits_per_sample=bits_per_sample, debug=debug,
+                          n_jobs=n_jobs)
 
     def _llr(self, audios, bits_per_sample):
         raw, _tv = self._engine.score_raw(_to_audio_list(audios), bits_per_sample=bits_per_sample)

@@ -44,6 +44,7 @@ extern "C" {
                                 would silently drop it and mis-align rows) */
 #define FB_E_NOMEM (-5)
 #define FB_E_LIMIT (-6)      /* iteration cap reached (estimate_threshold) */
+#define FB_E_CALLBACK (-7)   /* the score callback of a foreign model returned non-zero */
 
 enum { FB_TASK_OSI = 0, FB_TASK_CSI = 1, FB_TASK_SV = 2 };
 enum { FB_UNTARGETED = 0, FB_TARGETED = 1 };
@@ -196,6 +197,22 @@ int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p,
                           int max_total_iters, double *score_out,
                           int *n_iters, int *n_outer, double *thr_final,
                           double *adver_f64);
+
+/* ---- foreign models: the reference's plugin API ---------------------------------------------------
+ * FakeBob takes ANY `model` object with score / make_decisions (README.md:136; FAKEBOB.py:53,89,250).  For a
+ * model that is not one of this library's systems the per-iteration scores come from this callback --
+ * audios[B][N] float64, utterance-major: row 0 = the current adversarial audio, rows 1.. = the antithetic NES
+ * samples, exactly the columns FAKEBOB.py:234-238 hands to model.score; scores[B*S] out; return 0 -- and
+ * everything else of the NES iteration (Philox noise, perturbation, loss, gradient estimate, momentum sign step,
+ * clipping, loop control) still runs on the device.  No model has to be loaded into the engine; S = number of
+ * enrolled speakers (1 for SV).  Arguments otherwise as fb_get_grad / fb_attack. */
+typedef int (*fb_score_cb)(void *ctx, const double *audios, int64_t N, int B, double *scores);
+int fb_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
+                    const double *audio, int64_t N, uint32_t iter, const double *noise_pos,
+                    double *final_loss, double *grad, double *adver_loss, double *score0);
+int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
+                  const double *audio, int64_t N, const double *noise_all, int16_t *adv_i16,
+                  double *adver_f64, double *trace, int *n_trace, int *success_flag);
 
 /* --- test / profiling hooks (stable, used by tests/ and bench.py) ------- */
 /* z[half*N] float32 from the device Philox/Box-Muller (bit-exact contract) */

@@ -330,14 +330,24 @@ def test_kaldi_conf_parsing(tmp_path):
         assert k in [f[0] for f in _native.FrontendCfg._fields_]
 
 
-def test_fakebob_rejects_models_without_the_engine():
+def test_fakebob_accepts_any_model_with_score_and_rejects_objects_without():
+    """The reference's plugin API (README.md:136): any object with score / make_decisions is a model; it is
+    driven through fb_attack_ext (tests/test_gpu_plugin_api.py).  Constructing needs no GPU."""
     from fakebob_amd.attack import FakeBob
 
     class Plain(object):
+        spk_ids = ["a"]
+
         def score(self, a, **k):
             return 0.0
+    fb = FakeBob("SV", "targeted", Plain(), verbose=False)
+    assert fb._native is False and fb._speakers() == 1
     with pytest.raises(TypeError):
-        FakeBob("SV", "targeted", Plain())
+        FakeBob("SV", "targeted", object())
+    with pytest.raises(ValueError):
+        FakeBob("XYZ", "targeted", Plain())
+    with pytest.raises(ValueError):                      # anything but 16-bit is refused, not silently ignored
+        fb.get_grad(np.zeros(1600), bits_per_sample=8)
 
 
 def test_bench_roofline_object_and_traffic_file_follow_the_contract():
