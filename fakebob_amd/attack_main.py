@@ -102,7 +102,10 @@ def build_attack_list(task, attack_type, model, test_dir, illegal_dir, out_audio
     return items
 
 
-def main(argv=None):
+def main(argv=None, model_factory=None, bob_factory=None):
+    """model_factory(architecture, task, model_list, pre_model_dir, threshold, group_id) / bob_factory(task,
+    attack_type, model, **hyper_parameters): injection points for the driver-rule tests (a stub model / stub FakeBob
+    as in tests/golden/driver_site.py); default: the GPU systems and fakebob_amd.attack.FakeBob."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--speaker_id", "-spk_id", nargs="+", type=str, required=True)
     ap.add_argument("--architecture", "-archi", default="gmm", choices=["gmm", "iv"])
@@ -142,15 +145,25 @@ def main(argv=None):
 
     dist = parallel.init_process_group(args.dist_backend)
     rank, _local, world = parallel.dist_env()
-    model_list = load_spk_models(args.model_dir, spk_id_list, args.architecture)
     K = max(1, args.streams)
-    models = [make_model(args.architecture, task, model_list, args.pre_model_dir, args.threshold,
-                         os.path.join(args.out_dir, ident + ("-%d" % k))) for k in range(K)]
-    seed = args.seed if args.seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+    if model_factory is None:
+        model_list = load_spk_models(args.model_dir, spk_id_list, args.architecture)
+        model_factory = make_model
+    else:
+        model_list = spk_id_list
+    models = [model_factory(args.architecture, task, model_list, args.pre_model_dir, args.threshold,
+                            os.path.join(args.out_dir, ident + ("-%d" % k))) for k in range(K)]
+    # one Philox key for the whole job: drawn on rank 0 when --seed is omitted and broadcast, so that a multi-rank
+    # run is reproducible and its results do not depend on the sharding
+    seed = args.seed if args.seed is not None else (int(np.random.randint(0, 2 ** 31 - 1)) if rank == 0 else 0)
+    seed = int(parallel.broadcast_threshold(float(seed), dist))
     hp = dict(adver_thresh=args.adver_thresh, epsilon=args.epsilon, max_iter=args.max_iter, max_lr=args.max_lr,
               min_lr=args.min_lr, samples_per_draw=args.samples_per_draw, sigma=args.sigma,
               momentum=args.momentum, plateau_length=args.plateau_length, plateau_drop=args.plateau_drop)
-    bobs = [FakeBob(task, attack_type, m, seed=seed, verbose=False, **hp) for m in models]
+    if bob_factory is None:
+        bobs = [FakeBob(task, attack_type, m, seed=seed, verbose=False, **hp) for m in models]
+    else:
+        bobs = [bob_factory(task, attack_type, m, **hp) for m in models]
 
     items = build_attack_list(task, attack_type, models[0], args.test_dir, args.illegal_dir, out_audio, out_cp)
     total = len(items)
@@ -178,7 +191,9 @@ def main(argv=None):
             idx = mine[j]
             it = items[idx]
             bob._stream = idx + 1         # Philox stream = global attack index: results do not depend on the sharding
-            adv, flag = bob.attack(it["audio"], it["cp_path"], threshold=threshold, true=it["true"],
+            # the reference passes true= only for CSI untargeted (:346) and target= only for targeted attacks (:332,:367)
+            true = it["true"] if (task == "CSI" and attack_type == "untargeted") else None
+            adv, flag = bob.attack(it["audio"], it["cp_path"], threshold=threshold, true=true,
                                    target=it["target"], fs=fs, bits_per_sample=bits_per_sample)
             write(it["wav_path"], fs, adv)
             with lock:
@@ -187,7 +202,7 @@ def main(argv=None):
     ths = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
     [t.start() for t in ths]
     [t.join() for t in ths]
-    st = [m.engine.stats() for m in models]
+    st = [m.engine.stats() if hasattr(m, "engine") else dict(nes_iters=0, scored_utts=0) for m in models]
     succ = sum(1 for f in results.values() if f == 1)
     g = parallel.reduce_counters([succ, len(mine), sum(s["nes_iters"] for s in st), sum(s["scored_utts"] for s in st)], dist)
     if rank == 0:

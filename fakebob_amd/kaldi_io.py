@@ -88,8 +88,12 @@ class _Reader(object):
             m = np.frombuffer(self.b, dt, r * c, self.i).astype(np.float64).reshape(r, c)
             self.i += r * c * dt.itemsize
             return m
+        return np.asarray(self.text_rows(), np.float64)
+
+    def text_rows(self):
+        """Text-mode matrix body `[ r0 \n r1 ... ]` as a list of rows (rows may be ragged: a text SpMatrix)."""
         self.expect("[")
-        rows, cur = [], []
+        rows = []
         while True:
             self._skip_ws()
             # rows are newline separated; the closing bracket ends the last row
@@ -103,8 +107,7 @@ class _Reader(object):
                 self.i = j + 1
                 break
             self.i = j + 1
-        del cur
-        return np.asarray(rows, np.float64)
+        return rows
 
 
 def read_diag_gmm(path_or_bytes):
@@ -182,7 +185,8 @@ def _read_file(path_or_bytes):
 
 
 def _sp(rd):
-    """SpMatrix: binary "FP"/"DP" + int32 rows + packed lower-triangular data; text = full rows."""
+    """SpMatrix: binary "FP"/"DP" + int32 rows + packed lower-triangular data; text = the lower triangle, row i
+    holding i + 1 numbers (PackedMatrix::Write) -- a full square text matrix is accepted as well."""
     if rd.binary:
         t = rd.token()
         if t not in ("FP", "DP"):
@@ -193,10 +197,13 @@ def _sp(rd):
         v = np.frombuffer(rd.b, dt, cnt, rd.i).astype(np.float64)
         rd.i += cnt * dt.itemsize
         return v, n
-    m = rd.matrix()
-    n = m.shape[0]
-    r, c = np.tril_indices(n)
-    return np.array([m[i][j] for i, j in zip(r, c)], np.float64), n
+    rows = rd.text_rows()
+    n = len(rows)
+    if all(len(row) == i + 1 for i, row in enumerate(rows)):
+        return np.array([x for row in rows for x in row], np.float64), n
+    if all(len(row) == n for row in rows):
+        return np.array([rows[i][j] for i in range(n) for j in range(i + 1)], np.float64), n
+    raise ValueError("kaldi_io: text SpMatrix is neither lower-triangular nor square")
 
 
 def _f64(rd):
@@ -321,3 +328,76 @@ def load_gmm_any(loc):
             return DiagGmm(z["gconsts"], z["means_invvars"], z["inv_vars"])
         return read_diag_gmm(p)[0]
     raise TypeError("cannot load a GMM from %r" % (loc,))
+
+
+# ------------------------------------------------------------------ writers (binary Kaldi objects)
+def _tok(t):
+    return t.encode("ascii") + b" "
+
+
+def _i32(v):
+    return b"\x04" + struct.pack("<i", int(v))
+
+
+def _vec_bytes(v, double=False):
+    v = np.asarray(v).reshape(-1)
+    return _tok("DV" if double else "FV") + _i32(v.size) + v.astype("<f8" if double else "<f4").tobytes()
+
+
+def _mat_bytes(m, double=False):
+    m = np.asarray(m)
+    r, c = (m.shape if m.ndim == 2 else (0, 0))
+    return _tok("DM" if double else "FM") + _i32(r) + _i32(c) + np.ascontiguousarray(m, "<f8" if double else "<f4").tobytes()
+
+
+def _sp_bytes(packed, n, double=False):
+    return _tok("DP" if double else "FP") + _i32(n) + np.asarray(packed).reshape(-1).astype("<f8" if double else "<f4").tobytes()
+
+
+def write_vector(path, v, double=False):
+    with open(path, "wb") as w:
+        w.write(b"\x00B" + _vec_bytes(v, double))
+
+
+def write_matrix(path, m, double=False):
+    with open(path, "wb") as w:
+        w.write(b"\x00B" + _mat_bytes(m, double))
+
+
+def write_full_gmm(path, weights, means_invcovars, inv_covars):
+    """final.ubm: FullGmm::Write (float32; gconsts are recomputed by every reader)."""
+    C, D = np.asarray(means_invcovars).shape
+    b = b"\x00B" + _tok("<FullGMM>") + _tok("<GCONSTS>") + _vec_bytes(np.zeros(C)) + _tok("<WEIGHTS>") + _vec_bytes(weights) \
+        + _tok("<MEANS_INVCOVARS>") + _mat_bytes(means_invcovars) + _tok("<INV_COVARS>") \
+        + b"".join(_sp_bytes(inv_covars[k], D) for k in range(C)) + _tok("</FullGMM>")
+    with open(path, "wb") as w:
+        w.write(b)
+
+
+def write_ivector_extractor(path, M, sigma_inv, prior_offset):
+    """final.ie: IvectorExtractor::Write without weight projections (float64)."""
+    M = np.asarray(M, np.float64)
+    C, D, _ = M.shape
+    b = b"\x00B" + _tok("<IvectorExtractor>") + _tok("<w>") + _mat_bytes(np.zeros((0, 0)), True) + _tok("<w_vec>") \
+        + _vec_bytes(np.zeros(C), True) + _tok("<M>") + _i32(C) + b"".join(_mat_bytes(M[k], True) for k in range(C)) \
+        + _tok("<SigmaInv>") + b"".join(_sp_bytes(sigma_inv[k], D, True) for k in range(C)) \
+        + _tok("<IvectorOffset>") + b"\x08" + struct.pack("<d", float(prior_offset)) + _tok("</IvectorExtractor>")
+    with open(path, "wb") as w:
+        w.write(b)
+
+
+def write_plda(path, mean, transform, psi):
+    with open(path, "wb") as w:
+        w.write(b"\x00B" + _tok("<Plda>") + _vec_bytes(mean, True) + _mat_bytes(transform, True) + _vec_bytes(psi, True)
+                + _tok("</Plda>"))
+
+
+def write_ivector_pre_models(pre_model_dir, system):
+    """Everything load_ivector_pre_models reads, from a models.IvectorSystem (synthetic sites, enrolment tools)."""
+    os.makedirs(pre_model_dir, exist_ok=True)
+    p = lambda n: os.path.join(pre_model_dir, n)   # noqa: E731
+    write_full_gmm(p("final.ubm"), system.fg_weights, system.fg_means_invcovars, system.fg_inv_covars)
+    write_ivector_extractor(p("final.ie"), system.ie_M, system.ie_sigma_inv, system.prior_offset)
+    write_vector(p("mean.vec"), system.mean_vec)
+    write_matrix(p("transform.mat"), system.lda)
+    write_plda(p("plda"), system.plda_mean, system.plda_transform, system.plda_psi)

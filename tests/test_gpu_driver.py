@@ -112,3 +112,105 @@ def test_evaluate_counterpart_on_site(tmp_path):
     for k in ("FRR", "FAR"):
         assert 0.0 <= r["SV"][k] <= 100.0 and 0.0 <= r["OSI"][k] <= 100.0
     assert 0.0 <= r["OSI"]["IER"] <= 100.0 and np.isfinite(r["SV"]["threshold"]) and np.isfinite(r["OSI"]["threshold"])
+
+
+def _oracle_site_scores(oracle, tmp_path, ids):
+    """Oracle scores of the site's voices with the SAME model files the product reads (the format readers are not
+    arithmetic): raw[b][m] per task -> the wrappers' post-processing in numpy."""
+    from fakebob_amd import attack_main as AM
+    from fakebob_amd import evaluate as E
+    from fakebob_amd.kaldi_io import load_gmm_any
+    from fakebob_amd.models import stack_models
+    ml = AM.load_spk_models(str(tmp_path / "model"), ids, "gmm")
+    ubm = load_gmm_any(str(tmp_path / "pre-models" / "final.dubm"))
+    spk = [load_gmm_any(m[2]) for m in ml]
+    cfg = oracle.default_cfg()
+
+    def raw(models, wavs):
+        gc, miv, iv = stack_models(models)
+        return oracle.gmm_score_batch(cfg, [np.asarray(w, np.int16) for w in wavs], gc, miv, iv, nthreads=8)[0]
+    imp = E.load_impostors(str(tmp_path / "data" / "illegal-set"))
+    audios, labels = E.load_trials(str(tmp_path / "data" / "test-set"), ids)
+    zm = np.array([m[3] for m in ml]); zs = np.array([m[4] for m in ml])
+    return ml, ubm, spk, raw, imp, audios, labels, zm, zs
+
+
+def test_evaluate_counterpart_equals_oracle_derived_numbers(tmp_path, oracle):
+    """test.py counterpart on the GPU against the same (golden-pinned) formulas applied to ORACLE scores: accuracy,
+    FRR, FAR, IER are counts and must be identical; thresholds are scores (<= 1e-4)."""
+    from fakebob_amd import evaluate as E
+    ids, _, _ = _site(tmp_path)
+    ml, ubm, spk, raw, imp, audios, labels, zm, zs = _oracle_site_scores(oracle, tmp_path, ids)
+    r = E.evaluate("gmm", ml, str(tmp_path / "pre-models"), str(tmp_path / "data" / "test-set"),
+                   str(tmp_path / "data" / "illegal-set"), group_prefix=str(tmp_path / "ev"))
+    csi = (raw(spk, audios) - zm) / zs
+    assert r["CSI"]["accuracy"] == E.csi_accuracy(np.argmax(csi, axis=1), labels)
+    st, su = [], []
+    for i, sid in enumerate(ids):
+        own = E._read_dir(str(tmp_path / "data" / "test-set" / sid))
+        ro, ri = raw([ubm, spk[i]], own), raw([ubm, spk[i]], imp)
+        st += list(ro[:, 1] - ro[:, 0])
+        su += list(ri[:, 1] - ri[:, 0])
+    thr, frr, far = E.set_threshold(st, su)
+    assert r["SV"]["FRR"] == frr and r["SV"]["FAR"] == far and abs(r["SV"]["threshold"] - thr) <= 1e-4
+    ro, ri = raw([ubm] + spk, audios), raw([ubm] + spk, imp)
+    thr, frr, ier, far = E.osi_metrics(ro[:, 1:] - ro[:, :1], labels, ri[:, 1:] - ri[:, :1])
+    assert (r["OSI"]["FRR"], r["OSI"]["IER"], r["OSI"]["FAR"]) == (frr, ier, far)
+    assert abs(r["OSI"]["threshold"] - thr) <= 1e-4
+
+
+def test_iv_architecture_site_run(tmp_path, capsys, oracle):
+    """`-archi iv` end to end on a synthetic site: Kaldi-format final.ubm / final.ie / mean.vec / transform.mat /
+    plda, `.iv` speaker pickles whose identity_location points into a text ark (build_spk_models.py:146-150), SV
+    task with the threshold estimated on rank 0 (attackMain.py:393-394)."""
+    from fakebob_amd import attack_main as AM
+    from fakebob_amd.kaldi_io import write_ivector_pre_models
+    from fakebob_amd.models import synthetic_ivector_system
+    sy = synthetic_ivector_system(C=64, D=72, R=32, L=16, n_speakers=2, seed=4)
+    pre = tmp_path / "pre-models"
+    write_ivector_pre_models(str(pre), sy)
+    (pre / "conf").mkdir()
+    (pre / "conf" / "mfcc.conf").write_text("--sample-frequency=16000\n--frame-length=25\n--low-freq=20\n--high-freq=7600\n"
+                                            "--num-mel-bins=30\n--num-ceps=24\n--snip-edges=false\n")
+    (pre / "conf" / "vad.conf").write_text("--vad-energy-threshold=5.5\n--vad-energy-mean-scale=0.5\n"
+                                           "--vad-proportion-threshold=0.12\n--vad-frames-context=2\n")
+    (pre / "delta_opts").write_text("--delta-window=3 --delta-order=2\n")
+    (tmp_path / "model").mkdir()
+    ids = ["1580", "61"]
+    ark = tmp_path / "model" / "ivector.1.ark"
+    offs, txt = [], ""
+    for i, sid in enumerate(ids):
+        head = "%s-enroll  " % sid
+        offs.append(len(txt) + len(head))
+        txt += head + "[ " + " ".join("%.9g" % v for v in sy.enrolled[i]) + " ]\n"
+    ark.write_text(txt)
+    for i, sid in enumerate(ids):
+        with open(str(tmp_path / "model" / (sid + ".iv")), "wb") as f:
+            pickle.dump([sid, sid + "-enroll", "%s:%d" % (ark, offs[i]), -30.0 - i, 6.0 + i], f)
+    for j, s in enumerate(["9001", "9002"]):
+        d = tmp_path / "data" / "illegal-set" / s
+        d.mkdir(parents=True)
+        for u in range(2):
+            write(str(d / ("%s-utt%d.wav" % (s, u))), 16000, (synthetic_audio(10 * j + u, 16000) * 32768).astype(np.int16))
+    (tmp_path / "data" / "test-set").mkdir()
+    # the benign scores of the illegal voices, from the ORACLE, place the system threshold just above them
+    voices = AM.collect_voices(str(tmp_path / "data" / "illegal-set"))
+    sv_sys = sy.with_enrolled(sy.enrolled[:1], [-30.0], [6.0])
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sv_sys, nthreads=8)
+    so = ctx.score(np.stack([v[2] for v in voices], axis=1))[:, 0]
+    thr = float(so.max()) + 0.01
+    argv = ["-spk_id"] + ids + ["-archi", "iv", "-task", "SV", "-thresh", str(thr), "-max_iter", "12", "-samples", "10",
+            "--streams", "2", "--seed", "11", "--model_dir", str(tmp_path / "model"), "--pre_model_dir", str(pre),
+            "--test_dir", str(tmp_path / "data" / "test-set"), "--illegal_dir", str(tmp_path / "data" / "illegal-set"),
+            "--out_dir", str(tmp_path / "out")]
+    np.random.seed(5)
+    g, results, thr_est = AM.main(argv)
+    out = capsys.readouterr().out
+    assert "load data done, total num: 4" in out and "attack successful rate" in out   # all 4 voices rejected -> attacked
+    assert g[1] == 4 and len(results) == 4 and g[2] > 0
+    assert thr_est >= thr - 1e-4                      # estimate_threshold returns an accepted score (FAKEBOB.py:96-103)
+    base = tmp_path / "out" / "adversarial-audio" / "iv-SV-targeted" / "1580"
+    for (spk_id, name, audio) in voices:
+        _, adv = read(str(base / spk_id / name))
+        assert adv.dtype == np.int16 and np.abs(adv / 32768.0 - audio).max() <= 0.002 + 1.0 / 32768
+        assert (tmp_path / "out" / "checkpoint" / "iv-SV-targeted" / "1580" / spk_id / (name.split(".")[0] + ".cp")).exists()

@@ -377,3 +377,26 @@ def test_bench_roofline_object_and_traffic_file_follow_the_contract():
     for key in ("k_gmm_fx2<5, false>", "k_gmm_bx3<5, false>", "k_gmm<36, false>", "k_iv_contract_dma<lin>+<quad>"):
         assert tr[key]["hbm_bytes_per_launch"] > 0
     assert bench.GMM_TRAFFIC_KEY in tr
+
+
+def test_kaldi_text_spmatrix_is_lower_triangular_and_writers_round_trip(tmp_path):
+    """Kaldi writes a text SpMatrix as its lower triangle, row i holding i + 1 numbers (PackedMatrix::Write): a
+    hand-written text final.ubm must load; and the binary writers round-trip a synthetic i-vector system through
+    load_ivector_pre_models bit for bit."""
+    from fakebob_amd import kaldi_io as K
+    from fakebob_amd.models import synthetic_ivector_system
+    txt = ("<FullGMM> <GCONSTS>  [ 0 0 ]\n<WEIGHTS>  [ 0.25 0.75 ]\n<MEANS_INVCOVARS>  [\n  1 2 3\n  4 5 6 ]\n"
+           "<INV_COVARS>  [\n  1\n  0.5 2\n  -0.25 0.125 3 ]\n [\n  4\n  1 5\n  2 3 6 ]\n</FullGMM> ")
+    w, mic, covs = K.read_full_gmm(txt.encode())
+    assert list(w) == [0.25, 0.75] and mic.shape == (2, 3)
+    assert np.array_equal(covs, np.array([[1, 0.5, 2, -0.25, 0.125, 3], [4, 1, 5, 2, 3, 6]], np.float64))
+    # a full square text matrix is accepted too
+    sq = "<FullGMM> <WEIGHTS>  [ 1 ]\n<MEANS_INVCOVARS>  [\n  1 2 ]\n<INV_COVARS>  [\n  2 0.5\n  0.5 3 ]\n</FullGMM> "
+    assert np.array_equal(K.read_full_gmm(sq.encode())[2], np.array([[2, 0.5, 3]], np.float64))
+    sy = synthetic_ivector_system(C=6, D=72, R=10, L=4, n_speakers=2, seed=2)
+    K.write_ivector_pre_models(str(tmp_path / "pre"), sy)
+    d = K.load_ivector_pre_models(str(tmp_path / "pre"))
+    for k in ("fg_weights", "fg_means_invcovars", "fg_inv_covars", "ie_M", "ie_sigma_inv", "mean_vec", "lda",
+              "plda_mean", "plda_transform", "plda_psi"):
+        assert np.array_equal(np.asarray(d[k], getattr(sy, k).dtype), getattr(sy, k)), k
+    assert d["prior_offset"] == sy.prior_offset
