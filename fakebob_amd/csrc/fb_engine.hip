@@ -568,6 +568,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.item_model = e->gmm_items.as<int>();
+  g.item_model_host_q_first = (G == 1) ? 1 : 0;  // one group: the list built above is {Q, 0, 1, ..., M-1}
   e->n_groups = G;
   e->have_gmm = true;
   e->kind = 0;
@@ -659,10 +660,11 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
 // Split the component tiles into chunks so that the launch is ONE fully resident round:
 // ~4 workgroups per CU (VGPR/LDS budget of k_gmm) x 256 CUs.  A second, partially filled round
 // would idle most of the chip for a whole chunk's duration.
-static int choose_chunks(const FbGmmDev &g, int rows_cap) {
-  const int strips = (rows_cap + 127) / 128;
+static int choose_chunks(const FbGmmDev &g, int rows_cap, bool scoring = true) {
+  const bool wide = scoring && fb_gmm_use_wide(g);  // k_gmm_fx2w: 256-frame strips, one workgroup per CU
+  const int strips = wide ? (rows_cap + 255) / 256 : (rows_cap + 127) / 128;
   const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
-  const int target = ev ? atoi(ev) : (g.mode == FB_GMM_MODE_F32 ? 1024 : (g.mode == FB_GMM_MODE_FX2 ? 256 * FB_FX_OCC : 512));
+  const int target = ev ? atoi(ev) : (wide ? 256 : (g.mode == FB_GMM_MODE_F32 ? 1024 : (g.mode == FB_GMM_MODE_FX2 ? 256 * FB_FX_OCC : 512)));
   int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;
@@ -752,7 +754,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   FBCHK(e->tv.ensure(sizeof(int) * (size_t)B));
   FBCHK(e->row_off.ensure(sizeof(int) * (size_t)(B + 1)));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)total_frames * fe.dim));
-  const int n_chunks = choose_chunks(g, total_frames);
+  const int n_chunks = choose_chunks(g, total_frames, e->kind == 0);
   if (e->kind == 0) {
     FBCHK(e->part_m.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
     FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * total_frames));
@@ -1672,7 +1674,7 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
   FBCHK(e->enr_stats.ensure(sizeof(double) * (size_t)g.C * (g.D + 1)));
   hipStream_t s = e->stream;
   const int *n_rows_ptr = e->row_off.as<int>() + 1;
-  fb_launch_gmm_dump(s, g, e->feats.as<float>(), n_rows_ptr, T, choose_chunks(g, T), e->enr_ll.as<float>());
+  fb_launch_gmm_dump(s, g, e->feats.as<float>(), n_rows_ptr, T, choose_chunks(g, T, false), e->enr_ll.as<float>());
   double *d_occ = e->enr_stats.as<double>(), *d_F = d_occ + g.C;
   fb_launch_gmm_post_stats(s, g.C, ld, g.D, e->enr_ll.as<float>(), e->feats.as<float>(), n_rows_ptr, T,
                            e->enr_aux.as<float>(), e->enr_aux.as<float>() + T, d_occ, d_F);

@@ -108,6 +108,7 @@ struct FbGmmDev {
   int img_floats;                     // floats per tile image
   const float *images;                // [n_tiles][n_items][img_floats]
   const int *item_model;              // [n_items]: -1 = quadratic (Q) item, else model index
+  int item_model_host_q_first;        // 1: the item list is exactly {Q, model 0, 1, ..., M-1} (one variance group)
   // bf16x3 variant (k_gmm_bx3): K padded to 16*NK >= D + 3, images [n_tiles][n_items][3][NK][64] x 16 B
   int mode, NK;
   const unsigned int __attribute__((ext_vector_type(4))) * images_bx;
@@ -140,6 +141,9 @@ static inline bool fb_device_needs_optin(std::atomic<unsigned long long> &mask, 
 }
 
 
+// true when fb_launch_gmm runs the one-wave-per-SIMD scoring kernel k_gmm_fx2w (256-frame strips, one round of <= 256
+// workgroups): the engine sizes the component chunks for it
+bool fb_gmm_use_wide(const FbGmmDev &g);
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

@@ -716,6 +716,294 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_gmm_fx2w: the scoring form of k_gmm_fx2 for ONE variance group (mean-only MAP adaptation: the UBM and all its
+// speaker models; items per tile = Q, m_0 .. m_{M-1}) -- one wave per SIMD, 64 frames per wave, software-pipelined,
+// the whole tile as straight-line code.
+//
+// Why (tools/probes/coissue_probe.hip, cycles per two items = 30 MFMAs + two logsumexp updates):
+//   * MFMAs on ONE accumulator issue only as fast as they execute (the wave sits at the next dependent MFMA), so in
+//     k_gmm_fx2 an item's update (~2/3 of its MFMA time in vector instructions) starts when its 15 MFMAs are done: 1549.
+//   * MFMAs that alternate between two INDEPENDENT accumulators are queued by the matrix pipe and the wave goes on
+//     issuing behind them: with the update of the PREVIOUS item's values placed after the current item's MFMAs the
+//     same work takes 1061 (969 = the MFMA time alone with a finer interleave).
+// The two independent chains of an item are the two 32-frame halves of the wave's 64 frames: both use the SAME
+// parameter fragments (half the LDS reads per MFMA) and every item, the quadratic one included, is a pair.  That needs
+// 160 registers of frame operands + 96 of accumulators (hq, in flight, being consumed; two halves each) + two sets of
+// parameter fragments: the 512-register budget of one wave per SIMD -- 4 waves (256 frames) per workgroup, one
+// workgroup per CU, component chunks chosen so that a launch is one round of <= 256 workgroups.  An empty asm pins the
+// accumulators to AGPRs (left alone hipcc parks the FRAME operands there and copies them back in front of every
+// MFMA: 1190 v_accvgpr moves).
+// With one wave per SIMD nothing hides instruction fetch after a branch (a loop over items with the item kind,
+// pending update and padding decided by branches ran at ~1500 cycles per item with an EMPTY body), hence the
+// specialisation: M is a template parameter, accumulator sets and fragment sets have static roles (model m writes set
+// m & 1 while set (m - 1) & 1 is updated behind its MFMAs; the quadratic item overlaps the update of the previous
+// tile's last model), and a tile is one basic block.  Models with C % 32 != 0, several variance groups or other M
+// run on k_gmm_fx2.
+// Parameter items arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): wave w brings
+// the 1 KB pieces w, w + 4, w + 8 of the 10 KB image (clamped: every wave issues NPW loads per item, which keeps the
+// vmcnt bookkeeping uniform) three items ahead into a ring of four slots; the fragments of item i + 1 are read into
+// the second fragment set while the MFMAs of item i run, so an image must be in LDS and published by a barrier two
+// iterations before its MFMAs.
+__device__ __forceinline__ void fb_glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int NK>
+__device__ __forceinline__ void fb_fxw_frags(const u32x4 *__restrict__ cur4, int lane, u32x4 (&a1)[NK], u32x4 (&a2)[NK]) {
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    a1[c] = cur4[(0 * NK + c) * 64 + lane];
+    a2[c] = cur4[(1 * NK + c) * 64 + lane];
+  }
+}
+// the 2 x 3 NK MFMAs of one item: out0/out1 = init0/init1 + a (x) b[half], halves alternating
+template <int NK>
+__device__ __forceinline__ void fb_fxw_pair(const u32x4 (&a1)[NK], const u32x4 (&a2)[NK], const u32x4 (&b1)[2][NK],
+                                            const u32x4 (&b2)[2][NK], const f32x16 &init0, const f32x16 &init1,
+                                            f32x16 &out0, f32x16 &out1) {
+  f32x16 x0 = init0, x1 = init1;
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    FB_FX_MFMA(a2[c], b1[0][c], x0);
+    FB_FX_MFMA(a2[c], b1[1][c], x1);
+    FB_FX_MFMA(a1[c], b2[0][c], x0);
+    FB_FX_MFMA(a1[c], b2[1][c], x1);
+    FB_FX_MFMA(a1[c], b1[0][c], x0);
+    FB_FX_MFMA(a1[c], b1[1][c], x1);
+  }
+  asm volatile("" : "+a"(x0), "+a"(x1));
+  out0 = x0;
+  out1 = x1;
+}
+
+template <int NK, int M>
+__global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__restrict__ feats,
+                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                     int rows_cap, float *__restrict__ part_m,
+                                                     float *__restrict__ part_s, int xcd_map) {
+  if (g.stop && *g.stop) return;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
+  constexpr int NI = M + 1;          // items per tile: Q, m_0 .. m_{M-1}
+  constexpr int GA = (NI + 1) / 2, GB = NI - GA;  // a tile's items live in two LDS slots: A = items 0 .. GA-1, B = the rest
+  const int n_rows = *n_rows_ptr;
+  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
+  if (xcd_map) {
+    const int lin = blockIdx.x, per = 8 / xcd_map;
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 256;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const u32x4 *slot0 = reinterpret_cast<const u32x4 *>(lds);
+  float *st_m = lds + NI * IMG4 * 4;           // [M][2 halves][256]
+  float *st_s = st_m + M * 512;                // [M][2 halves][256]
+
+  // ---- frame fragments of the two 32-frame halves (layout and range guard as in k_gmm_fx2; the power-of-two shift
+  //      is uniform over the wave's 64 frames)
+  u32x4 bx1[2][NK], bx2[2][NK], bq1[2][NK], bq2[2][NK];
+  int sh = 0;
+  int rows[2];
+  {
+    const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);
+    float vv[2][NK][8], qq[2][NK][8];
+    float amax = xs;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      rows[hf] = strip0 + w * 64 + hf * 32 + j;
+      const bool ok = rows[hf] < n_rows;
+      const float *fr = feats + (size_t)(ok ? rows[hf] : 0) * g.D;
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        const int d0 = 16 * c + 8 * h;
+        float *v = vv[hf][c], *q = qq[hf][c];
+        if ((g.D & 3) == 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int d = d0 + 4 * u;
+            const float4 t = *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
+            const bool in = ok && d < g.D;
+            v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
+            v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fmaxf(fabsf(v[i]), q[i]));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (amax >= 32768.0f) {
+      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+      sh = min(ex - 14, 100);
+    }
+    const float down = fb_pow2f(-sh);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        if (sh) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { vv[hf][c][i] = __fmul_rn(vv[hf][c][i], down); qq[hf][c][i] = __fmul_rn(qq[hf][c][i], down); }
+        }
+        fb_split2_frag(vv[hf][c], bx1[hf][c], bx2[hf][c]);
+        fb_split2_frag(qq[hf][c], bq1[hf][c], bq2[hf][c]);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
+
+  const int tile0 = chunk_i * tiles_per_chunk;
+  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
+  const int n_t = tile1 - tile0, total_items = n_t * NI;
+  const u32x4 *gimg = g.images_fx + (size_t)tile0 * NI * IMG4;
+  const float unscale = fb_pow2f(sh - g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
+
+  // ---- parameter stream.  A workgroup barrier per item costs ~400 cycles at one wave per SIMD (the probe's mode 12
+  // against 11), so the barrier is taken twice per TILE: slot A holds items 0 .. GA-1, slot B items GA .. NI-1.
+  // While group A of tile t is processed the LDS-DMA fills slot B with group B of the same tile, while group B is
+  // processed it fills slot A with group A of tile t + 1; the pieces (1 KB each, NPIECE per item) are dealt over the
+  // steps of the group and the four waves, issued in front of each step's MFMAs (issuing them behind costs 200 cycles
+  // more per step, probe modes 14 / 15), awaited with vmcnt(0) + barrier where the group ends.
+  constexpr int NPIECE = IMG4 / 64;
+  constexpr int PPS_A = (GB * NPIECE + 4 * GA - 1) / (4 * GA);  // pieces per wave and step while group A runs (fills B)
+  constexpr int PPS_B = GB > 0 ? (GA * NPIECE + 4 * GB - 1) / (4 * GB) : 0;  // ... while group B runs (fills A)
+  const int wv = __builtin_amdgcn_readfirstlane(w);
+  const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
+  // piece q of the group that starts at item `first` (n_items_grp items) -> LDS slot offset slot4 (16-byte units)
+  auto dma = [&](int first, int n_items_grp, int slot4, int step, int pps) {
+#pragma unroll
+    for (int u = 0; u < pps; ++u) {
+      const int q = min((step * pps + u) * 4 + wv, n_items_grp * NPIECE - 1);
+      const int item_i = min(first + q / NPIECE, total_items - 1), pc = q % NPIECE;
+      fb_glds16(gimg + (size_t)item_i * IMG4 + pc * 64 + lane, ring_lds + (unsigned)((slot4 + (q / NPIECE) * IMG4 + pc * 64) * 16));
+    }
+  };
+  auto update = [&](const f32x16 &v0, const f32x16 &v1, int model) {
+    fb_lse_update16(v0, st_m + (2 * model) * 256 + tid, st_s + (2 * model) * 256 + tid, ls);
+    fb_lse_update16(v1, st_m + (2 * model + 1) * 256 + tid, st_s + (2 * model + 1) * 256 + tid, ls);
+  };
+  auto publish = [&]() {  // everything this wave asked for has landed; the barrier publishes all four waves' pieces
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  f32x16 hq[2], acc[2][2], zero;  // acc[set][half]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    hq[0][r] = 0.f; hq[1][r] = 0.f; zero[r] = 0.f;
+    acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+  }
+  {  // group A of the first tile
+    constexpr int P0 = (GA * NPIECE + 3) / 4;
+    dma(0, GA, 0, 0, P0);
+    publish();
+  }
+  u32x4 f1[2][NK], f2[2][NK];  // parameter fragment sets: item j of a tile uses set j & 1
+  for (int t = 0; t < n_t; ++t) {
+    const int it0 = t * NI;
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {   // compile-time item index within the tile: 0 = Q, 1 + m = model m
+      const int fs = jj & 1;
+      const bool first_of_group = (jj == 0 || jj == GA);
+      if (first_of_group)  // its image was published by the barrier just passed: these reads are not prefetched
+        fb_fxw_frags<NK>(slot0 + jj * IMG4, lane, f1[fs], f2[fs]);
+      if (jj < GA) dma(it0 + GA, GB, GA * IMG4, jj, PPS_A);
+      else dma(it0 + NI, GA, 0, jj - GA, PPS_B);
+      if (jj == 0) fb_fxw_pair<NK>(f1[fs], f2[fs], bq1, bq2, zero, zero, hq[0], hq[1]);
+      else fb_fxw_pair<NK>(f1[fs], f2[fs], bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1]);
+      // everything below is issued behind the queued MFMAs and runs in their shadow
+      if (jj + 1 < NI && jj + 1 != GA)
+        fb_fxw_frags<NK>(slot0 + (jj + 1) * IMG4, lane, f1[fs ^ 1], f2[fs ^ 1]);
+      if (jj == 0) {
+        if (t > 0) update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);  // last model of the previous tile
+      } else if (jj >= 2) {
+        update(acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], jj - 2);
+      }
+      if (jj == GA - 1 || jj == NI - 1) publish();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);
+
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float ms = st_m[(2 * m + hf) * 256 + tid];  // maximum of ll * 2^(kacc - sh)
+      const float mm = ms * unscale, ss = fb_lse_to_natural(ms, st_s[(2 * m + hf) * 256 + tid], ls);
+      const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
+      const float mx = fmaxf(mm, m2);
+      const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
+      if (h == 0 && rows[hf] < n_rows) {
+        const size_t o = ((size_t)chunk_i * M + m) * rows_cap + rows[hf];
+        part_m[o] = mx;
+        part_s[o] = sx;
+      }
+    }
+}
+
+template <int NK, int M>
+static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                             int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+  const int strips = (rows_cap + 255) / 256;
+  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  int xcd_map = 0;
+  static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
+  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
+    const int per = 8 / n_chunks;
+    grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
+    xcd_map = n_chunks;
+  }
+  const size_t ldsb = (size_t)(M + 1) * 2 * NK * 64 * 16 + (size_t)2 * M * 512 * sizeof(float);  // one tile + the state
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (ldsb > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gmm_fx2w<NK, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) == hipSuccess)
+      optin.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((k_gmm_fx2w<NK, M>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap, part_m, part_s,
+                     xcd_map);
+}
+// k_gmm_fx2w is instantiated for the shapes the reference's systems have with the recipe's 72-dimensional features
+// (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models (SV: UBM + 1; OSI: UBM +
+// speakers; CSI: the speakers).  Everything else runs on k_gmm_fx2.
+#define FB_FXW_MAX_M 6
+bool fb_gmm_use_wide(const FbGmmDev &g) {
+  static const bool off = getenv("FB_GMM_NARROW") != nullptr;
+  return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
+         g.M <= FB_FXW_MAX_M && g.item_model_host_q_first;
+}
+static void launch_gmm_fxw(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
+                           int n_chunks, int tpc, float *part_m, float *part_s) {
+  switch (g.M) {
+    case 2: launch_gmm_fxw_t<5, 2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 3: launch_gmm_fxw_t<5, 3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 4: launch_gmm_fxw_t<5, 4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 5: launch_gmm_fxw_t<5, 5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 6: launch_gmm_fxw_t<5, 6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    default: break;  // fb_gmm_use_wide() admits only the cases above
+  }
+}
+
 template <int NK, bool DUMP>
 static void launch_gmm_fx_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                             int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
@@ -783,6 +1071,7 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
                    int rows_cap, int n_chunks, float *part_m, float *part_s) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
+  if (fb_gmm_use_wide(g)) { launch_gmm_fxw(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   if (g.mode == FB_GMM_MODE_FX2) { launch_gmm_fx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
   switch (g.KH) {
