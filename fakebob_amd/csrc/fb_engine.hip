@@ -101,7 +101,11 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter, ctl, ctl_ls, trace_dev, enr_ll, enr_aux, enr_stats;
+  DevBuf frame_rec, vad_counter, vad_pub, fin_counter, ctl, ctl_ls, trace_dev, enr_ll, enr_aux, enr_stats;
+  long long pre_iter = -1;  // >= 0: wav / zbuf / dist_part already hold the NES batch of this iteration (k_update_perturb)
+  int pre_ndp = 0;
+  bool defer_finalize = false;  // run_scoring leaves the GMM finalisation to the fused finalize + loss launch
+  unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernel on vad_pub (its published counts carry the epoch)
   FbCtlDev *h_ctl = nullptr;  // pinned
   hipEvent_t evg_ring[2 * 16] = {};
   int evg_n = 0;
@@ -217,7 +221,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -729,6 +733,21 @@ static int run_post_mfcc(fb_engine *e, int B) {
     FBCHK(e->feat_mm.ensure(sizeof(float) * 2 * (size_t)B));
     fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->feat_mm.as<float>());
   }
+  {  // every utterance fits the CMVN window (all NES batches): VAD, deltas, CMVN and the row offsets in one launch
+    const size_t had = e->vad_pub.cap;
+    FBCHK(e->vad_pub.ensure(sizeof(unsigned long long) * (size_t)B));
+    if (e->vad_pub.cap != had || e->vad_epoch == 0xffffffffu) {  // fresh buffer, or the epoch counter is about to wrap
+      HIPCHK(hipMemsetAsync(e->vad_pub.p, 0, e->vad_pub.cap, s));
+      e->vad_epoch = 0;
+    }
+    static const bool unfused = getenv("FB_NO_FUSE") != nullptr;
+    if (!unfused && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
+                                             e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
+                                             e->row_off.as<int>(), e->feats.as<float>())) {
+      e->vad_epoch += 1;
+      return FB_OK;
+    }
+  }
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>(),
                 e->vad_counter.as<int>(), e->row_off.as<int>());
   if (fb_launch_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), e->vrank.as<int>(),
@@ -769,8 +788,9 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                   e->part_m.as<float>(), e->part_s.as<float>());
     FBCHK(time_end(e));
-    fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
-                           e->row_off.as<int>(), B, e->raw.as<double>());
+    if (!e->defer_finalize)
+      fb_launch_gmm_finalize(s, g, e->part_m.as<float>(), e->part_s.as<float>(), total_frames, n_chunks,
+                             e->row_off.as<int>(), B, e->raw.as<double>());
   } else {
     const FbIvDev &iv = e->iv;
     const int64_t Q = (int64_t)iv.C * iv.D;
@@ -1186,13 +1206,17 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
   FBCHK(e->grad.ensure(sizeof(double) * (size_t)N));
   FBCHK(e->scores.ensure(sizeof(double) * (size_t)B * (S > 0 ? S : 1)));
   FBCHK(e->loss.ensure(sizeof(double) * (size_t)B));
-  FBCHK(e->dist_part.ensure(sizeof(double) * (size_t)((N + 1023) / 1024 + 1)));
+  FBCHK(e->dist_part.ensure(sizeof(double) * (size_t)((N + 255) / 256 + 1)));  // k_perturb: one per 1024 samples, k_update_perturb: per 256
   FBCHK(e->nes_out.ensure(sizeof(FbNesDev)));
   FBCHK(e->zbuf.ensure(sizeof(float) * (size_t)N * (size_t)((B - 1) / 2 > 0 ? (B - 1) / 2 : 1)));
   return FB_OK;
 }
 
 // One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
+static bool fb_fuse_on() {
+  static const bool off = getenv("FB_NO_FUSE") != nullptr;  // FB_NO_FUSE=1: the 8-launch chain (A/B and debugging)
+  return !off;
+}
 static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
                             const double *noise_dev, bool with_dist, FbCtlDev *ctl = nullptr,
                             double *trace_dev = nullptr, int trace_row = 0) {
@@ -1201,13 +1225,35 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   const int *stop = ctl ? &ctl->stop : nullptr;
   e->fe.stop = stop;
   e->gmm.stop = stop;
-  fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
-                    p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
-                    e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>(), stop);
+  if (ctl && e->pre_iter == (long long)iter && !noise_dev) {
+    ndp = e->pre_ndp;  // the fused update of the previous iteration already wrote this batch
+  } else {
+    fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
+                      p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
+                      e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>(), stop);
+  }
+  e->pre_iter = -1;
+  // GMM systems inside the device-controlled loop: finalisation and loss share one launch
+  const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_on();
+  e->defer_finalize = fuse_fin;
   const int rc = run_scoring(e, B, e->h_frame_off[B]);
+  e->defer_finalize = false;
   e->fe.stop = nullptr;
   e->gmm.stop = nullptr;
   FBCHK(rc);
+  if (fuse_fin) {
+    if (!e->fin_counter.p) {
+      FBCHK(e->fin_counter.ensure(sizeof(int)));
+      HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+    }
+    fb_launch_gmm_finalize_loss(e->stream, e->gmm, e->part_m.as<float>(), e->part_s.as<float>(), e->last_total_frames,
+                                e->last_chunks, e->row_off.as<int>(), B, e->raw.as<double>(), e->fin_counter.as<int>(),
+                                e->tv.as<int>(), p->task, p->attack_type, e->zmean.as<double>(), e->zstd.as<double>(),
+                                p->threshold, p->adver_thresh, p->target, p->true_label, e->dist_part.as<double>(),
+                                with_dist ? ndp : 0, e->scores.as<double>(), e->loss.as<double>(),
+                                e->nes_out.as<FbNesDev>(), ctl, trace_dev, trace_row);
+    return FB_OK;
+  }
   fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->n_out, p->task, e->kind, p->attack_type,
                  e->zmean.as<double>(), e->zstd.as<double>(), p->threshold, p->adver_thresh, p->target,
                  p->true_label, e->dist_part.as<double>(), with_dist ? ndp : 0, e->scores.as<double>(),
@@ -1235,6 +1281,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
   FBCHK(e->ctl_ls.ensure(sizeof(double) * (size_t)(p->plateau_length > 0 ? p->plateau_length : 1)));
   FbCtlDev *ctl = e->ctl.as<FbCtlDev>();
   if (reset) {
+    e->pre_iter = -1;
     FbCtlDev h;
     memset(&h, 0, sizeof(h));
     h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;
@@ -1260,9 +1307,19 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
       FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base));
       FB_DBG_SYNC(e, "loss");
-      fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
-                            nullptr, 1, p->momentum, one_minus_m, 0.0, p->epsilon, e->audio.as<double>(),
-                            e->grad_m.as<double>(), e->adver.as<double>(), ctl);
+      if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on()) {
+        // momentum sign step of this iteration + the perturbed batch of the next one in a single launch
+        e->pre_ndp = fb_launch_update_perturb(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(),
+                                              p->momentum, one_minus_m, p->epsilon, e->audio.as<double>(),
+                                              e->grad_m.as<double>(), e->adver.as<double>(), ctl, p->seed,
+                                              (uint32_t)(it + 1), p->stream, e->wav.as<int16_t>(),
+                                              e->dist_part.as<double>());
+        e->pre_iter = (long long)it + 1;
+      } else {
+        fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
+                              nullptr, 1, p->momentum, one_minus_m, 0.0, p->epsilon, e->audio.as<double>(),
+                              e->grad_m.as<double>(), e->adver.as<double>(), ctl);
+      }
     }
     HIPCHK(hipMemcpyAsync(e->h_ctl, ctl, sizeof(FbCtlDev), hipMemcpyDeviceToHost, e->stream));
     FBCHK(sync_stream(e));

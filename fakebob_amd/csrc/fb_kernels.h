@@ -68,6 +68,13 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
                     double adver_thresh, int target, int true_label, const double *dist_part,
                     int n_dist_part, double *scores, double *loss, FbNesDev *out, FbCtlDev *ctl = nullptr,
                     double *trace = nullptr, int it = 0);
+// k_grad_update (iteration `next_iter - 1`) + k_perturb (iteration next_iter) in one launch; device-controlled attacks
+// with Philox noise and half <= FB_FUSE_MAX_HALF only.  Returns the number of distance partials written.
+#define FB_FUSE_MAX_HALF 40
+int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
+                             double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
+                             double *adver, const FbCtlDev *ctl, uint64_t seed, uint32_t next_iter, uint32_t stream,
+                             int16_t *q, double *dist_part);
 // grad estimate (numpy-pairwise order) + optional momentum/sign/clip update.
 // do_update: 0 = only grad_out; 1 = momentum+update with lr.
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
@@ -91,6 +98,10 @@ void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                    int *vrank, int *tv, int *counter, int *row_off);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
+// VAD + deltas + CMVN + voiced-row compaction of a batch whose utterances fit the CMVN window, one launch
+bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                              int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
+                              float *feats);
 bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
                           const int *vrank, const int *row_off, int B, int t_max, float *feats);
 // add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk
@@ -150,6 +161,13 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
 // single model (g.M == 1): ll[row][n_tiles*32] = every component log-likelihood (gmm-gselect input)
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                         int rows_cap, int n_chunks, float *ll);
+// k_gmm_finalize + k_loss fused (GMM systems in the NES loop): counter = one int, zero before the first launch
+void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
+                                 int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
+                                 const int *tv, int task, int attack_type, const double *z_mean, const double *z_std,
+                                 double threshold, double adver_thresh, int target, int true_label,
+                                 const double *dist_part, int n_dist_part, double *scores, double *loss, FbNesDev *out,
+                                 FbCtlDev *ctl, double *trace, int it);
 // enrolment statistics of a single model from its dump matrix ll[rows][ld]: occ[C], F[C][D] (float64)
 void fb_launch_gmm_post_stats(hipStream_t s, int C, int ld, int D, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, float *mx, float *inv_sum, double *occ,

@@ -1,0 +1,193 @@
+// fb_nes_device.h -- device code shared by the NES kernels (nes_kernels.hip) and the fused GMM finalisation
+// (gmm_kernels.hip): numpy-order summation and the loss / loop-control body of FakeBob.loss_fn + attack.
+#pragma once
+#include "fb_device.h"
+#include "fb_kernels.h"
+
+__device__ __forceinline__ double fb_ld_agent_f64(const double *p) {
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+
+// numpy pairwise summation over elem(i), i in [lo, lo+n)  (see oracle/fb_oracle.c
+// fbo_np_sum; verified bit-for-bit against numpy 2.2.6)
+struct D1 {
+  double v;
+  __device__ __forceinline__ static D1 zero() { return D1{0.0}; }
+  __device__ __forceinline__ D1 operator+(const D1 &o) const { return D1{__dadd_rn(v, o.v)}; }
+};
+struct D4 {
+  double v[4];
+  __device__ __forceinline__ static D4 zero() { return D4{{0.0, 0.0, 0.0, 0.0}}; }
+  __device__ __forceinline__ D4 operator+(const D4 &o) const {
+    return D4{{__dadd_rn(v[0], o.v[0]), __dadd_rn(v[1], o.v[1]), __dadd_rn(v[2], o.v[2]), __dadd_rn(v[3], o.v[3])}};
+  }
+};
+template <typename T, typename F>
+__device__ __forceinline__ T fb_np_sum_block(F elem, int lo, int n) {  // n <= 128
+  if (n < 8) {
+    T r = T::zero();
+    for (int i = 0; i < n; ++i) r = r + elem(lo + i);
+    return r;
+  }
+  T r0 = elem(lo + 0), r1 = elem(lo + 1), r2 = elem(lo + 2), r3 = elem(lo + 3);
+  T r4 = elem(lo + 4), r5 = elem(lo + 5), r6 = elem(lo + 6), r7 = elem(lo + 7);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 = r0 + elem(lo + i + 0); r1 = r1 + elem(lo + i + 1); r2 = r2 + elem(lo + i + 2);
+    r3 = r3 + elem(lo + i + 3); r4 = r4 + elem(lo + i + 4); r5 = r5 + elem(lo + i + 5);
+    r6 = r6 + elem(lo + i + 6); r7 = r7 + elem(lo + i + 7);
+  }
+  T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res = res + elem(lo + i);
+  return res;
+}
+// numpy recurses sum(lo,n) = sum(lo,n2) + sum(lo+n2,n-n2), n2 = n/2 - (n/2)%8, above 128
+// elements; an explicit post-order stack replaces the recursion (no device call stack).
+template <typename T, typename F>
+__device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
+  if (n <= 128) return fb_np_sum_block<T>(elem, lo, n);
+  int lo_s[14], n_s[14], st_s[14];
+  T left_s[14];
+  int sp = 0;
+  T ret = T::zero();
+  lo_s[0] = lo; n_s[0] = n; st_s[0] = 0;
+  while (sp >= 0) {
+    const int cn = n_s[sp], cl = lo_s[sp];
+    if (cn <= 128) {
+      ret = fb_np_sum_block<T>(elem, cl, cn);
+      --sp;
+    } else {
+      int n2 = cn / 2;
+      n2 -= n2 % 8;
+      if (st_s[sp] == 0) {
+        st_s[sp] = 1;
+        ++sp; lo_s[sp] = cl; n_s[sp] = n2; st_s[sp] = 0;
+      } else if (st_s[sp] == 1) {
+        left_s[sp] = ret;
+        st_s[sp] = 2;
+        ++sp; lo_s[sp] = cl + n2; n_s[sp] = cn - n2; st_s[sp] = 0;
+      } else {
+        ret = left_s[sp] + ret;
+        --sp;
+      }
+    }
+  }
+  return ret;
+}
+
+// SMALL: samples_per_draw <= 128 -- numpy's sum is a single block then and the kernel needs no
+// recursion stack (the stack lives in scratch memory, which also slows the dispatch down)
+// FUSED: the caller is the last workgroup of k_gmm_finalize_loss; raw[] was written by OTHER workgroups of the same
+// launch and is read with agent-scope loads.
+template <bool SMALL, bool FUSED>
+__device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, const int *__restrict__ tv,
+                                              int B, int M, int task, int znorm_all, int attack_type,
+                                              const double *__restrict__ z_mean,
+                                              const double *__restrict__ z_std, double threshold,
+                                              double adver_thresh, int target, int true_label,
+                                              const double *__restrict__ dist_part, int n_dist_part,
+                                              double *__restrict__ scores, double *__restrict__ loss,
+                                              FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
+                                              double *__restrict__ trace, int it) {
+  const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
+  __shared__ int s_err;
+  if (threadIdx.x == 0) s_err = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (tv && tv[b] <= 0) atomicMax(&s_err, b + 1);
+    auto r = [&](int m) -> double { return FUSED ? fb_ld_agent_f64(raw + (size_t)b * M + m) : raw[(size_t)b * M + m]; };
+    double *sc = scores + (size_t)b * S;
+    if (task == FB_TASK_CSI || znorm_all) {
+      // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
+      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r(m), z_mean[m]), z_std[m]);
+    } else {
+      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r(1 + m), r(0));  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
+    }
+    double l;
+    if (task == FB_TASK_SV) {
+      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
+    } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
+      double mx = -INFINITY;
+      for (int m = 0; m < S; ++m) mx = sc[m] > mx ? sc[m] : mx;
+      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), mx);  // :269
+    } else if (task == FB_TASK_OSI) {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+      double mx = om > threshold ? om : threshold;
+      l = __dsub_rn(__dadd_rn(mx, adver_thresh), sc[target]);  // :262
+    } else if (attack_type == FB_TARGETED) {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+      l = __dsub_rn(__dadd_rn(om, adver_thresh), sc[target]);  // :281
+    } else {
+      double om = -INFINITY;
+      for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
+      l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
+    }
+    loss[b] = l;
+  }
+  // max |audio - adver| over the perturb kernel's per-workgroup partials (order-independent: every thread takes a
+  // strided share instead of thread 0 walking up to N / 256 entries alone)
+  __shared__ double s_dmax[4];
+  {
+    double dm = 0.0;
+    for (int i = threadIdx.x; i < n_dist_part; i += blockDim.x) { const double v = dist_part[i]; dm = v > dm ? v : dm; }
+    dm = fb_wave_max(dm);
+    if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int spd = B - 1;
+    out->adver_loss = loss[0];
+    auto el = [&](int i) { return D1{loss[1 + i]}; };
+    const double lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    // np.mean :243 -- of an empty slice when samples_per_draw < 2: NaN, like NumPy
+    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
+    for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
+    double d = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
+    out->distance = d;
+    out->err = s_err;
+    if (ctl) {
+      double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
+      const double al = loss[0];
+      if (s_err) {
+        ctl->err = s_err;
+        ctl->stop = 1;
+      } else {
+        if (al < 0.0 && !ctl->disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
+          ctl->stop = 1;
+          ctl->broke = 1;
+          ctl->stop_iter = it;
+        } else {  // :195-200
+          const int PL = ctl->plateau_length;
+          if (PL > 0) {
+            int n = ctl->n_ls;
+            if (n < PL) {
+              ctl->ls[n++] = out->final_loss;
+            } else {
+              for (int i = 1; i < PL; ++i) ctl->ls[i - 1] = ctl->ls[i];
+              ctl->ls[PL - 1] = out->final_loss;
+            }
+            if (n == PL && ctl->ls[PL - 1] > ctl->ls[0]) {
+              if (ctl->lr > ctl->min_lr) {
+                const double l2 = __ddiv_rn(ctl->lr, ctl->plateau_drop);
+                ctl->lr = l2 > ctl->min_lr ? l2 : ctl->min_lr;
+              }
+              n = 0;
+            }
+            ctl->n_ls = n;
+          }
+        }
+        if (row) {
+          row[0] = d; row[1] = al; row[2] = ctl->lr;
+          for (int m = 0; m < S; ++m) row[3 + m] = scores[m];
+        }
+        ctl->iters_done = it + 1;
+      }
+    }
+  }
+}
+

@@ -1194,6 +1194,198 @@ __global__ __launch_bounds__(1024) void k_delta_cmvn(FbFrontendDev fe, const flo
     }
   }
 }
+// compute-vad-decision | add-deltas | apply-cmvn-sliding | select-voiced-frames in ONE launch (every NES batch).
+// k_delta_cmvn with the VAD of k_vad in front -- the MFCCs of the utterance are in LDS anyway -- and the row offsets
+// of the compacted feature matrix obtained without a scan kernel:
+//   * workgroups take their utterance index from a ticket counter, so every utterance with a smaller index has
+//     already been started by a running workgroup (no assumption about dispatch order);
+//   * a workgroup publishes its voiced-frame count as (launch epoch << 32 | count) with an agent-scope release store
+//     as soon as the VAD is done, computes deltas and CMVN sums, and only then -- usually without waiting -- reads the
+//     counts of the utterances before it (acquire loads, spinning on a stale epoch) and adds them up;
+//   * the workgroup that takes the last ticket resets the ticket counter; the one that holds utterance B - 1 also
+//     writes the total (row_off[B], what the GMM kernel reads as its row count).
+// Arithmetic, summation orders and results are those of k_vad + k_delta_cmvn, bit for bit.
+template <int ORDER, int WIN>
+__global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const float *__restrict__ mfcc,
+                                                         const int *__restrict__ frame_off, int B, int t_cap,
+                                                         unsigned epoch, int *__restrict__ ticket,
+                                                         unsigned long long *__restrict__ pub, int *__restrict__ tv,
+                                                         int *__restrict__ row_off, float *__restrict__ feats) {
+  if (fe.stop && *fe.stop) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  __shared__ int s_b, s_run, s_wtot[16], s_rbase;
+  __shared__ float s_thr;
+  const int nc = fe.nc, dim = fe.dim, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    const int tk = atomicAdd(ticket, 1);
+    if (tk == B - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else will draw
+    s_b = tk;
+    s_run = 0;
+  }
+  __syncthreads();
+  const int b = s_b;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const int order = ORDER > 0 ? ORDER : fe.order, dwin = ORDER > 0 ? WIN : fe.dwin;
+  const int maxlen = 2 * order * dwin + 1;
+  double *s_sum = s_dyn;                                        // [dim]
+  double *s_sc = s_sum + dim;                                   // [(order+1)][maxlen]
+  const int ctx = order * dwin;
+  float *s_mf = reinterpret_cast<float *>(s_sc + (order + 1) * maxlen);  // [ctx + T + ctx][nc], edges replicated
+  float *s_df = s_mf + (size_t)(t_cap + 2 * ctx) * nc;          // [T][dim]
+  int *s_vr = reinterpret_cast<int *>(s_df + (size_t)t_cap * dim);  // [T]
+  double *s_red = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(s_vr + t_cap) + 7) & ~(uintptr_t)7);  // [256]
+  for (int i = tid; i < (order + 1) * maxlen; i += 1024) s_sc[i] = fe.dscale[i];
+  {  // MFCCs of the utterance: issue every load of this thread before the first LDS store
+    constexpr int NL = 8;
+    const float *src = mfcc + (size_t)base * nc;
+    const int n = T * nc;
+    for (int i0 = tid; i0 < n; i0 += 1024 * NL) {
+      float v[NL];
+#pragma unroll
+      for (int u = 0; u < NL; ++u) v[u] = src[min(i0 + 1024 * u, n - 1)];
+#pragma unroll
+      for (int u = 0; u < NL; ++u) if (i0 + 1024 * u < n) s_mf[ctx * nc + i0 + 1024 * u] = v[u];
+    }
+    for (int i = tid; i < ctx * nc; i += 1024) {  // Kaldi clamps the frame index at both ends
+      const int d = i % nc;
+      s_mf[i] = src[d];
+      s_mf[(ctx + T) * nc + i] = src[(size_t)(T - 1) * nc + d];
+    }
+  }
+  __syncthreads();
+  // ---- VAD on the C0 column (k_vad's arithmetic: 256 strided float64 partial sums, binary tree; +-vad_ctx vote)
+  const float *c0 = s_mf + ctx * nc;  // c0[t * nc]
+  if (tid < 256) {
+    double part = 0.0;
+    for (int t = tid; t < T; t += 256) part += (double)c0[(size_t)t * nc];
+    s_red[tid] = part;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] += s_red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) s_thr = (float)(fe.vad_thr + fe.vad_mean_scale * s_red[0] / (double)T);
+  __syncthreads();
+  const float thr = s_thr;
+  for (int t0 = 0; t0 < T; t0 += 1024) {
+    const int t = t0 + tid;
+    int v = 0;
+    if (t < T) {
+      int num = 0, den = 0;
+      for (int t2 = t - fe.vad_ctx; t2 <= t + fe.vad_ctx; ++t2)
+        if (t2 >= 0 && t2 < T) { ++den; if (c0[(size_t)t2 * nc] > thr) ++num; }
+      v = ((float)num >= (float)den * fe.vad_prop) ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(v);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wtot[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < w; ++i) woff += s_wtot[i];
+    if (t < T) s_vr[t] = v ? (s_run + woff + pre) : -1;
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int i = 0; i < 16; ++i) a += s_wtot[i]; s_run += a; }
+    __syncthreads();
+  }
+  const int n_voiced = s_run;
+  if (tid == 0) {
+    tv[b] = n_voiced;
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
+  if constexpr (ORDER > 0) {
+#pragma unroll
+    for (int i = 0; i <= ORDER; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * ORDER * WIN + 1; ++j) creg[i][j] = s_sc[i * (2 * ORDER * WIN + 1) + j];
+  }
+  // ---- add-deltas: half-wave = frame, lane = coefficient (no divisions); float64 taps in order
+  for (int d0 = 0; d0 < nc; d0 += 32) {
+    const int d = d0 + (lane & 31);
+    for (int t = 2 * w + (lane >> 5); t < T; t += 32) {
+      if (d < nc) {
+        if constexpr (ORDER > 0) {
+#pragma unroll
+          for (int i = 0; i <= ORDER; ++i) {
+            constexpr int ML = 2 * ORDER * WIN + 1;
+            const int off = i * WIN;
+            float x[ML];
+            const float *row = s_mf + (t + ctx - off) * nc + d;
+#pragma unroll
+            for (int j = 0; j < ML; ++j)
+              if (j <= 2 * off) x[j] = row[j * nc];
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < ML; ++j)
+              if (j <= 2 * off) acc = __dadd_rn(acc, __dmul_rn(creg[i][j], (double)x[j]));
+            s_df[t * dim + i * nc + d] = (float)acc;
+          }
+        } else {
+          for (int i = 0; i <= order; ++i) {
+            const double *sc = s_sc + i * maxlen;
+            const int off = i * dwin;
+            double acc = 0.0;
+            for (int j = 0; j <= 2 * off; ++j)
+              acc = __dadd_rn(acc, __dmul_rn(sc[j], (double)s_mf[(t + ctx - off + j) * nc + d]));
+            s_df[t * dim + i * nc + d] = (float)acc;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < dim) {  // frames in order; the loads of 8 frames are issued before their (dependent) adds
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)x[u];
+    }
+    for (; t < T; ++t) acc += (double)s_df[t * dim + tid];
+    s_sum[tid] = acc;
+  }
+  // ---- row offset: voiced counts of the utterances before this one (published above by their workgroups)
+  {
+    int mine = 0;
+    for (int i = tid; i < b; i += 1024) {
+      unsigned long long v;
+      do {
+        v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((unsigned)(v >> 32) != epoch);
+      const int c = (int)(unsigned)v;
+      mine += c > 0 ? c : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) s_wtot[w] = mine;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int i = 0; i < 16; ++i) a += s_wtot[i];
+    s_rbase = a;
+    row_off[b] = a;
+    if (b == B - 1) row_off[B] = a + (n_voiced > 0 ? n_voiced : 0);
+  }
+  __syncthreads();
+  // ---- CMVN + voiced-row compaction: wave = frame, lane = dimension
+  const int rbase = s_rbase;
+  const double alpha = (double)(float)(-1.0 / (double)T);
+  for (int d = lane; d < dim; d += 64) {
+    const double shift = __dmul_rn(alpha, s_sum[d]);
+#pragma unroll 4
+    for (int t = w; t < T; t += 16) {
+      const int r = s_vr[t];
+      if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[t * dim + d], shift);
+    }
+  }
+}
 size_t fb_delta_cmvn_lds_bytes(const FbFrontendDev &fe, int t_cap) {
   const int maxlen = 2 * fe.order * fe.dwin + 1;
   return sizeof(double) * (size_t)(fe.dim + (fe.order + 1) * maxlen) +
@@ -1223,6 +1415,34 @@ bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *m
     hipLaunchKernelGGL((k_delta_cmvn<2, 2>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);
   else
     hipLaunchKernelGGL((k_delta_cmvn<-1, 0>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, vrank, row_off, t_max, feats);
+  return true;
+}
+
+// returns false when the batch does not qualify (as fb_launch_delta_cmvn): the caller then runs fb_launch_vad and
+// the separate delta / CMVN kernels.  ticket: one int, zero before the first launch; pub: B x 8 bytes; epoch: a
+// number no earlier launch on these buffers used (the engine counts launches).
+bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                              int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
+                              float *feats) {
+  if (B <= 0) return true;
+  if (t_max > fe.cmn_window) return false;
+  const size_t shm = fb_delta_cmvn_lds_bytes(fe, t_max) + 16 + sizeof(double) * 256;
+  if (shm > 150 * 1024) return false;
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (fb_device_needs_optin(optin, &bit)) {
+    const void *fns[] = {reinterpret_cast<const void *>(k_vad_delta_cmvn<2, 3>), reinterpret_cast<const void *>(k_vad_delta_cmvn<2, 2>),
+                         reinterpret_cast<const void *>(k_vad_delta_cmvn<-1, 0>)};
+    for (const void *fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;
+    optin.fetch_or(bit, std::memory_order_release);
+  }
+  if (fe.order == 2 && fe.dwin == 3)
+    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 3>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
+  else if (fe.order == 2 && fe.dwin == 2)
+    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 2>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
+  else
+    hipLaunchKernelGGL((k_vad_delta_cmvn<-1, 0>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
   return true;
 }
 

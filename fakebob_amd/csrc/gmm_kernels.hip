@@ -29,6 +29,7 @@
 #include "fb_device.h"
 #include <cstdlib>
 #include "fb_kernels.h"
+#include "fb_nes_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1116,6 +1117,77 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
     if (g.text_scores && tv > 0) avg = fb_round6(avg);
     raw[(size_t)b * g.M + m] = avg;
   }
+}
+
+// k_gmm_finalize + k_loss in one launch (GMM systems inside the NES loop): every workgroup finishes one (utterance,
+// model) average as k_gmm_finalize does; the workgroup that finishes last (device counter, left at zero) then runs the
+// loss / loop-control body on the complete raw matrix.  Same arithmetic and orders as the two kernels.
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
+                                                           const float *__restrict__ part_s, int rows_cap,
+                                                           int n_chunks, const int *__restrict__ row_off, int B,
+                                                           double *__restrict__ raw, int *__restrict__ counter,
+                                                           const int *__restrict__ tv, int task, int attack_type,
+                                                           const double *__restrict__ z_mean,
+                                                           const double *__restrict__ z_std, double threshold,
+                                                           double adver_thresh, int target, int true_label,
+                                                           const double *__restrict__ dist_part, int n_dist_part,
+                                                           double *__restrict__ scores, double *__restrict__ loss,
+                                                           FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
+                                                           double *__restrict__ trace, int it) {
+  if (ctl && ctl->stop) return;  // queued behind the stopping iteration
+  const int b = blockIdx.x, m = blockIdx.y;
+  const int r0 = row_off[b], r1 = row_off[b + 1];
+  __shared__ double red[256];
+  __shared__ int s_last;
+  double acc = 0.0;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    float mx = FB_GMM_NEG;
+    for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
+    double ssum = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+      const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
+      ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+    }
+    const float ll = (float)((double)mx + log(ssum));
+    acc += (double)ll;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int tvb = r1 - r0;
+    double avg = tvb > 0 ? red[0] / (double)tvb : __longlong_as_double(0x7ff8000000000000ll);
+    if (g.text_scores && tvb > 0) avg = fb_round6(avg);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(raw + (size_t)b * g.M + m),
+                       (unsigned long long)__double_as_longlong(avg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = (atomicAdd(counter, 1) == (int)(gridDim.x * gridDim.y) - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
+}
+void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
+                                 int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
+                                 const int *tv, int task, int attack_type, const double *z_mean, const double *z_std,
+                                 double threshold, double adver_thresh, int target, int true_label,
+                                 const double *dist_part, int n_dist_part, double *scores, double *loss, FbNesDev *out,
+                                 FbCtlDev *ctl, double *trace, int it) {
+  if (B - 1 <= 128)
+    hipLaunchKernelGGL(k_gmm_finalize_loss<true>, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
+                       row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                       true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
+  else
+    hipLaunchKernelGGL(k_gmm_finalize_loss<false>, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
+                       row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                       true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
 }
 
 void fb_launch_gmm_finalize(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,

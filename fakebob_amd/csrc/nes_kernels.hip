@@ -6,6 +6,7 @@
 // mul/add so the results are bit-identical to NumPy's (no FMA contraction).
 #include "fb_device.h"
 #include "fb_kernels.h"
+#include "fb_nes_device.h"
 
 // ------------------------------------------------------------------ perturb
 // grid.x over n4 blocks (4 samples per thread), grid.y over antithetic pairs.
@@ -183,73 +184,7 @@ void fb_launch_noise(hipStream_t s, uint64_t seed, uint32_t iter, uint32_t strea
 }
 
 // --------------------------------------------------------------------- loss
-// numpy pairwise summation over elem(i), i in [lo, lo+n)  (see oracle/fb_oracle.c
-// fbo_np_sum; verified bit-for-bit against numpy 2.2.6)
-struct D1 {
-  double v;
-  __device__ __forceinline__ static D1 zero() { return D1{0.0}; }
-  __device__ __forceinline__ D1 operator+(const D1 &o) const { return D1{__dadd_rn(v, o.v)}; }
-};
-struct D4 {
-  double v[4];
-  __device__ __forceinline__ static D4 zero() { return D4{{0.0, 0.0, 0.0, 0.0}}; }
-  __device__ __forceinline__ D4 operator+(const D4 &o) const {
-    return D4{{__dadd_rn(v[0], o.v[0]), __dadd_rn(v[1], o.v[1]), __dadd_rn(v[2], o.v[2]), __dadd_rn(v[3], o.v[3])}};
-  }
-};
-template <typename T, typename F>
-__device__ __forceinline__ T fb_np_sum_block(F elem, int lo, int n) {  // n <= 128
-  if (n < 8) {
-    T r = T::zero();
-    for (int i = 0; i < n; ++i) r = r + elem(lo + i);
-    return r;
-  }
-  T r0 = elem(lo + 0), r1 = elem(lo + 1), r2 = elem(lo + 2), r3 = elem(lo + 3);
-  T r4 = elem(lo + 4), r5 = elem(lo + 5), r6 = elem(lo + 6), r7 = elem(lo + 7);
-  int i = 8;
-  for (; i < n - (n % 8); i += 8) {
-    r0 = r0 + elem(lo + i + 0); r1 = r1 + elem(lo + i + 1); r2 = r2 + elem(lo + i + 2);
-    r3 = r3 + elem(lo + i + 3); r4 = r4 + elem(lo + i + 4); r5 = r5 + elem(lo + i + 5);
-    r6 = r6 + elem(lo + i + 6); r7 = r7 + elem(lo + i + 7);
-  }
-  T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-  for (; i < n; ++i) res = res + elem(lo + i);
-  return res;
-}
-// numpy recurses sum(lo,n) = sum(lo,n2) + sum(lo+n2,n-n2), n2 = n/2 - (n/2)%8, above 128
-// elements; an explicit post-order stack replaces the recursion (no device call stack).
-template <typename T, typename F>
-__device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
-  if (n <= 128) return fb_np_sum_block<T>(elem, lo, n);
-  int lo_s[14], n_s[14], st_s[14];
-  T left_s[14];
-  int sp = 0;
-  T ret = T::zero();
-  lo_s[0] = lo; n_s[0] = n; st_s[0] = 0;
-  while (sp >= 0) {
-    const int cn = n_s[sp], cl = lo_s[sp];
-    if (cn <= 128) {
-      ret = fb_np_sum_block<T>(elem, cl, cn);
-      --sp;
-    } else {
-      int n2 = cn / 2;
-      n2 -= n2 % 8;
-      if (st_s[sp] == 0) {
-        st_s[sp] = 1;
-        ++sp; lo_s[sp] = cl; n_s[sp] = n2; st_s[sp] = 0;
-      } else if (st_s[sp] == 1) {
-        left_s[sp] = ret;
-        st_s[sp] = 2;
-        ++sp; lo_s[sp] = cl + n2; n_s[sp] = cn - n2; st_s[sp] = 0;
-      } else {
-        ret = left_s[sp] + ret;
-        --sp;
-      }
-    }
-  }
-  return ret;
-}
-
+// (numpy-order sums and the loss body: fb_nes_device.h, shared with k_gmm_finalize_loss)
 // SMALL: samples_per_draw <= 128 -- numpy's sum is a single block then and the kernel needs no
 // recursion stack (the stack lives in scratch memory, which also slows the dispatch down)
 template <bool SMALL>
@@ -263,95 +198,8 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                               double *__restrict__ trace, int it) {
   if (ctl && ctl->stop) return;  // queued behind the stopping iteration
-  const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
-  __shared__ int s_err;
-  if (threadIdx.x == 0) s_err = 0;
-  __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    if (tv && tv[b] <= 0) atomicMax(&s_err, b + 1);
-    const double *r = raw + (size_t)b * M;
-    double *sc = scores + (size_t)b * S;
-    if (task == FB_TASK_CSI || znorm_all) {
-      // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
-      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r[m], z_mean[m]), z_std[m]);
-    } else {
-      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r[1 + m], r[0]);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
-    }
-    double l;
-    if (task == FB_TASK_SV) {
-      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
-    } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
-      double mx = -INFINITY;
-      for (int m = 0; m < S; ++m) mx = sc[m] > mx ? sc[m] : mx;
-      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), mx);  // :269
-    } else if (task == FB_TASK_OSI) {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
-      double mx = om > threshold ? om : threshold;
-      l = __dsub_rn(__dadd_rn(mx, adver_thresh), sc[target]);  // :262
-    } else if (attack_type == FB_TARGETED) {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
-      l = __dsub_rn(__dadd_rn(om, adver_thresh), sc[target]);  // :281
-    } else {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
-      l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
-    }
-    loss[b] = l;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int spd = B - 1;
-    out->adver_loss = loss[0];
-    auto el = [&](int i) { return D1{loss[1 + i]}; };
-    const double lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
-    // np.mean :243 -- of an empty slice when samples_per_draw < 2: NaN, like NumPy
-    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
-    for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
-    double d = 0.0;
-    for (int i = 0; i < n_dist_part; ++i) d = dist_part[i] > d ? dist_part[i] : d;
-    out->distance = d;
-    out->err = s_err;
-    if (ctl) {
-      double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
-      const double al = loss[0];
-      if (s_err) {
-        ctl->err = s_err;
-        ctl->stop = 1;
-      } else {
-        if (al < 0.0 && !ctl->disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
-          ctl->stop = 1;
-          ctl->broke = 1;
-          ctl->stop_iter = it;
-        } else {  // :195-200
-          const int PL = ctl->plateau_length;
-          if (PL > 0) {
-            int n = ctl->n_ls;
-            if (n < PL) {
-              ctl->ls[n++] = out->final_loss;
-            } else {
-              for (int i = 1; i < PL; ++i) ctl->ls[i - 1] = ctl->ls[i];
-              ctl->ls[PL - 1] = out->final_loss;
-            }
-            if (n == PL && ctl->ls[PL - 1] > ctl->ls[0]) {
-              if (ctl->lr > ctl->min_lr) {
-                const double l2 = __ddiv_rn(ctl->lr, ctl->plateau_drop);
-                ctl->lr = l2 > ctl->min_lr ? l2 : ctl->min_lr;
-              }
-              n = 0;
-            }
-            ctl->n_ls = n;
-          }
-        }
-        if (row) {
-          row[0] = d; row[1] = al; row[2] = ctl->lr;
-          for (int m = 0; m < S; ++m) row[3 + m] = scores[m];
-        }
-        ctl->iters_done = it + 1;
-      }
-    }
-  }
+  fb_loss_body<SMALL, false>(raw, tv, B, M, task, znorm_all, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                             true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
 }
 
 void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,
@@ -426,6 +274,120 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
     a = a > hi ? hi : a;
     adver[n] = a;
   }
+}
+
+// k_grad_update (momentum sign step of iteration `iter`) + k_perturb (the batch of iteration iter + 1) in one launch:
+// a workgroup owns 256 consecutive samples.  Phase 1 is k_grad_update for them (normals of iteration `iter` from
+// zbuf, products summed in NumPy's pairwise order); the updated samples stay in LDS.  Phase 2 is k_perturb for the
+// same samples: the block's 64 x half (sample quad, antithetic pair) items are dealt over its threads, each draws its
+// Philox normals for iteration iter + 1, overwrites its zbuf entries (read in phase 1 by this block only) and writes
+// the two int16 columns; thread = sample writes the clean column and the distance partial.  Same arithmetic as the
+// two kernels, so trajectories are bit-identical.  Device-controlled attacks only (lr / stop from the control block).
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_update_perturb(const double *__restrict__ loss, int64_t N, int half,
+                                                        double sigma, float *__restrict__ zbuf, double momentum,
+                                                        double one_minus_m, double epsilon,
+                                                        const double *__restrict__ audio, double *__restrict__ grad_m,
+                                                        double *__restrict__ adver, const FbCtlDev *__restrict__ ctl,
+                                                        uint64_t seed, uint32_t next_iter, uint32_t stream,
+                                                        int16_t *__restrict__ q, double *__restrict__ dist_part) {
+  if (ctl->stop) return;
+  const double lr = ctl->lr;
+  extern __shared__ double s_loss[];  // loss[1..spd], the block's updated samples [256], the block's normals [half][256]
+  const int spd = 2 * half;
+  double *s_a = s_loss + spd;
+  float *s_z = reinterpret_cast<float *>(s_a + 256);
+  for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  {
+    const int64_t nc = n < N ? n : N - 1;
+    for (int j = 0; j < half; ++j) s_z[j * 256 + threadIdx.x] = zbuf[(int64_t)j * N + nc];
+  }
+  __syncthreads();
+  double dmax = 0.0;
+  if (n < N) {
+    auto el = [&](int i) -> D1 {
+      const int j = i < half ? i : i - half;
+      double z = (double)s_z[j * 256 + threadIdx.x];
+      if (i >= half) z = -z;
+      return D1{__dmul_rn(s_loss[i], z)};
+    };
+    double g = __longlong_as_double(0x7ff8000000000000ll);
+    if (spd > 0) {
+      const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+      g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
+    }
+    double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
+    grad_m[n] = gm;
+    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
+    double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
+    const double au = audio[n];
+    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
+    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
+    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
+    a = a < lo ? lo : a;
+    a = a > hi ? hi : a;
+    adver[n] = a;
+    s_a[threadIdx.x] = a;
+    q[n] = fb_quantize(a, 32768.0);  // column 0 of the next batch: the clean adver
+    const double d = fabs(__dsub_rn(au, a));
+    dmax = d;
+  } else {
+    s_a[threadIdx.x] = 0.0;
+  }
+  {  // distance partial of the NEXT iteration's trace row (max |audio - adver|, as k_perturb reports it)
+    __shared__ double red[4];
+    double m = fb_wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();  // also: s_a complete
+    if (threadIdx.x == 0) {
+      double r = red[0];
+      for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
+      dist_part[blockIdx.x] = r;
+    }
+  }
+  // ---- phase 2: the perturbed columns of iteration next_iter for this block's samples
+  const int64_t n4_0 = (int64_t)blockIdx.x * 64;  // first sample quad of the block
+  for (int idx = threadIdx.x; idx < 64 * half; idx += 256) {
+    const int n4l = idx & 63, j = idx >> 6;
+    const int64_t n0 = (n4_0 + n4l) * 4;
+    if (n0 >= N) continue;
+    const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
+    float zf[4];
+    fb_noise4(seed, next_iter, stream, (uint32_t)(n4_0 + n4l), (uint32_t)j, zf);
+    float *zp = zbuf + (int64_t)j * N + n0;
+    int16_t *qp = q + (int64_t)(1 + j) * N + n0;
+    int16_t *qm = q + (int64_t)(1 + half + j) * N + n0;
+    int16_t vp[4], vm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double a = s_a[4 * n4l + k], z = (double)zf[k];
+      vp[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, z), a), 32768.0);   // noise_audios = sigma * noise + audio (:237)
+      vm[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, -z), a), 32768.0);
+    }
+    if (cnt == 4 && ((N & 3) == 0)) {
+      *reinterpret_cast<float4 *>(zp) = make_float4(zf[0], zf[1], zf[2], zf[3]);
+      *reinterpret_cast<short4 *>(qp) = make_short4(vp[0], vp[1], vp[2], vp[3]);
+      *reinterpret_cast<short4 *>(qm) = make_short4(vm[0], vm[1], vm[2], vm[3]);
+    } else {
+      for (int k = 0; k < cnt; ++k) { zp[k] = zf[k]; qp[k] = vp[k]; qm[k] = vm[k]; }
+    }
+  }
+}
+// returns the number of distance partials the launch writes (one per workgroup)
+int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
+                             double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
+                             double *adver, const FbCtlDev *ctl, uint64_t seed, uint32_t next_iter, uint32_t stream,
+                             int16_t *q, double *dist_part) {
+  const int blocks = (int)((N + 255) / 256);
+  const size_t shm = sizeof(double) * (size_t)(2 * half + 256) + sizeof(float) * 256 * (size_t)(half > 0 ? half : 1);
+  if (2 * half <= 128)
+    hipLaunchKernelGGL(k_update_perturb<true>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, momentum,
+                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
+  else
+    hipLaunchKernelGGL(k_update_perturb<false>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, momentum,
+                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
+  return blocks;
 }
 
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,
