@@ -34,7 +34,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 S_SPK, C_GAUSS, D_FEAT, SPD, N_SAMPLES = 5, 2048, 72, 50, 48000
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (32x32x16)
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0
@@ -310,8 +309,8 @@ def bench_ivector(args, torch):
 
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
-GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2<5, false>", "bx3": "k_gmm_bx3<5, false>", "f32": "k_gmm<36, false>"}[GMM_MODE]
-TRAFFIC_FILE = "r01_traffic.json"
+GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
+TRAFFIC_FILE = "r02_traffic.json"
 # bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip): the clock drops to ~1.6 GHz
 # under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
 MFMA16_POWER_LIMITED_TFLOPS = 1660.0
@@ -320,8 +319,8 @@ MFMA16_POWER_LIMITED_TFLOPS = 1660.0
 def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows):
     """Roofline of the dominant kernel.  `achieved` = ALGORITHMIC flops ((S+1)*C*4D per voiced frame,
     two length-D dot products per component per model as Kaldi evaluates them) / average launch duration;
-    `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16/bf16: 2.5 PF; the plain-f32 kernel:
-    157.3 TF), so `frac` is a true fraction.  `executed_*`: the products the kernel really issues -- (1+M)/(2M) of
+    `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16 / bf16: 2.5 PF), so `frac` is a true
+    fraction.  `executed_*`: the products the kernel really issues -- (1+M)/(2M) of
     the algorithmic ones because the quadratic term is shared by the 6 models, times 3 (fx2) / 6 (bx3) partial
     products per f32 product, times the K padding."""
     M = S_SPK + 1
@@ -331,22 +330,19 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows):
     if GMM_MODE == "fx2":
         nk = (D_FEAT + 1 + 15) // 16
         ex, pipe, peak = flops_launch * shared * 3 * (16.0 * nk / D_FEAT), "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
-        name = ("k_gmm_fx2<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split accurate "
-                "to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, f32 accumulate)")
-    elif GMM_MODE == "bx3":
+        name = ("k_gmm_fx2w<5,6> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split accurate "
+                "to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, f32 accumulate; one wave per SIMD, "
+                "64 frames per wave, software-pipelined)")
+    else:
         nk = (D_FEAT + 3 + 15) // 16
         ex, pipe, peak = flops_launch * shared * 6 * (16.0 * nk / D_FEAT), "bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_F16_MFMA_TFLOPS
         name = ("k_gmm_bx3<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as an exact 3-way bf16 split, "
                 "6 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")
-    else:
-        ex, pipe, peak = flops_launch * shared, "f32 MFMA (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS
-        name = "k_gmm<36,false> (diag-GMM log-likelihood + logsumexp, f32 MFMA 32x32x2)"
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": None, "avg_launch_ms": gmm_ms_avg, "algorithmic_flops_per_launch": flops_launch,
          "kernel": name, "peak_pipe": pipe,
          "executed_flops_per_launch": ex, "executed_tflops": ex * per_s, "executed_frac": ex * per_s / peak}
-    if peak == PEAK_F16_MFMA_TFLOPS:
-        r["executed_frac_of_power_limited_ceiling"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS
+    r["executed_frac_of_power_limited_ceiling"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS
     if solo_ms and solo_ms > 0:
         fl_solo = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows
         r["solo_launch_ms"] = solo_ms
@@ -446,8 +442,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; f64 front-end/NES)",
-                      "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)",
-                      "f32": "f32 (MFMA f32 GMM; f64 front-end/NES)"}[GMM_MODE],
+                      "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)"}[GMM_MODE],
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS,

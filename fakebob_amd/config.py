@@ -52,8 +52,13 @@ def frontend_overrides(mfcc_conf="", vad_conf="", delta_opts=""):
             o[f] = conv(m[k])
     if "window-type" in m and m["window-type"] != "povey":
         raise ValueError("window-type=%s unsupported (povey only)" % m["window-type"])
-    if float(m.get("dither", 0.0)) != 0.0:
-        warnings.warn("Kaldi dither=%s is random and not reproducible; the engine always uses dither=0" % m["dither"])
+    # Kaldi's default is --dither=1.0 and the stock voxceleb mfcc.conf does not override it: a real Kaldi run adds
+    # random noise of one LSB to every sample before the MFCC, which no re-implementation can reproduce
+    dither = float(m.get("dither", 1.0))
+    if dither != 0.0:
+        warnings.warn("Kaldi would run with dither=%g (%s): its features are random at the 1-LSB level; the engine "
+                      "always uses dither=0, so scores differ from a Kaldi run by that noise"
+                      % (dither, "set in mfcc.conf" if "dither" in m else "Kaldi's default, mfcc.conf does not set it"))
     v = _parse_opts(vad_conf)
     for k, f, conv in [("vad-energy-threshold", "vad_energy_threshold", float),
                        ("vad-energy-mean-scale", "vad_energy_mean_scale", float),

@@ -85,7 +85,7 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_images, gmm_items, gmm_images_bx, gmm_images_fx;
+  DevBuf gmm_items, gmm_images_bx, gmm_images_fx;
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
@@ -220,7 +220,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_images, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
@@ -390,10 +390,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   if (M > 60) return fb_fail(FB_E_ARG, "at most 60 models per engine (got %d)", M);
   if (!e->have_fe || e->fe.dim != D)
     return fb_fail(FB_E_ARG, "GMM dim %d != front-end feature dim %d", D, e->have_fe ? e->fe.dim : -1);
-  static const int khs[] = {20, 32, 36, 40};
-  int KH = -1;
-  for (int k : khs) if (2 * k >= D) { KH = k; break; }
-  if (KH < 0) return fb_fail(FB_E_ARG, "feature dim %d > 80 unsupported by the MFMA kernel", D);
+  if (D > 80) return fb_fail(FB_E_ARG, "feature dim %d > 80 unsupported by the MFMA kernels", D);
   HIPCHK(hipSetDevice(e->device));
   // groups of models with bitwise-identical inv_vars
   std::vector<int> group_of(M, -1);
@@ -414,38 +411,14 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   }
   const int n_items = (int)item_model.size();
   const int n_tiles = (C + 31) / 32;
-  const int ROWF = 2 * KH + 4, IMGF = 32 * ROWF + 32;
-  std::vector<float> img((size_t)n_tiles * n_items * IMGF, 0.0f);
-  for (int t = 0; t < n_tiles; ++t)
-    for (int it = 0; it < n_items; ++it) {
-      float *im = &img[((size_t)t * n_items + it) * IMGF];
-      const int im_model = item_model[it];
-      for (int cc = 0; cc < 32; ++cc) {
-        const int c = t * 32 + cc;
-        float *row = im + (size_t)cc * ROWF;
-        if (c < C) {
-          if (im_model < 0) {
-            const float *src = iv + ((size_t)group_rep[-1 - im_model] * C + c) * D;
-            for (int d = 0; d < D; ++d) row[d] = -0.5f * src[d];
-          } else {
-            const float *src = miv + ((size_t)im_model * C + c) * D;
-            for (int d = 0; d < D; ++d) row[d] = src[d];
-          }
-        }
-        if (im_model >= 0) im[32 * ROWF + cc] = c < C ? gconsts[(size_t)im_model * C + c] : -1.0e30f;
-      }
-    }
   FBCHK(sync_stream(e));
-  FBCHK(e->gmm_images.ensure(sizeof(float) * img.size()));
-  HIPCHK(hipMemcpy(e->gmm_images.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
   // bf16x3 images (k_gmm_bx3): exact 3-way bf16 split of every parameter, gconst in the K padding
   const int NK = (D + 3 + 15) / 16 < 3 ? 3 : (D + 3 + 15) / 16;  // kernels are instantiated for NK = 3..6 (zero padding is free)
   const char *mode_env = getenv("FB_GMM_MODE");
   int mode = FB_GMM_MODE_FX2;
-  if (mode_env && strcmp(mode_env, "f32") == 0) mode = FB_GMM_MODE_F32;
-  else if (mode_env && strcmp(mode_env, "bx3") == 0) mode = FB_GMM_MODE_BX3;
+  if (mode_env && strcmp(mode_env, "bx3") == 0) mode = FB_GMM_MODE_BX3;  // force the fallback kernel (tests)
   else if (mode_env && *mode_env && strcmp(mode_env, "fx2") != 0)
-    return fb_fail(FB_E_ARG, "FB_GMM_MODE must be fx2, bx3 or f32 (got '%s')", mode_env);
+    return fb_fail(FB_E_ARG, "FB_GMM_MODE must be fx2 or bx3 (got '%s')", mode_env);
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
@@ -563,8 +536,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   FBCHK(e->gmm_items.ensure(sizeof(int) * im_dev.size()));
   HIPCHK(hipMemcpy(e->gmm_items.p, im_dev.data(), sizeof(int) * im_dev.size(), hipMemcpyHostToDevice));
   FbGmmDev &g = e->gmm;
-  g.M = M; g.C = C; g.D = D; g.KH = KH; g.n_tiles = n_tiles; g.n_items = n_items; g.img_floats = IMGF;
-  g.images = e->gmm_images.as<float>();
+  g.M = M; g.C = C; g.D = D; g.n_tiles = n_tiles; g.n_items = n_items;
   g.mode = mode; g.NK = NK;
   g.text_scores = e->cfg.text_scores;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
@@ -633,7 +605,7 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
     if (T > e->cfg.cmn_window) e->any_long = true;
     if (T > e->t_max) e->t_max = T;
   }
-  {  // per-frame records for k_mfcc_r4: {absolute start sample (int64), start within the utterance, n}
+  {  // per-frame records for k_mfcc_r16: {absolute start sample (int64), start within the utterance, n}
     const int total = e->h_frame_off[B];
     e->h_frame_rec.resize((size_t)4 * total);
     const fb_frontend_cfg &c = e->cfg;
@@ -668,7 +640,7 @@ static int choose_chunks(const FbGmmDev &g, int rows_cap, bool scoring = true) {
   const bool wide = scoring && fb_gmm_use_wide(g);  // k_gmm_fx2w: 256-frame strips, one workgroup per CU
   const int strips = wide ? (rows_cap + 255) / 256 : (rows_cap + 127) / 128;
   const char *ev = getenv("FB_GMM_TARGET_BLOCKS");
-  const int target = ev ? atoi(ev) : (wide ? 256 : (g.mode == FB_GMM_MODE_F32 ? 1024 : (g.mode == FB_GMM_MODE_FX2 ? 256 * FB_FX_OCC : 512)));
+  const int target = ev ? atoi(ev) : (wide ? 256 : (g.mode == FB_GMM_MODE_FX2 ? 256 * FB_FX_OCC : 512));
   int want = target / (strips > 0 ? strips : 1);
   if (want < 1) want = 1;
   if (want > g.n_tiles) want = g.n_tiles;
@@ -721,6 +693,7 @@ static int time_end(fb_engine *e) {
   return FB_OK;
 }
 
+static bool fb_fuse_on();
 // mfcc -> VAD (+ row offsets) -> deltas -> CMVN -> voiced-row compaction
 static int run_post_mfcc(fb_engine *e, int B) {
   const FbFrontendDev &fe = e->fe;
@@ -740,8 +713,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
       HIPCHK(hipMemsetAsync(e->vad_pub.p, 0, e->vad_pub.cap, s));
       e->vad_epoch = 0;
     }
-    static const bool unfused = getenv("FB_NO_FUSE") != nullptr;
-    if (!unfused && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
+    if (fb_fuse_on() && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                              e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
                                              e->row_off.as<int>(), e->feats.as<float>())) {
       e->vad_epoch += 1;
@@ -819,7 +791,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     }
     FBCHK(e->iv_linp.ensure(sizeof(double) * (size_t)e->iv_kchunks * B * iv.R));
     FBCHK(e->iv_quad.ensure(sizeof(double) * (size_t)B * iv.triR));
-    FBCHK(e->iv_A.ensure(sizeof(double) * (size_t)B * iv.R * iv.R));
+    FBCHK(e->iv_A.ensure(sizeof(double) * (size_t)B * iv.R));  // the right-hand side row each factorisation carries along
     FBCHK(e->iv_linv.ensure(sizeof(double) * (size_t)B * ((iv.R + 31) / 32) * 1024));
     FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
     FBCHK(e->iv_fail.ensure(sizeof(int)));
@@ -1157,7 +1129,9 @@ extern "C" int fb_debug_iv_active(fb_engine *e, int *n_active) {
   return FB_OK;
 }
 
-extern "C" int fb_debug_ivectors(fb_engine *e, int B, double *ivecs) {
+// i-vectors of the last scored batch (enrolment: build_spk_models.py:104-150 keeps the enrolment utterance's
+// i-vector as the speaker identity)
+extern "C" int fb_last_ivectors(fb_engine *e, int B, double *ivecs) {
   if (!e || !ivecs || B <= 0) return fb_fail(FB_E_ARG, "bad argument");
   if (e->kind != 1 || e->last_B < B) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
   HIPCHK(hipSetDevice(e->device));
@@ -1214,8 +1188,7 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
 
 // One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
 static bool fb_fuse_on() {
-  static const bool off = getenv("FB_NO_FUSE") != nullptr;  // FB_NO_FUSE=1: the 8-launch chain (A/B and debugging)
-  return !off;
+  return getenv("FB_NO_FUSE") == nullptr;  // FB_NO_FUSE=1: the 8-launch chain (A/B, debugging; read per call)
 }
 static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
                             const double *noise_dev, bool with_dist, FbCtlDev *ctl = nullptr,
@@ -1746,9 +1719,6 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
   return FB_OK;
 }
 
-// i-vectors of the last scored batch (enrolment: build_spk_models.py:104-150 keeps the enrolment utterance's
-// i-vector as the speaker identity)
-extern "C" int fb_last_ivectors(fb_engine *e, int B, double *ivecs) { return fb_debug_ivectors(e, B, ivecs); }
 
 extern "C" int fb_gmm_kernel_mode(fb_engine *e) {
   if (!e) return fb_fail(FB_E_ARG, "null engine");

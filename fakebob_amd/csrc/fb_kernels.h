@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/fakebob_hip.h"
+#include "../../include/fakebob_hip_test.h"
 
 // ---- device-resident front-end tables (built on the host at fb_set_frontend)
 struct FbFrontendDev {
@@ -115,9 +116,7 @@ void fb_launch_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *dfeat, 
 
 // ---- diagonal GMM -----------------------------------------------------------
 struct FbGmmDev {
-  int M, C, D, KH, n_tiles, n_items;  // items per tile = groups + models
-  int img_floats;                     // floats per tile image
-  const float *images;                // [n_tiles][n_items][img_floats]
+  int M, C, D, n_tiles, n_items;      // items per tile = groups + models
   const int *item_model;              // [n_items]: -1 = quadratic (Q) item, else model index
   int item_model_host_q_first;        // 1: the item list is exactly {Q, model 0, 1, ..., M-1} (one variance group)
   // bf16x3 variant (k_gmm_bx3): K padded to 16*NK >= D + 3, images [n_tiles][n_items][3][NK][64] x 16 B
@@ -132,7 +131,6 @@ struct FbGmmDev {
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
-#define FB_GMM_MODE_F32 0
 #define FB_GMM_MODE_BX3 1
 #define FB_GMM_MODE_FX2 2
 #ifndef FB_FX_OCC

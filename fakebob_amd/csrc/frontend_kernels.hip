@@ -222,23 +222,8 @@ __global__ __launch_bounds__(256) void k_mfcc(FbFrontendDev fe, int melw_n, cons
 }
 
 // ---------------------------------------------------------- MFCC, P = 512 (the recipe's size)
-// Same arithmetic as k_mfcc, organised for latency: the complex FFT of size 256 runs as four radix-4
-// Stockham stages with one butterfly per lane (4 points per lane in registers), so a frame crosses the
-// LDS three times instead of eight and the first stage starts straight from the windowed samples in
-// registers.  The per-wave exchange buffer is padded by one 16-byte slot per 8 (the stride-4 stores
-// of the first stage would otherwise be 4-way bank-conflicted); power spectrum and log-mel energies
-// alias it.  The waves of a workgroup share the tables; workgroups are persistent and sized so every
-// wave gets the same number of frames.
-#ifndef FB_R4_WAVES
-#define FB_R4_WAVES 4
-#endif
-#ifndef FB_R4_OCC
-#define FB_R4_OCC 3
-#endif
-#ifndef R4_UNROLL
-#define R4_UNROLL 4  // mel / DCT tap loops: batches the LDS reads of 4 taps (41.7 -> 40.4 us)
-#endif
-#define FB_R4_XSLOTS 288  // 256 + 256/8 padded complex slots
+// LDS table layout and small FFT helpers of k_mfcc_r16 (P = 512).
+#define FB_R4_XSLOTS 288  // 256 + 256/8 padded complex slots (per-wave scratch size the layout reserves)
 
 struct MfccR4Lds {  // offsets in doubles
   int tw, twf, win, melw, dct, lift, melidx, wave0, per_wave;
@@ -259,7 +244,6 @@ __host__ __device__ inline MfccR4Lds fb_mfcc_r4_layout(int L, int nb, int nc, in
   return o;
 }
 
-__device__ __forceinline__ int fb_r4_phys(int idx) { return idx + (idx >> 3); }
 __device__ __forceinline__ double2 fb_cmul(double2 a, double2 w) {
   return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
 }
@@ -273,214 +257,11 @@ __device__ __forceinline__ void fb_dft4(double2 &v0, double2 &v1, double2 &v2, d
   v3 = make_double2(b.x - d.y, b.y + d.x);  // b + i d
 }
 
-__global__ __launch_bounds__(64 * FB_R4_WAVES, FB_R4_OCC) void k_mfcc_r4(FbFrontendDev fe, int melw_n,
-                                                                       const int16_t *__restrict__ wav,
-                                                                       const int4 *__restrict__ frame_rec,
-                                                                       int total_frames,
-                                                                       float *__restrict__ mfcc) {
-  if (fe.stop && *fe.stop) return;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int NT = 64 * FB_R4_WAVES, Nc = 256;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int L = fe.L, nb = fe.nb, nc = fe.nc;
-  const MfccR4Lds lo = fb_mfcc_r4_layout(L, nb, nc, melw_n);
-  double2 *s_tw = reinterpret_cast<double2 *>(smem + lo.tw);
-  double2 *s_twf = reinterpret_cast<double2 *>(smem + lo.twf);
-  float *s_win = reinterpret_cast<float *>(smem + lo.win);
-  float *s_melw = reinterpret_cast<float *>(smem + lo.melw);
-  float *s_dct = reinterpret_cast<float *>(smem + lo.dct);
-  float *s_lift = reinterpret_cast<float *>(smem + lo.lift);
-  int *s_mfirst = reinterpret_cast<int *>(smem + lo.melidx), *s_mlen = s_mfirst + nb, *s_moff = s_mlen + nb;
-  double2 *X = reinterpret_cast<double2 *>(smem + lo.wave0 + (size_t)w * lo.per_wave);
-  for (int i = tid; i < Nc; i += NT) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
-  for (int i = tid; i <= Nc; i += NT) s_twf[i] = reinterpret_cast<const double2 *>(fe.tw_full)[i];
-  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
-  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
-  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
-  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
-  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
-  __syncthreads();
-
-  // The frame index is wave-uniform: it (and the frame record read through it) stays in scalar
-  // registers.  Lane l owns complex points p = l + 64 q <-> samples 2p, 2p+1 (and 2p-1 for the
-  // pre-emphasis); the raw samples of the NEXT frame are requested before the current one is
-  // processed, so their L2 latency is off the critical path.
-  auto load_raw = [&](int f, int (&r0)[4], int (&r1)[4], int (&rm)[4]) {
-    const int4 rec = frame_rec[f];
-    const int64_t abs_start = ((int64_t)(unsigned)rec.x) | ((int64_t)rec.y << 32);
-    const int start = rec.z, n = rec.w;
-    if (start >= 0 && start + L <= n) {  // interior frame (uniform branch): no reflection
-      // (loads are unconditional on clamped indices and selected afterwards: a predicated load is
-      //  followed by its own s_waitcnt and the twelve L2 latencies would add up)
-      const int16_t *fr = wav + abs_start;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int s0 = 2 * (lane + 64 * q);
-        r0[q] = fr[min(s0, L - 1)];
-        r1[q] = fr[min(s0 + 1, L - 1)];
-        rm[q] = fr[min(max(s0 - 1, 0), L - 1)];
-      }
-    } else {
-      const int16_t *wv = wav + (abs_start - start);
-      auto sample = [&](int s) -> int {  // reflected at the utterance edges
-        int64_t k = (int64_t)start + s;
-        while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
-        return wv[k];
-      };
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const int s0 = 2 * (lane + 64 * q);
-        r0[q] = sample(min(s0, L - 1));
-        r1[q] = sample(min(s0 + 1, L - 1));
-        rm[q] = sample(min(max(s0 - 1, 0), L - 1));
-      }
-    }
-  };
-  const int w_s = __builtin_amdgcn_readfirstlane(w);
-  const int f_first = blockIdx.x * FB_R4_WAVES + w_s, f_step = gridDim.x * FB_R4_WAVES;
-  int n0[4], n1[4], nm[4];
-  if (f_first < total_frames) load_raw(f_first, n0, n1, nm);
-  // loop-invariant per-lane constants: window weights (0 outside the frame) and 0/1 frame masks
-  double wq0[4], wq1[4], mq0[4], mq1[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int s0 = 2 * (lane + 64 * q);
-    wq0[q] = s0 < L ? (double)s_win[min(s0, L - 1)] : 0.0;
-    wq1[q] = s0 + 1 < L ? (double)s_win[min(s0 + 1, L - 1)] : 0.0;
-    mq0[q] = s0 < L ? 1.0 : 0.0;
-    mq1[q] = s0 + 1 < L ? 1.0 : 0.0;
-  }
-  for (int f = f_first; f < total_frames; f += f_step) {
-    // DC: the samples are integers, |sum| < 2^24: exact in int32 in any order
-    int isum = 0;
-    double xm[4], x0[4], x1[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int s0 = 2 * (lane + 64 * q);
-      isum += (s0 < L ? n0[q] : 0) + (s0 + 1 < L ? n1[q] : 0);
-      x0[q] = (double)n0[q];
-      x1[q] = (double)n1[q];
-      xm[q] = (double)(s0 > 0 ? nm[q] : n0[q]);  // Kaldi: sample 0 is pre-emphasised with itself
-    }
-    if (f + f_step < total_frames) load_raw(f + f_step, n0, n1, nm);
-    const double mean = fe.remove_dc ? (double)fb_wave_sum_i32_dpp(isum) / (double)L : 0.0;
-    double en = 0.0, en2 = 0.0;
-    double2 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // out-of-frame positions hold clamped samples: the masks zero them for the energy, the zero
-      // window weights for the FFT input
-      const double a = (x0[q] - mean) * mq0[q], c = (x1[q] - mean) * mq1[q], pm = xm[q] - mean;
-      en = fma(a, a, en);
-      en = fma(c, c, en);
-      const double y0 = (a - fe.preemph * pm) * wq0[q];
-      const double y1 = (c - fe.preemph * a) * wq1[q];
-      v[q] = make_double2(y0, y1);
-    }
-    if (!fe.raw_energy) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { en2 = fma(v[q].x, v[q].x, en2); en2 = fma(v[q].y, v[q].y, en2); }
-    }
-    const double energy = fb_wave_sum_dpp(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
-
-    // ---- radix-4 Stockham, Ns = 1, 4, 16, 64; input of a stage: points lane + 64 r
-    fb_dft4(v[0], v[1], v[2], v[3]);  // Ns = 1: no twiddles
-#pragma unroll
-    for (int r = 0; r < 4; ++r) X[fb_r4_phys(4 * lane + r)] = v[r];
-    fb_wave_sync();
-#pragma unroll
-    for (int st = 1; st < 4; ++st) {
-      const int Ns = 1 << (2 * st), k = lane & (Ns - 1), tstep = Nc / (4 * Ns);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = X[fb_r4_phys(lane + 64 * r)];
-      v[1] = fb_cmul(v[1], s_tw[k * tstep]);
-      v[2] = fb_cmul(v[2], s_tw[2 * k * tstep]);
-      v[3] = fb_cmul(v[3], s_tw[3 * k * tstep]);
-      fb_dft4(v[0], v[1], v[2], v[3]);
-      fb_wave_sync();  // all reads of this stage are issued before its stores (LDS is in-order per wave)
-      const int base = 4 * lane - 3 * k;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[fb_r4_phys(base + r * Ns)] = v[r];
-      fb_wave_sync();
-    }
-    // ---- real-FFT unpack + power spectrum of bins k = lane + 64 i (i < 4) and bin 256 (lane 0)
-    double pwv[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int k = lane + 64 * i;
-      const int kc = min(k, Nc);  // i == 4: only lane 0 holds a bin (k = 256); the others compute and drop
-      const double2 zk = X[fb_r4_phys(kc & (Nc - 1))];
-      const double2 zr = X[fb_r4_phys((Nc - kc) & (Nc - 1))];
-      const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);
-      const double dr = zk.x - zr.x, di = zk.y + zr.y;
-      const double orr = 0.5 * di, oi = -0.5 * dr;
-      const double2 wk = s_twf[kc];
-      const double xr = er + (wk.x * orr - wk.y * oi);
-      const double xi = ei + (wk.x * oi + wk.y * orr);
-      pwv[i] = xr * xr + xi * xi;
-    }
-    fb_wave_sync();
-    double *PW = reinterpret_cast<double *>(X);  // 257 doubles; LM behind it
-    double *LM = PW + 264;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int k = lane + 64 * i;
-      if (k <= Nc) PW[k] = pwv[i];
-    }
-    fb_wave_sync();
-    // ---- mel filterbank + log: two lanes per filter (nb <= 31: one pass); lane 63 takes the log of the
-    //      frame energy in the same call
-    {
-      const int m = lane >> 1, part = lane & 1;
-      double e = 0.0;
-      if (m < nb) {
-        const float *wm = s_melw + s_moff[m];
-        const int first = s_mfirst[m], len = s_mlen[m];
-        const int h0 = (len + 1) >> 1;
-        const int i0 = part ? h0 : 0, i1 = part ? len : h0;
-#ifdef R4_UNROLL
-#pragma unroll R4_UNROLL
-#endif
-        for (int i = i0; i < i1; ++i) e = fma((double)wm[i], PW[first + i], e);
-      }
-      e += __shfl_xor(e, 1, 64);
-      if (lane == 63) e = energy;
-      if (e < (double)FLT_EPSILON) e = (double)FLT_EPSILON;
-      const double le = fb_log_f64(e);
-      if (m < nb && part == 0) LM[m] = le;
-      if (lane == 63) LM[nb] = le < fe.log_energy_floor ? fe.log_energy_floor : le;
-    }
-    fb_wave_sync();
-    // ---- DCT-II, lifter, C0 <- log energy: two lanes per coefficient
-    for (int c2 = lane; c2 < 2 * ((nc + 31) / 32) * 32; c2 += 64) {
-      const int c = c2 >> 1, part = c2 & 1;
-      double acc = 0.0;
-      if (c < nc) {
-        const float *dr = s_dct + c * nb;
-        const int h0 = (nb + 1) >> 1;
-        const int i0 = part ? h0 : 0, i1 = part ? nb : h0;
-#ifdef R4_UNROLL
-#pragma unroll R4_UNROLL
-#endif
-        for (int m = i0; m < i1; ++m) acc = fma((double)dr[m], LM[m], acc);
-      }
-      acc += __shfl_xor(acc, 1, 64);
-      if (c < nc && part == 0) {
-        acc *= (double)s_lift[c];
-        float o = (float)acc;
-        if (c == 0 && fe.use_energy) o = (float)LM[nb];
-        mfcc[(size_t)f * nc + c] = o;
-      }
-    }
-    fb_wave_sync();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_mfcc_r16: P = 512 with FOUR frames per wave.  16 lanes own one frame and 16 complex points each, so the 256-point
-// complex FFT is two radix-16 passes held in registers with ONE transpose through LDS between them (k_mfcc_r4: three
-// exchanges per frame), and every LDS / DPP round trip of the remaining stages serves four frames.  Same arithmetic
-// (float64 between Kaldi's float32 storage points), different summation trees than k_mfcc_r4 -- both sit within 1e-6 of
+// complex FFT is two radix-16 passes held in registers with ONE transpose through LDS between them (a radix-4 form needs three exchanges
+// per frame), and every LDS / DPP round trip of the remaining stages serves four frames.  Same arithmetic
+// (float64 between Kaldi's float32 storage points), different summation trees than the generic k_mfcc -- both sit within 1e-6 of
 // the oracle.  16 lanes = one DPP row: the per-frame reductions are four row-local DPP steps.
 #define FB_R16_WAVES 8
 #define FB_R16_SLOTS 272  // complex slots per frame buffer: 256 + one pad per 16 (conflict-free 16 x 16 transpose)
@@ -536,7 +317,7 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int t = lane & 15, fq = lane >> 4;
   const int L = fe.L, nb = fe.nb, nc = fe.nc;
-  const MfccR4Lds lo = fb_mfcc_r4_layout(L, nb, nc, melw_n);  // same table layout as k_mfcc_r4
+  const MfccR4Lds lo = fb_mfcc_r4_layout(L, nb, nc, melw_n);  
   double2 *s_tw = reinterpret_cast<double2 *>(smem + lo.tw);
   double2 *s_twf = reinterpret_cast<double2 *>(smem + lo.twf);
   float *s_win = reinterpret_cast<float *>(smem + lo.win);
@@ -723,9 +504,7 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
                     const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
                     int total_frames, float *mfcc) {
   if (total_frames <= 0) return;
-  const char *mfcc_mode = getenv("FB_MFCC");  // r4: the one-frame-per-wave predecessor (read per launch: tests switch it)
-  const bool want_r4 = mfcc_mode && strcmp(mfcc_mode, "r4") == 0;
-  if (fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2 && !want_r4) {
+  if (fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2) {
     const MfccR4Lds l16 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
     const size_t shm16 = sizeof(double) * (size_t)l16.wave0 + sizeof(double2) * (size_t)FB_R16_WAVES * 4 * FB_R16_SLOTS;
     static std::atomic<unsigned long long> optin16{0};
@@ -740,18 +519,6 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
       const int rounds = (n_groups + 256 * FB_R16_WAVES - 1) / (256 * FB_R16_WAVES);
       const int blocks = (n_groups + rounds * FB_R16_WAVES - 1) / (rounds * FB_R16_WAVES);
       hipLaunchKernelGGL(k_mfcc_r16, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
-                         reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
-      return;
-    }
-  }
-  if (fe.P == 512 && fe.nb <= 31) {
-    const MfccR4Lds l4 = fb_mfcc_r4_layout(fe.L, fe.nb, fe.nc, melw_n);
-    const size_t shm4 = sizeof(double) * (size_t)(l4.wave0 + FB_R4_WAVES * l4.per_wave);
-    if (shm4 <= 64 * 1024) {
-      const int max_blocks = 256 * (4 * FB_R4_OCC / FB_R4_WAVES);  // FB_R4_OCC waves per SIMD
-      const int rounds = (total_frames + max_blocks * FB_R4_WAVES - 1) / (max_blocks * FB_R4_WAVES);
-      const int blocks = (total_frames + rounds * FB_R4_WAVES - 1) / (rounds * FB_R4_WAVES);
-      hipLaunchKernelGGL(k_mfcc_r4, dim3(blocks), dim3(64 * FB_R4_WAVES), shm4, s, fe, melw_n, wav,
                          reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
       return;
     }

@@ -1,6 +1,7 @@
 // gmm_kernels.hip -- K7: diagonal-GMM frame log-likelihoods for all models of a
 // speaker-recognition system, fused with the per-frame logsumexp, on the gfx950
-// matrix cores (exact-f32 MFMA v_mfma_f32_32x32x2_f32).
+// matrix cores: f32 arithmetic carried by the f16 / bf16 MFMA pipe (k_gmm_fx2w / k_gmm_fx2: two-term f16 split;
+// k_gmm_bx3: exact three-term bf16 split for models whose parameters do not fit f16's range).
 //
 // Replaces `gmm-global-get-frame-likes --average=true MODEL feats` run once per
 // model by the reference (gmm_ubm_kaldiHelper.py:202-221) ([EXT] SURVEY.md A.7):
@@ -11,10 +12,9 @@
 //     frames.  With the C/D layout of the 32x32 MFMA every lane then owns ONE
 //     frame (col = lane&31) and 16 components of it, so the online logsumexp is
 //     lane-local: no cross-lane traffic in the hot loop.
-//   * A wave keeps its 32 frames (x and x^2, 2*KH VGPRs) in registers for the
-//     whole kernel; parameter tiles stream HBM/L2 -> registers -> LDS
-//     (double-buffered, one barrier per 36-MFMA item) and are shared by the 4
-//     waves (128 frames) of the workgroup.
+//   * A wave keeps its frames (x and x^2 as split fragments) in registers for the
+//     whole kernel; parameter tiles stream HBM/L2 -> LDS and are shared by the 4
+//     waves of the workgroup.
 //   * Models with bitwise-identical inverse variances (mean-only MAP adaptation,
 //     build_spk_models.py:170) share the quadratic term: acc_q = -1/2 iv . x^2 is
 //     computed once per tile ("Q item") and every model continues the fma chain
@@ -35,162 +35,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FB_GMM_NEG (-3.0e38f)
 
-// DUMP = true: single-model variant that stores every component log-likelihood ll[row][comp]
-// (leading dimension n_tiles*32) instead of reducing them -- the gmm-gselect stage of the
-// i-vector path (ivector_kernels.hip) takes the top-n per frame from it.
-template <int KH, bool DUMP>
-__global__ __launch_bounds__(256, 2) void k_gmm(FbGmmDev g, const float *__restrict__ feats,
-                                                const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
-                                                int rows_cap, float *__restrict__ part_m,
-                                                float *__restrict__ part_s) {
-  if (g.stop && *g.stop) return;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int ROWF = 2 * KH + 4;
-  constexpr int IMGF = 32 * ROWF + 32;
-  constexpr int IMG4 = IMGF / 4;
-  constexpr int NST = (IMG4 + 255) / 256;
-  const int n_rows = *n_rows_ptr;
-  const int strip0 = blockIdx.x * 128;
-  if (strip0 >= n_rows) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int h = lane >> 5, j = lane & 31;
-  const int row = strip0 + w * 32 + j;
-  float *slot0 = lds, *slot1 = lds + IMGF;
-  float *st_m = lds + 2 * IMGF;            // [M][256]
-  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
-
-  // ---- frame fragments: x[h*KH + i], i < KH
-  float xf[KH], xq[KH];
-  {
-    const bool ok = row < n_rows;
-    const float *fr = feats + (size_t)(ok ? row : 0) * g.D + h * KH;
-    if (g.D == 2 * KH) {  // rows are 16-byte aligned and fully used: 9 x 16-byte loads per lane
-#pragma unroll
-      for (int q = 0; q < KH / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(fr + 4 * q);
-        xf[4 * q + 0] = ok ? v.x : 0.0f; xf[4 * q + 1] = ok ? v.y : 0.0f;
-        xf[4 * q + 2] = ok ? v.z : 0.0f; xf[4 * q + 3] = ok ? v.w : 0.0f;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < KH; ++i) {
-        const int d = h * KH + i;
-        xf[i] = (ok && d < g.D) ? fr[i] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < KH; ++i) xq[i] = __fmul_rn(xf[i], xf[i]);
-  }
-  for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
-
-  const int tile0 = blockIdx.y * tiles_per_chunk;
-  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
-  const int total_items = (tile1 - tile0) * g.n_items;
-  const float4 *gimg = reinterpret_cast<const float4 *>(g.images + (size_t)tile0 * g.n_items * IMGF);
-
-  float4 stage[NST];
-  // prologue: item 0 -> slot 0
-  // (indices are clamped instead of predicated: a predicated "load or keep" forces the staging
-  //  registers to scratch and serialises every load behind s_waitcnt vmcnt(0))
-#pragma unroll
-  for (int s = 0; s < NST; ++s) {
-    const int q = min(tid + 256 * s, IMG4 - 1);
-    reinterpret_cast<float4 *>(slot0)[q] = gimg[q];
-  }
-  __syncthreads();
-
-  f32x16 accq;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accq[r] = 0.0f;
-
-  for (int it = 0; it < total_items; ++it) {
-    float *cur = (it & 1) ? slot1 : slot0;
-    float *nxt = (it & 1) ? slot0 : slot1;
-    {  // unconditional prefetch of the next item (the last iteration re-loads its own item)
-      const float4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
-#pragma unroll
-      for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
-    }
-    const int item = it % g.n_items;
-    const int model = g.item_model[item];
-    const float *prow = cur + j * ROWF + h * KH;
-    if (model < 0) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-      for (int q = 0; q < KH / 4; ++q) {
-        const float4 p = *reinterpret_cast<const float4 *>(prow + 4 * q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, xq[4 * q + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, xq[4 * q + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, xq[4 * q + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, xq[4 * q + 3], acc, 0, 0, 0);
-      }
-      accq = acc;
-    } else {
-      f32x16 acc = accq;
-#pragma unroll
-      for (int q = 0; q < KH / 4; ++q) {
-        const float4 p = *reinterpret_cast<const float4 *>(prow + 4 * q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, xf[4 * q + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, xf[4 * q + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, xf[4 * q + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, xf[4 * q + 3], acc, 0, 0, 0);
-      }
-      // epilogue: + gconst, online logsumexp over this lane's 16 components
-      const float *gc = cur + 32 * ROWF + 4 * h;
-      float v[16];
-      float tm = FB_GMM_NEG;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float4 gq = *reinterpret_cast<const float4 *>(gc + 8 * rr);
-        v[4 * rr + 0] = acc[4 * rr + 0] + gq.x;
-        v[4 * rr + 1] = acc[4 * rr + 1] + gq.y;
-        v[4 * rr + 2] = acc[4 * rr + 2] + gq.z;
-        v[4 * rr + 3] = acc[4 * rr + 3] + gq.w;
-      }
-      if constexpr (DUMP) {
-        if (row < n_rows) {
-          const int tile = tile0 + it / g.n_items;
-          float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(v[4 * rr], v[4 * rr + 1], v[4 * rr + 2], v[4 * rr + 3]);
-        }
-      } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, v[r]);
-      const float m_old = st_m[model * 256 + tid], s_old = st_s[model * 256 + tid];
-      const float m_new = fmaxf(m_old, tm);
-      float ssum = s_old * __expf(m_old - m_new);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ssum += __expf(v[r] - m_new);
-      st_m[model * 256 + tid] = m_new;
-      st_s[model * 256 + tid] = ssum;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NST; ++s) reinterpret_cast<float4 *>(nxt)[min(tid + 256 * s, IMG4 - 1)] = stage[s];
-    __syncthreads();
-  }
-
-  if constexpr (DUMP) return;
-  // ---- merge the two lane halves (components 4h..) and publish the chunk partial
-  for (int m = 0; m < g.M; ++m) {
-    const float mm = st_m[m * 256 + tid], ss = st_s[m * 256 + tid];
-    const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
-    const float mx = fmaxf(mm, m2);
-    const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
-    if (h == 0 && row < n_rows) {
-      const size_t o = ((size_t)blockIdx.y * g.M + m) * rows_cap + row;
-      part_m[o] = mx;
-      part_s[o] = sx;
-    }
-  }
-}
+// DUMP = true (template parameter of the kernels below): single-model variant that stores every component
+// log-likelihood ll[row][comp] (leading dimension n_tiles*32) instead of reducing them -- the gmm-gselect stage of the
+// i-vector path (ivector_kernels.hip) takes the top-n per frame from it, the enrolment statistics use it too.
 
 // ------------------------------------------------------------------------------------------------
-// k_gmm_bx3: the same computation on the bf16 matrix pipe (16x the f32 MFMA rate) WITHOUT giving up
+// k_gmm_bx3: the computation on the bf16 matrix pipe (16x the f32 MFMA rate) WITHOUT giving up
 // f32 accuracy.  Every f32 operand is split exactly into three bf16 terms (v = v1 + v2 + v3, 8
 // significant bits each, round-to-nearest residuals -- the three terms carry all 24 bits exactly), and
 // a product a*b is accumulated in f32 from the six partial products of order <= 2^-16:
@@ -436,10 +286,10 @@ static void launch_gmm_bx(hipStream_t s, const FbGmmDev &g, const float *feats, 
 // f32 value to within half an f32 ulp.  A product needs
 //     a1b1 + (a1b2 + a2b1)          (dropped: a2b2 <= 2^-24 |ab|, the size of one f32 rounding)
 // i.e. 3 MFMAs per 16 K instead of bx3's 6, at the same matrix rate.  Measured against float64 the
-// result is as close as the f32 MFMA kernel's (numpy model in scratch/fx2_emul.py).
+// result is as close as the f32 MFMA kernel's (numpy model in tools/probes/fx2_emul.py).
 // f16's narrow exponent range is handled without data-dependent scaling:
 //   * all three products go into ONE accumulator; residuals are stored unscaled.  The f16 matrix pipe keeps
-//     subnormal inputs (scratch/f16_denorm_probe.hip), so a residual below 2^-14 is still exact to 2^-25 absolute.
+//     subnormal inputs (tools/probes/f16_denorm_probe.hip), so a residual below 2^-14 is still exact to 2^-25 absolute.
 //   * operands are moved up by exact powers of two chosen at load time (fb_load_gmm): (mu/sigma^2, gconst) * 2^kl
 //     against (x, 1) * 2^kx, and -1/(2 sigma^2) * 2^kq against x^2 * 2^kx2 with kl + kx = kq + kx2 = kacc, so
 //     that typical residuals are normal numbers and the largest operand stays below 2^15 (|x| < 4094, |x| < 511
@@ -483,7 +333,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define FB_LOG2E_F 1.44269502162933349609375f  // fl(log2 e)
 __device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts,
                                                 float ls = FB_LOG2E_F) {  // ls = fl(log2 e) * 2^-kacc for scaled values
-#ifndef FB_ABL_NOEPI
   float tm = FB_GMM_NEG;
 #pragma unroll
   for (int r = 0; r < 16; ++r) tm = fmaxf(tm, pv[r]);
@@ -501,9 +350,6 @@ __device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restr
   }
   *stm = m_new;
   *sts = acc[0] + acc[1];
-#else
-  if (pv[3] == 1.2345f) *stm = pv[0];
-#endif
 }
 // s (log2-domain state, see above) -> sum exp(v - m):  s * 2^(r - L m), evaluated in float64 (|r - L m| < 1e-4)
 __device__ __forceinline__ float fb_lse_to_natural(float m, float s, float ls = FB_LOG2E_F) {
@@ -529,22 +375,14 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
   u32x4 a1[NK], a2[NK];
 #pragma unroll
   for (int c = 0; c < NK; ++c) {
-#ifndef FB_ABL_NOLDSREAD
     a1[c] = cur4[(0 * NK + c) * 64 + lane];
     a2[c] = cur4[(1 * NK + c) * 64 + lane];
-#else
-    a1[c] = b1[c]; a2[c] = b2[(c + 1) % NK];
-#endif
   }
 #pragma unroll
   for (int c = 0; c < NK; ++c) {
-#ifndef FB_ABL_NOMFMA
     FB_FX_MFMA(a2[c], b1[c], hi);
     FB_FX_MFMA(a1[c], b2[c], hi);
     FB_FX_MFMA(a1[c], b1[c], hi);
-#else
-    hi[c] += __uint_as_float(a1[c][0] ^ b1[c][1]) + __uint_as_float(a2[c][0] ^ b2[c][1]);
-#endif
   }
   if constexpr (ISQ) hq = hi; else pv = hi;
 }
@@ -661,13 +499,11 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
   for (int it = 0; it < total_items; ++it) {
     u32x4 *cur = (it & 1) ? slot1 : slot0;
     u32x4 *nxt = (it & 1) ? slot0 : slot1;
-#ifndef FB_ABL_NOLOAD
     {
       const u32x4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
 #pragma unroll
       for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
     }
-#endif
     const int item = it % g.n_items;
     const int model = g.item_model[item];
     if (model < 0) {
@@ -693,13 +529,9 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
         fb_lse_update16(pv, st_m + model * 256 + tid, st_s + model * 256 + tid, ls);
       }
     }
-#ifndef FB_ABL_NOLOAD
 #pragma unroll
     for (int s = 0; s < NST; ++s) nxt[min(tid + 256 * s, IMG4 - 1)] = stage[s];
-#endif
-#ifndef FB_ABL_NOBAR
     __syncthreads();
-#endif
   }
 
   if constexpr (DUMP) return;
@@ -989,7 +821,7 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
 // speakers; CSI: the speakers).  Everything else runs on k_gmm_fx2.
 #define FB_FXW_MAX_M 6
 bool fb_gmm_use_wide(const FbGmmDev &g) {
-  static const bool off = getenv("FB_GMM_NARROW") != nullptr;
+  const bool off = getenv("FB_GMM_NARROW") != nullptr;  // read per call: the tests switch it inside one process
   return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
          g.M <= FB_FXW_MAX_M && g.item_model_host_q_first;
 }
@@ -1034,54 +866,21 @@ static void launch_gmm_fx(hipStream_t s, const FbGmmDev &g, const float *feats, 
   }
 }
 
-static int fb_gmm_lds_bytes(const FbGmmDev &g) {
-  const int imgf = 32 * (2 * g.KH + 4) + 32;
-  return (2 * imgf + 2 * g.M * 256) * (int)sizeof(float);
-}
-
-template <int KH>
-static void launch_gmm_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
-                         int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
-  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
-  hipLaunchKernelGGL((k_gmm<KH, false>), grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr,
-                     tpc, rows_cap, part_m, part_s);
-}
-template <int KH>
-static void launch_gmm_dump_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
-                              int rows_cap, int n_chunks, int tpc, float *ll) {
-  dim3 grid((unsigned)((rows_cap + 127) / 128), (unsigned)n_chunks);
-  hipLaunchKernelGGL((k_gmm<KH, true>), grid, dim3(256), (size_t)fb_gmm_lds_bytes(g), s, g, feats, n_rows_ptr,
-                     tpc, rows_cap, ll, (float *)nullptr);
-}
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                         int rows_cap, int n_chunks, float *ll) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
-  if (g.mode == FB_GMM_MODE_FX2) { launch_gmm_fx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr); return; }
-  if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr); return; }
-  switch (g.KH) {
-    case 20: launch_gmm_dump_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
-    case 32: launch_gmm_dump_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
-    case 36: launch_gmm_dump_t<36>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
-    case 40: launch_gmm_dump_t<40>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll); break;
-    default: break;
-  }
+  if (g.mode == FB_GMM_MODE_FX2) launch_gmm_fx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr);
+  else launch_gmm_bx<true>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, ll, nullptr);
 }
 
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                    int rows_cap, int n_chunks, float *part_m, float *part_s) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
-  if (fb_gmm_use_wide(g)) { launch_gmm_fxw(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
-  if (g.mode == FB_GMM_MODE_FX2) { launch_gmm_fx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
-  if (g.mode == FB_GMM_MODE_BX3) { launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); return; }
-  switch (g.KH) {
-    case 20: launch_gmm_t<20>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 32: launch_gmm_t<32>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 36: launch_gmm_t<36>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 40: launch_gmm_t<40>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    default: break;  // fb_load_gmm only produces the KH values above
-  }
+  if (fb_gmm_use_wide(g)) launch_gmm_fxw(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
+  else if (g.mode == FB_GMM_MODE_FX2) launch_gmm_fx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
+  else launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
 }
 
 // raw[b][m] = (1/Tv) * sum_{voiced rows of b} logsumexp_k ll_k   (float64 sum of

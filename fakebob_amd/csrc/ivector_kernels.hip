@@ -17,7 +17,7 @@
 //   k_iv_active           list of the components with posterior mass
 //   k_iv_contract_gemm    the T-matrix contraction: lin = sum_k (S_k^-1 M_k)^T F_k, quad = sum_k N_k U_k
 //                         as an LDS-tiled float64-MFMA GEMM over the active rows (of 0.47 GB + 1.3 GB)
-//   k_iv_solve            blocked Cholesky (f64 MFMA, look-ahead) + triangular solves of the B (R x R) systems
+//   k_iv_solve_packed     blocked Cholesky (f64 MFMA, look-ahead) + triangular solves of the B (R x R) systems
 //   k_iv_backend          mean subtraction, LDA, length norm, PLDA transform, LLR vs enrolled
 #include <float.h>
 #include <stdlib.h>
@@ -900,8 +900,8 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
                            double *quad) {
   hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
   const int bgroups = (B + 63) / 64;
-  static const bool reg_staged = getenv("FB_IV_CONTRACT") && strcmp(getenv("FB_IV_CONTRACT"), "reg") == 0;
-  const bool dma = !reg_staged && (iv.R % 2 == 0) && (iv.triR % 2 == 0) && iv.R >= 2;  // 16-byte aligned row segments
+  // LDS-DMA form: needs 16-byte aligned row segments; odd R / odd R(R+1)/2 take the register-staged kernel
+  const bool dma = (iv.R % 2 == 0) && (iv.triR % 2 == 0) && iv.R >= 2;
   if (dma) {
     hipLaunchKernelGGL((k_iv_contract_dma<true>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0, s,
                        iv, XT, Bpad, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp);
@@ -929,260 +929,9 @@ __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(512) void k_iv_solve(FbIvDev iv, const double *__restrict__ quad,
-                                                   const double *__restrict__ linp, int n_kchunks, int B,
-                                                   double *__restrict__ Aall, double *__restrict__ LinvAll,
-                                                   double *__restrict__ ivec, int *__restrict__ fail) {
-  extern __shared__ __attribute__((aligned(16))) double smd[];
-  constexpr int LD = FB_IV_NB + 1;
-  const int R = iv.R, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-  const int npanel = (R + FB_IV_NB - 1) / FB_IV_NB;
-  double *A = Aall + (size_t)b * R * R;
-  double *Lg = LinvAll + (size_t)b * npanel * FB_IV_NB * FB_IV_NB;
-  double *rhs = smd;                  // [R]
-  double *Dg = rhs + ((R + 1) & ~1);  // [NB][LD]  L11
-  double *Di = Dg + FB_IV_NB * LD;    // [NB][LD]  L11^-1
-  constexpr int LDP = FB_IV_NB + 2;   // panel row stride: conflict-free for the MFMA fragment reads
-  double *Lp = Di + FB_IV_NB * LD;    // [R+16][LDP] panel below the diagonal block
-  const double *qb = quad + (size_t)b * iv.triR;
-  // ---- unpack the lower triangle (+ I): wave w walks rows w, w+nw, ...; lanes walk columns
-  for (int r = wv; r < R; r += nw) {
-    const double *qr = qb + (size_t)r * (r + 1) / 2;
-    for (int c = lane; c < R; c += 64) A[(size_t)r * R + c] = (c <= r) ? qr[c] + (r == c ? 1.0 : 0.0) : 0.0;
-  }
-  {  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order
-    double *part = Lp;
-    for (int idx = tid; idx < 8 * R; idx += nt) {
-      const int sl = idx / R, r = idx - sl * R;
-      double acc = 0.0;
-      for (int ch = sl; ch < n_kchunks; ch += 8) acc += linp[((size_t)ch * B + b) * R + r];
-      part[sl * R + r] = acc;
-    }
-    __syncthreads();
-    for (int r = tid; r < R; r += nt) {
-      double acc = 0.0;
-      for (int sl = 0; sl < 8; ++sl) acc += part[sl * R + r];
-      rhs[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
-    }
-  }
-  __syncthreads();
-  // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
-  // registers (lane = row for the factor, lane = column for the inverse; pivots and columns are broadcast
-  // with v_readlane).  Leaves L11 in Dg and in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
-  // fixed-size code valid for a short last block.
-  auto factor_block = [&](int j0, int nb, int pi) {
-    double row[FB_IV_NB];
-    const int rr = lane & 31;
-    {
-      const double *ar = A + (size_t)(j0 + min(rr, nb - 1)) * R + j0;
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) {
-        const double v = ar[min(c, nb - 1)];
-        row[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
-      }
-    }
-    bool bad = false;
-    double rinv_mine = 1.0;  // lane c keeps 1 / L11[c][c]
-#pragma unroll
-    for (int c = 0; c < FB_IV_NB; ++c) {
-      const double d = fb_readlane_f64(row[c], c);
-      bad |= !(d > 0.0);
-      // 1/sqrt(d) by v_rsq_f64 + two Newton steps (full double precision) instead of a sqrt and 32
-      // divisions on the critical path of the column loop
-      const double dd = d > 0.0 ? d : 1.0;
-      double ri = __builtin_amdgcn_rsq(dd);
-      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-      const double piv = dd * ri;
-      if (rr == c) rinv_mine = ri;
-      const double l = (rr == c) ? piv : row[c] * ri;
-      row[c] = (rr >= c) ? l : 0.0;
-#pragma unroll
-      for (int cc = c + 1; cc < FB_IV_NB; ++cc) row[cc] = fma(-l, fb_readlane_f64(l, cc), row[cc]);
-    }
-    if (bad && lane == 0) atomicMax(fail, b + 1);
-    if (lane < FB_IV_NB) {
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) {
-        Dg[rr * LD + c] = row[c];
-        if (rr < nb && c <= rr) A[(size_t)(j0 + rr) * R + j0 + c] = row[c];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
-    // (column updates: once li[q] is known it is subtracted from every later row at once -- 31 - q independent
-    //  fmas -- instead of one 496-long dependent chain; the operations and their order per entry are unchanged)
-    double li[FB_IV_NB], ac[FB_IV_NB];
-#pragma unroll
-    for (int r = 0; r < FB_IV_NB; ++r) ac[r] = (r == rr) ? 1.0 : 0.0;
-#pragma unroll
-    for (int q = 0; q < FB_IV_NB; ++q) {
-      li[q] = ac[q] * fb_readlane_f64(rinv_mine, q);
-#pragma unroll
-      for (int r = q + 1; r < FB_IV_NB; ++r) ac[r] = fma(-Dg[r * LD + q], li[q], ac[r]);
-    }
-    if (lane < FB_IV_NB) {
-#pragma unroll
-      for (int r = 0; r < FB_IV_NB; ++r) {
-        Di[r * LD + rr] = li[r];
-        Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = li[r];
-      }
-    }
-  };
-  // Right-looking blocked Cholesky with look-ahead: while the other waves apply panel j to the trailing
-  // matrix, wave 0 first updates the three 16x16 tiles of the NEXT diagonal block, then factors and
-  // inverts it -- the serial part runs in the shadow of the update.
-  if (wv == 0) factor_block(0, min(FB_IV_NB, R), 0);
-  __syncthreads();
-  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
-    const int nb = min(FB_IV_NB, R - j0);
-    // (b) panel below: X = A21 * L11^-T on the float64 matrix cores.  Wave = 16 rows: A fragment straight
-    //     from global A (lane l: row l % 16, column 4 q + l / 16), B fragment = L11^-1 from LDS (explicit
-    //     zeros above its diagonal), 2 column tiles x 8 steps.  Rows past the end contribute zeros, so the
-    //     panel copy in LDS is padded to a multiple of 16 rows for the update below.
-    const int m = R - j0 - nb;
-    const int mt16 = (m + 15) / 16;
-    for (int tI = wv; tI < mt16; tI += nw) {
-      const int i0 = 16 * tI;
-      const int ri = i0 + (lane & 15);
-      const bool rok = ri < m;
-      const double *arow = A + (size_t)(j0 + nb + (rok ? ri : 0)) * R + j0 + (lane >> 4);
-      fb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
-      double av[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {  // (unconditional load on a clamped address, then masked)
-        const int kk = 4 * q + (lane >> 4);
-        const double v = arow[kk < nb ? 4 * q : 0];
-        av[q] = (rok && kk < nb) ? v : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int kk = 4 * q + (lane >> 4);
-        const double b0v = Di[(lane & 15) * LD + kk], b1v = Di[(16 + (lane & 15)) * LD + kk];
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b0v, x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b1v, x1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr2 = i0 + (lane >> 4) + 4 * i, cc = lane & 15;
-        Lp[rr2 * LDP + cc] = x0[i];
-        Lp[rr2 * LDP + 16 + cc] = x1[i];
-        if (rr2 < m) {
-          double *ao = A + (size_t)(j0 + nb + rr2) * R + j0;
-          if (cc < nb) ao[cc] = x0[i];
-          if (16 + cc < nb) ao[16 + cc] = x1[i];
-        }
-      }
-    }
-    __syncthreads();
-    // (c) trailing update A22 -= L21 L21^T (lower triangle) in 16x16 tiles, 8 MFMAs each, both operands
-    //     from the LDS panel; the 4 results of a lane are 4 rows of one column, so 16 lanes write 128
-    //     contiguous bytes.  (Diagonal tiles also touch the strict upper triangle of A, which nothing reads.)
-    // NT tiles of one tile row at a time: their old values (global A, L2 latency) and column fragments
-    // are all requested before the first MFMA, the row fragment is loaded once.
-    auto update_tiles = [&](int tr, int tc0, int ntc) {  // tiles (tr, tc0 .. tc0 + ntc - 1), ntc <= 4
-      constexpr int NT = 4;
-      const double *lr = Lp + (size_t)(16 * tr + (lane & 15)) * LDP + (lane >> 4);
-      double af[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) af[q] = lr[4 * q];
-      double *cp[NT][4];
-      double cv[NT][4];
-      bool ok[NT][4];
-      double bf[NT][8];
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const int tc = tc0 + min(u, ntc - 1);
-        const int cc2 = 16 * tc + (lane & 15);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int rr2 = 16 * tr + (lane >> 4) + 4 * x;
-          ok[u][x] = u < ntc && rr2 < m && cc2 < m;
-          cp[u][x] = A + (size_t)(j0 + nb + (ok[u][x] ? rr2 : 0)) * R + j0 + nb + (ok[u][x] ? cc2 : 0);
-          cv[u][x] = *cp[u][x];
-        }
-        const double *lc = Lp + (size_t)(16 * tc + (lane & 15)) * LDP + (lane >> 4);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bf[u][q] = lc[4 * q];
-      }
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        fb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[u][q], acc, 0, 0, 0);
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-          if (ok[u][x]) *cp[u][x] = cv[u][x] - acc[x];
-      }
-    };
-    if (wv == 0) {
-      if (m > 0) {  // tiles (0,0), (1,0), (1,1) = the next diagonal block, then its factorisation
-        update_tiles(0, 0, 1);
-        if (mt16 > 1) update_tiles(1, 0, 2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the factor reads what other lanes just stored
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        factor_block(j0 + nb, min(FB_IV_NB, m), pi + 1);
-      }
-    } else {
-      // work items = (tile row tr >= 2, group of 4 column tiles); rows are dealt out longest first
-      int item = 0;
-      for (int tr = mt16 - 1; tr >= 2; --tr)
-        for (int tc0 = 0; tc0 <= tr; tc0 += 4, ++item)
-          if (item % (nw - 1) == wv - 1) update_tiles(tr, tc0, min(4, tr + 1 - tc0));
-    }
-    __syncthreads();
-  }
-  // ---- L y = rhs then L^T x = y, panel by panel, with the stored panel inverses
-  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
-    const int nb = min(FB_IV_NB, R - j0);
-    if (tid < FB_IV_NB) {
-      double y = 0.0;
-      if (tid < nb)
-        for (int q = 0; q <= tid; ++q) y = fma(Lg[((size_t)pi * FB_IV_NB + tid) * FB_IV_NB + q], rhs[j0 + q], y);
-      __builtin_amdgcn_wave_barrier();
-      if (tid < nb) Dg[tid] = y;
-    }
-    __syncthreads();
-    if (tid < nb) rhs[j0 + tid] = Dg[tid];
-    __syncthreads();
-    for (int i = j0 + nb + tid; i < R; i += nt) {
-      double v = rhs[i];
-      const double *arow = A + (size_t)i * R + j0;
-#pragma unroll 8
-      for (int q = 0; q < nb; ++q) v = fma(-arow[q], rhs[j0 + q], v);
-      rhs[i] = v;
-    }
-    __syncthreads();
-  }
-  for (int pi = npanel - 1; pi >= 0; --pi) {
-    const int j0 = pi * FB_IV_NB, nb = min(FB_IV_NB, R - j0);
-    if (tid < FB_IV_NB) {
-      double x = 0.0;
-      if (tid < nb)
-        for (int q = tid; q < nb; ++q) x = fma(Lg[((size_t)pi * FB_IV_NB + q) * FB_IV_NB + tid], rhs[j0 + q], x);
-      if (tid < nb) Dg[tid] = x;
-    }
-    __syncthreads();
-    if (tid < nb) rhs[j0 + tid] = Dg[tid];
-    __syncthreads();
-    for (int i = tid; i < j0; i += nt) {
-      double v = rhs[i];
-#pragma unroll 8
-      for (int q = 0; q < nb; ++q) v = fma(-A[(size_t)(j0 + q) * R + i], rhs[j0 + q], v);
-      rhs[i] = v;
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
-}
-// Default form of the solve: the same right-looking factorisation IN PLACE on the packed lower triangle the
-// contraction produced (no 1.3 MB dense copy per utterance: 126 us of unpacking gone), with the right-hand side
-// carried along as row R of the matrix so that the forward substitution falls out of the panel solves and the
-// trailing updates (another 50 us).  quad is consumed.
+// The factorisation runs IN PLACE on the packed lower triangle the contraction produced (a dense copy cost 126 us of
+// unpacking per batch), with the right-hand side carried along as row R of the matrix so that the forward
+// substitution falls out of the panel solves and the trailing updates (another 50 us).  quad is consumed.
 __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__restrict__ quad,
                                                    const double *__restrict__ linp, int n_kchunks, int B,
                                                    double *__restrict__ AugAll, double *__restrict__ LinvAll,
@@ -1219,9 +968,6 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
     aug[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
   }
   __syncthreads();
-#ifdef FB_SOLVE_PROBE_SETUP
-  if (R > 0) { for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = aug[r] * 1e-3; return; }  // timing probe only
-#endif
   // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
   // registers (lane = row for the factor, lane = column for the inverse; pivots and columns are broadcast
   // with v_readlane).  Leaves L11 in Dg and in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
@@ -1393,9 +1139,6 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
     }
     __syncthreads();
   }
-#ifdef FB_SOLVE_PROBE_CHOL
-  if (R > 0) { for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = aug[r] * 1e-3; return; }  // timing probe only
-#endif
   // ---- the augmented row now holds y = L^-1 rhs; L^T x = y panel by panel with the stored panel inverses
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
@@ -1442,16 +1185,11 @@ void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, co
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (fb_device_needs_optin(optin, &bit)) {  // > 64 KiB of dynamic LDS needs the opt-in, once per device
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     if (ok) optin.fetch_or(bit, std::memory_order_release);  // a failed opt-in surfaces as a launch error (hipGetLastError in run_scoring)
   }
-  static const char *mode = getenv("FB_IV_SOLVE");
-  if (mode && strcmp(mode, "dense") == 0)  // predecessor: dense copy + separate forward substitution (585 us vs 455 us)
-    hipLaunchKernelGGL(k_iv_solve, dim3(B), dim3(512), shm, s, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
-  else  // default: in place on the packed triangle (quad is consumed), right-hand side carried as an extra row
-    hipLaunchKernelGGL(k_iv_solve_packed, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
-                       LinvAll, ivec, fail);
+  hipLaunchKernelGGL(k_iv_solve_packed, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
+                     LinvAll, ivec, fail);
 }
 
 // ------------------------------------------------------ back-end (K11/K12)

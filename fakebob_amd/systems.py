@@ -14,6 +14,21 @@ from .engine import Engine
 from .kaldi_io import load_gmm_any
 
 
+def _pipeline_options(text_scores, compress_feats):
+    """The two round trips the reference's pipeline takes through files and the engine reproduces on request:
+    text_scores (Kaldi prints scores with 6 significant digits and the helpers parse that text) and compress_feats
+    (make_mfcc.sh stores the MFCCs through Kaldi's lossy CompressedMatrix).  Constructor keywords win over the
+    FB_TEXT_SCORES / FB_COMPRESS_FEATS environment variables; both default to off (fakebob_amd/dropin/README.md)."""
+    out = {}
+    ts = text_scores if text_scores is not None else os.environ.get("FB_TEXT_SCORES", "0") == "1"
+    cf = compress_feats if compress_feats is not None else os.environ.get("FB_COMPRESS_FEATS", "0") == "1"
+    if ts:
+        out["text_scores"] = 1
+    if cf:
+        out["compress_feats"] = 1
+    return out
+
+
 def default_device():
     return int(os.environ.get("FAKEBOB_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
@@ -34,7 +49,8 @@ def _to_audio_list(audios):
 class _GmmSystem(object):
     task = None
 
-    def _setup(self, group_id, models, spk_ids, utt_ids, locations, z_means, z_stds, pre_model_dir, engine):
+    def _setup(self, group_id, models, spk_ids, utt_ids, locations, z_means, z_stds, pre_model_dir, engine,
+               text_scores=None, compress_feats=None):
         self.pre_model_dir = os.path.abspath(pre_model_dir)
         self.group_id = os.path.abspath(group_id)
         self.spk_ids = spk_ids
@@ -47,10 +63,7 @@ class _GmmSystem(object):
         if os.path.isdir(conf):
             from .config import frontend_from_kaldi_conf
             over = frontend_from_kaldi_conf(self.pre_model_dir)
-        if os.environ.get("FB_TEXT_SCORES", "0") == "1":   # reproduce the 6-digit text round trip of Kaldi's scores
-            over = dict(over, text_scores=1)
-        if os.environ.get("FB_COMPRESS_FEATS", "0") == "1":  # make_mfcc.sh's lossy `copy-feats --compress=true`
-            over = dict(over, compress_feats=1)
+        over = dict(over, **_pipeline_options(text_scores, compress_feats))
         if over:
             self._engine.set_frontend(**over)
         self._engine.load_gmm(models)
@@ -76,13 +89,14 @@ class gmm_OSI(_GmmSystem):
     """gmm_ubm_OSI.py:13-112"""
     task = "OSI"
 
-    def __init__(self, group_id, model_list, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None):
+    def __init__(self, group_id, model_list, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None,
+                 text_scores=None, compress_feats=None):
         self.threshold = threshold
         locs = [m[2] for m in model_list]
         self.model_list = [ubm] + locs  # UBM first (gmm_ubm_OSI.py:45)
         models = [load_gmm_any(x) for x in self.model_list]
         self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs, None, None,
-                    pre_model_dir, engine)
+                    pre_model_dir, engine, text_scores, compress_feats)
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
         raw = self._raw(audios, bits_per_sample)
@@ -107,14 +121,15 @@ class gmm_CSI(_GmmSystem):
     """gmm_ubm_CSI.py:13-110 -- no UBM, z-normalised raw log-likelihoods."""
     task = "CSI"
 
-    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None):
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, text_scores=None,
+                 compress_feats=None):
         locs = [m[2] for m in model_list]
         self.model_list = locs
         self.z_norm_means = np.array([m[3] for m in model_list], np.float64)
         self.z_norm_stds = np.array([m[4] for m in model_list], np.float64)
         models = [load_gmm_any(x) for x in locs]
         self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs,
-                    self.z_norm_means, self.z_norm_stds, pre_model_dir, engine)
+                    self.z_norm_means, self.z_norm_stds, pre_model_dir, engine, text_scores, compress_feats)
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
         raw = self._raw(audios, bits_per_sample)
@@ -135,13 +150,15 @@ class gmm_SV(_GmmSystem):
     """gmm_ubm_SV.py:13-92 -- one enrolled speaker against the UBM."""
     task = "SV"
 
-    def __init__(self, spk_id, model, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None):
+    def __init__(self, spk_id, model, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None,
+                 text_scores=None, compress_feats=None):
         self.threshold = threshold
         self.utt_id = model[1]
         self.identity_location = model[2]
         self.model_list = [ubm, self.identity_location]
         models = [load_gmm_any(x) for x in self.model_list]
-        self._setup(spk_id, models, [model[0]], [model[1]], [model[2]], None, None, pre_model_dir, engine)
+        self._setup(spk_id, models, [model[0]], [model[1]], [model[2]], None, None, pre_model_dir, engine,
+                    text_scores, compress_feats)
         self.spk_id = self.group_id
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
@@ -162,7 +179,7 @@ class gmm_SV(_GmmSystem):
 class _IvSystem(object):
     task = None
 
-    def _setup(self, group_id, model_list, pre_model_dir, engine, system):
+    def _setup(self, group_id, model_list, pre_model_dir, engine, system, text_scores=None, compress_feats=None):
         from .models import IvectorSystem
         self.pre_model_dir = os.path.abspath(pre_model_dir)
         self.group_id = os.path.abspath(group_id)
@@ -193,15 +210,15 @@ class _IvSystem(object):
             if os.path.isdir(conf):
                 from .config import frontend_from_kaldi_conf
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
-            if os.environ.get("FB_TEXT_SCORES", "0") == "1":
-                over = dict(over, text_scores=1)
-            if os.environ.get("FB_COMPRESS_FEATS", "0") == "1":
-                over = dict(over, compress_feats=1)
+            over = dict(over, **_pipeline_options(text_scores, compress_feats))
             if over:
                 self._engine.set_frontend(**over)
             d = load_ivector_pre_models(self.pre_model_dir)
             system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
         else:
+            over = _pipeline_options(text_scores, compress_feats)
+            if over:
+                self._engine.set_frontend(**over)
             system = system.with_enrolled(enrolled, zm, zs)
         self._engine.load_ivector(system, self.task)
 
@@ -224,9 +241,10 @@ class iv_OSI(_IvSystem):
     """ivector_PLDA_OSI.py:16-143"""
     task = "OSI"
 
-    def __init__(self, group_id, model_list, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None):
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None,
+                 text_scores=None, compress_feats=None):
         self.threshold = threshold
-        self._setup(group_id, model_list, pre_model_dir, engine, system)
+        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats)
 
     def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
         s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds   # :119
@@ -253,8 +271,9 @@ class iv_CSI(_IvSystem):
     """ivector_PLDA_CSI.py:18-135"""
     task = "CSI"
 
-    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, system=None):
-        self._setup(group_id, model_list, pre_model_dir, engine, system)
+    def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, system=None, text_scores=None,
+                 compress_feats=None):
+        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats)
 
     def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
         s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds
@@ -276,9 +295,10 @@ class iv_SV(_IvSystem):
     """ivector_PLDA_SV.py:20-110"""
     task = "SV"
 
-    def __init__(self, spk_id, model, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None):
+    def __init__(self, spk_id, model, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None,
+                 text_scores=None, compress_feats=None):
         self.threshold = threshold
-        self._setup(spk_id, [model], pre_model_dir, engine, system)
+        self._setup(spk_id, [model], pre_model_dir, engine, system, text_scores, compress_feats)
         self.spk_id = self.group_id
         self.utt_id = model[1]
         self.identity_location = model[2]

@@ -20,6 +20,9 @@
  *   fb_get_grad               FakeBob.get_grad + loss_fn (FAKEBOB.py:223-299)
  *   fb_attack                 FakeBob.attack (FAKEBOB.py:139-221)
  *   fb_estimate_threshold     FakeBob.estimate_threshold (FAKEBOB.py:39-137)
+ *   fb_get_grad_ext / fb_attack_ext   the same around a foreign `model` (README.md:136)
+ *
+ * Test / profiling hooks (no reference counterpart) live in fakebob_hip_test.h.
  *
  * Conventions: plain pointers and sizes, host memory unless a name ends in
  * _dev; every function returns 0 on success or a negative FB_E_* code and
@@ -214,19 +217,10 @@ int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, v
                   const double *audio, int64_t N, const double *noise_all, int16_t *adv_i16,
                   double *adver_f64, double *trace, int *n_trace, int *success_flag);
 
-/* --- test / profiling hooks (stable, used by tests/ and bench.py) ------- */
-/* z[half*N] float32 from the device Philox/Box-Muller (bit-exact contract) */
-int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32_t stream,
-                   int64_t N, int half, float *z);
-/* the device int16 cast of model.score's float input (gmm_ubm_OSI.py:83-85) */
-int fb_debug_quantize(fb_engine *e, const double *x, int64_t n, int bits_per_sample, int16_t *q);
-/* front-end only: MFCC [T*num_ceps] of one utterance */
-int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T);
-/* compacted voiced CMVN'd features of one utterance: feats[Tv*dim] */
-int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
-                   int *Tv, int *T);
-/* i-vectors [B*R] (float64, prior offset removed) of the last scored batch */
-int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
+/* Work counters since engine creation: what the driver reduces over ranks next to the success counter
+ * (attackMain.py:312,411 keeps success_cnt / total_cnt only). */
+int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames,
+             int64_t *voiced_frames, int64_t *nes_iters);
 
 /* ---- enrolment (build_spk_models.py) ------------------------------------------
  * fb_gmm_acc_stats replaces `gmm-global-acc-stats --update-flags=m final.dubm feats acc`
@@ -238,30 +232,6 @@ int fb_debug_ivectors(fb_engine *e, int B, double *ivecs);
  * last with an i-vector system: the enrolment identity of ivector_PLDA (build_spk_models.py:104-150). */
 int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, double *occ, double *F, int *tv_out);
 int fb_last_ivectors(fb_engine *e, int B, double *ivecs);
-
-/* Which diagonal-GMM kernel the loaded model runs on: 2 = k_gmm_fx2 (two-term f16 split, default),
- * 1 = k_gmm_bx3 (three-term bf16 split; FB_GMM_MODE=bx3, or chosen automatically when a parameter does not
- * fit f16's exponent range), 0 = k_gmm (plain f32 MFMA; FB_GMM_MODE=f32).  Negative FB_E_* without a model.
- * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
-int fb_gmm_kernel_mode(fb_engine *e);
-
-/* number of UBM components that received posterior mass in the last i-vector batch (only their
- * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
-int fb_debug_iv_active(fb_engine *e, int *n_active);
-/* counters since engine creation */
-int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_frames,
-             int64_t *voiced_frames, int64_t *nes_iters);
-/* time `reps` back-to-back launches of the GMM log-likelihood kernel on the
- * engine's stream with HIP events over the current device feature buffer
- * (filled by the last score/get_grad call). ms_avg out. */
-int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64_t *rows);
-/* run `iters` NES iterations (get_grad + update, early stop disabled) on the
- * device without host round trips; returns elapsed ms (HIP events) and the
- * accumulated time of the GMM kernel alone (events around each launch when
- * time_gmm != 0). */
-int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *audio,
-                 int64_t N, int warmup, int iters, int time_gmm,
-                 double *ms_total, double *ms_gmm, int64_t *voiced_rows);
 
 #ifdef __cplusplus
 }

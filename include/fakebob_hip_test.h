@@ -1,0 +1,52 @@
+/*
+ * fakebob_hip_test.h -- test / profiling hooks of libfakebob_hip.so.
+ *
+ * Not part of the drop-in boundary (include/fakebob_hip.h): these entry points have no counterpart in the
+ * reference.  tests/ use them to compare intermediate stages with the oracle (noise stream, int16 cast, MFCC,
+ * compacted features), bench.py to time the dominant kernel and a run of NES iterations without host round
+ * trips.  Same conventions as fakebob_hip.h (0 / negative FB_E_* + fb_last_error()).
+ */
+#ifndef FAKEBOB_HIP_TEST_H
+#define FAKEBOB_HIP_TEST_H
+#include "fakebob_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* z[half*N] float32 from the device Philox/Box-Muller (bit-exact contract) */
+int fb_debug_noise(fb_engine *e, uint64_t seed, uint32_t iter, uint32_t stream,
+                   int64_t N, int half, float *z);
+/* the device int16 cast of model.score's float input (gmm_ubm_OSI.py:83-85) */
+int fb_debug_quantize(fb_engine *e, const double *x, int64_t n, int bits_per_sample, int16_t *q);
+/* front-end only: MFCC [T*num_ceps] of one utterance */
+int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T);
+/* compacted voiced CMVN'd features of one utterance: feats[Tv*dim] */
+int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
+                   int *Tv, int *T);
+
+/* Which diagonal-GMM arithmetic the loaded model runs on: 2 = two-term f16 split (k_gmm_fx2w / k_gmm_fx2, default),
+ * 1 = exact three-term bf16 split (k_gmm_bx3: chosen automatically when a parameter does not fit f16's exponent
+ * range; FB_GMM_MODE=bx3 forces it).  Negative FB_E_* without a model.
+ * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
+int fb_gmm_kernel_mode(fb_engine *e);
+
+/* number of UBM components that received posterior mass in the last i-vector batch (only their
+ * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
+int fb_debug_iv_active(fb_engine *e, int *n_active);
+/* time `reps` back-to-back launches of the GMM log-likelihood kernel on the
+ * engine's stream with HIP events over the current device feature buffer
+ * (filled by the last score/get_grad call). ms_avg out. */
+int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64_t *rows);
+/* run `iters` NES iterations (get_grad + update, early stop disabled) on the
+ * device without host round trips; returns elapsed ms (HIP events) and the
+ * accumulated time of the GMM kernel alone (events around each launch when
+ * time_gmm != 0). */
+int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *audio,
+                 int64_t N, int warmup, int iters, int time_gmm,
+                 double *ms_total, double *ms_gmm, int64_t *voiced_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -49,10 +49,12 @@ def test_frontend_and_scores_for_other_configs(oracle, over):
         e.close()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bx3"])
-def test_other_gmm_kernels_still_match(oracle, monkeypatch, mode):
-    """The default is k_gmm_fx2; the exact bf16x3 kernel and the plain f32 MFMA kernel stay selectable."""
-    monkeypatch.setenv("FB_GMM_MODE", mode)
+@pytest.mark.parametrize("mode,env", [("bx3", {"FB_GMM_MODE": "bx3"}), ("fx2", {"FB_GMM_NARROW": "1"})])
+def test_other_gmm_kernels_still_match(oracle, monkeypatch, mode, env):
+    """The default scoring kernel is k_gmm_fx2w; the general two-term kernel (k_gmm_fx2: any number of variance
+    groups, partial tiles, the gselect dump) and the exact bf16x3 fallback stay selectable and correct."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     e = Engine(0)
     try:
         ubm, spk = synthetic_gmm_system(n_speakers=3, C=256, D=72)
@@ -226,25 +228,43 @@ def test_empty_and_degenerate_batches_are_errors_not_crashes():
         e.close()
 
 
-def test_one_frame_per_wave_mfcc_kernel_still_matches(oracle, monkeypatch):
-    """k_mfcc_r16 (four frames per wave, radix-16 passes in registers) is the default for 512-point frames;
-    FB_MFCC=r4 selects its predecessor k_mfcc_r4.  Both against the oracle, and against each other."""
+def test_generic_mfcc_kernel_matches_the_fast_one(oracle):
+    """k_mfcc_r16 (four frames per wave, radix-16 passes in registers) handles 512-point frames with an even
+    frame length; any other front-end runs on the generic k_mfcc.  A 401-sample frame (25.0625 ms) takes the generic
+    kernel, a 400-sample frame the fast one: both against the oracle."""
+    for flen in (400, 401):
+        e = Engine(0)
+        try:
+            e.set_frontend(frame_length=flen)
+            cfg = oracle.default_cfg(frame_length=flen)
+            for utt, n in ((0, 48000), (1, 9000), (4, 100000)):
+                w = _wav(utt, n)
+                mo = oracle.mfcc(cfg, w)
+                mg = e.debug_mfcc(w)
+                assert mg.shape == mo.shape
+                assert np.abs(mg.astype(np.float64) - mo).max() <= 2e-5
+        finally:
+            e.close()
+
+
+def test_pipeline_round_trips_are_constructor_options(tmp_path, oracle):
+    """text_scores / compress_feats (the two file round trips of the reference's pipeline) are constructor keywords of
+    the systems, not only environment variables: gmm_SV(text_scores=True) returns scores that are differences of
+    6-significant-digit values, equal to the oracle's with the same option."""
+    from fakebob_amd.systems import gmm_SV
+    ubm, spk = synthetic_gmm_system(n_speakers=1, C=96, D=72)
+    ml = ["spk0", "utt0", spk[0], 0.0, 1.0]
     e = Engine(0)
     try:
-        ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
-        e.load_gmm([ubm] + spk)
-        cfg = oracle.default_cfg()
-        for utt, n in ((0, 48000), (1, 9000), (4, 100000)):
-            w = _wav(utt, n)
-            mo = oracle.mfcc(cfg, w)
-            monkeypatch.delenv("FB_MFCC", raising=False)
-            m16 = e.debug_mfcc(w)
-            monkeypatch.setenv("FB_MFCC", "r4")
-            m4 = e.debug_mfcc(w)
-            assert m16.shape == mo.shape == m4.shape
-            assert np.abs(m16.astype(np.float64) - mo).max() <= 2e-5
-            assert np.abs(m4.astype(np.float64) - mo).max() <= 2e-5
-            assert np.array_equal(m16[:, 0], m4[:, 0])            # C0 = log energy: no FFT involved
-            assert np.abs(m16 - m4).max() <= 2e-5
+        audio = synthetic_audio(2, 16000)
+        plain = gmm_SV(str(tmp_path / "a"), ml, ubm, pre_model_dir=str(tmp_path), engine=e)
+        s_plain = float(plain.score(audio))
+        txt = gmm_SV(str(tmp_path / "b"), ml, ubm, pre_model_dir=str(tmp_path), engine=e, text_scores=True)
+        s_txt = float(txt.score(audio))
+        gc, miv, iv = stack_models([ubm, spk[0]])
+        raw_o, _ = oracle.gmm_score_batch(oracle.default_cfg(text_scores=1), [_wav(2, 16000)], gc, miv, iv)
+        assert s_txt == raw_o[0, 1] - raw_o[0, 0]
+        assert s_txt != s_plain and abs(s_txt - s_plain) < 2e-3
     finally:
+        e.set_frontend(text_scores=0)
         e.close()

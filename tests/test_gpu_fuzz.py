@@ -26,7 +26,7 @@ def test_gmm_path_random_shapes(oracle, monkeypatch, seed):
         C = int(rng.choice([17, 33, 64, 100, 256]))
         S = int(rng.integers(2, 8))
         B = int(rng.choice([1, 3, 7, 16]))
-        mode = str(rng.choice(["fx2", "fx2", "bx3", "f32"]))
+        mode = str(rng.choice(["fx2", "fx2", "fx2", "bx3"]))
         monkeypatch.setenv("FB_GMM_MODE", mode)
         cfg = oracle.default_cfg(**over)
         e = Engine(0)
