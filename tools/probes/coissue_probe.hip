@@ -176,6 +176,33 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, long long *cyc, int 
       PHASE12(accA, accB, pvA, pvB, a, a2, 0)
       PHASE12(pvA, pvB, accA, accB, a2, a, 1)
       ++it;
+    } else if (MODE == 16 || MODE == 17) {
+      // 16: mode 9 with asm MFMAs -- accumulators in VGPRs, B operands read from AGPRs -- + s_nop 10 behind the block
+      // 17: the same block with builtin MFMAs (reference for the checksum)
+#define AMF(A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(C) : "v"(A), "a"(B))
+#define AMF0(A, B, C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(C) : "v"(A), "a"(B))
+#define PHASE16(XA, XB, YA, YB)                                                                                \
+      {                                                                                                        \
+        _Pragma("unroll") for (int c = 0; c < 5; ++c) {                                                         \
+          if (MODE == 16) {                                                                                    \
+            if (c == 0) { AMF0(a[c], b[c], XA); AMF0(a[c], b[(c + 3) % 5], XB); }                               \
+            else { AMF(a[c], b[c], XA); AMF(a[c], b[(c + 3) % 5], XB); }                                        \
+            AMF(a[c], b[(c + 1) % 5], XA); AMF(a[(c + 1) % 5], b[c], XB); AMF(a[(c + 2) % 5], b[c], XA); AMF(a[(c + 4) % 5], b[c], XB); \
+          } else {                                                                                             \
+            if (c == 0) { XA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[c], zero, 0, 0, 0);               \
+                          XB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[(c + 3) % 5], zero, 0, 0, 0); }   \
+            else { MF(a[c], b[c], XA); MF(a[c], b[(c + 3) % 5], XB); }                                          \
+            MF(a[c], b[(c + 1) % 5], XA); MF(a[(c + 1) % 5], b[c], XB); MF(a[(c + 2) % 5], b[c], XA); MF(a[(c + 4) % 5], b[c], XB); \
+          }                                                                                                    \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        lse16_pk(YA, m0, s0, ls); lse16_pk(YB, m1, s1, ls);                                                    \
+        if (MODE == 16) asm volatile("s_nop 10" : "+v"(XA), "+v"(XB));                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      }
+      PHASE16(accA, accB, pvA, pvB)
+      PHASE16(pvA, pvB, accA, accB)
+      ++it;
     } else if (MODE == 4) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) {
@@ -210,9 +237,11 @@ void run(const char *name, int blocks, int iters) {
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   long long h[4]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  float ho[256]; hipMemcpy(ho, out, sizeof(ho), hipMemcpyDeviceToHost);
+  double cs = 0; for (int i = 0; i < 256; ++i) cs += ho[i];
   const double phases = (double)iters;
-  printf("%-44s blocks %4d (%d waves/SIMD): %.3f ms, %lld cycles -> %.0f cycles/phase (30 MFMA + 2 epilogues); clock %.2f GHz\n", name, blocks,
-         blocks * 4 / 1024, ms, h[0], h[0] / phases, h[0] / (ms * 1e6));
+  printf("%-44s blocks %4d (%d waves/SIMD): %.3f ms, %lld cycles -> %.0f cycles/phase (30 MFMA + 2 epilogues); clock %.2f GHz; checksum %.6e\n", name, blocks,
+         blocks * 4 / 1024, ms, h[0], h[0] / phases, h[0] / (ms * 1e6), cs);
   hipFree(out); hipFree(cyc);
 }
 int main() {
@@ -233,6 +262,8 @@ int main() {
     run<13>("13 = 12 + A operands prefetched from LDS", b, 2000);
     run<14>("14 = 13 + 3 LDS-DMA pieces per phase (after MFMAs)", b, 2000);
     run<15>("15 = 13 + 3 LDS-DMA pieces per phase (before MFMAs)", b, 2000);
+    run<16>("16 = 9 with asm MFMAs (acc VGPR, B from AGPR)", b, 2000);
+    run<17>("17 = 9 again (builtin; checksum reference)", b, 2000);
   }
   return 0;
 }
