@@ -102,6 +102,9 @@ struct fb_engine {
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
   DevBuf frame_rec, vad_counter, vad_pub, fin_counter, ctl, ctl_ls, trace_dev, enr_ll, enr_aux, enr_stats;
+  long long bench_it = -1;  // fb_bench_nes: next iteration index of the attack left resident (-1: none)
+  int64_t bench_N = 0;
+  int bench_B = 0;
   long long pre_iter = -1;  // >= 0: wav / zbuf / dist_part already hold the NES batch of this iteration (k_update_perturb)
   int pre_ndp = 0;
   bool defer_finalize = false;  // run_scoring leaves the GMM finalisation to the fused finalize + loss launch
@@ -588,6 +591,7 @@ extern "C" int fb_num_speakers(fb_engine *e) {
 // ------------------------------------------------------- scoring pipeline
 // Prepares offsets for a batch whose int16 samples are already in e->wav.
 static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
+  e->bench_it = -1;  // whatever attack fb_bench_nes left resident is gone with the batch layout
   e->h_wav_off.assign(off, off + B + 1);
   e->h_frame_off.resize(B + 1);
   e->h_chunk_off.resize(B + 1);
@@ -1317,6 +1321,7 @@ static int fetch_out(fb_engine *e) {
 extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *audio, int64_t N, uint32_t iter,
                            const double *noise_pos, double *final_loss, double *grad, double *adver_loss,
                            double *score0) {
+  if (e) e->bench_it = -1;
   if (!audio) return fb_fail(FB_E_ARG, "audio is NULL");
   FBCHK(check_params(e, p, N));
   HIPCHK(hipSetDevice(e->device));
@@ -1413,6 +1418,7 @@ static int enqueue_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_
 extern "C" int fb_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
                                const double *audio, int64_t N, uint32_t iter, const double *noise_pos,
                                double *final_loss, double *grad, double *adver_loss, double *score0) {
+  if (e) e->bench_it = -1;
   if (!audio) return fb_fail(FB_E_ARG, "audio is NULL");
   FBCHK(check_params_ext(e, p, N, S, cb));
   HIPCHK(hipSetDevice(e->device));
@@ -1442,6 +1448,7 @@ extern "C" int fb_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_s
 extern "C" int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
                              const double *audio, int64_t N, const double *noise_all, int16_t *adv_i16,
                              double *adver_f64, double *trace, int *n_trace, int *success_flag) {
+  if (e) e->bench_it = -1;
   if (!audio || !adv_i16 || !success_flag) return fb_fail(FB_E_ARG, "null argument");
   FBCHK(check_params_ext(e, p, N, S, cb));
   if (p->max_iter <= 0) return fb_fail(FB_E_ARG, "max_iter must be > 0");
@@ -1519,6 +1526,7 @@ struct Plateau {  // FAKEBOB.py:195-200
 extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *audio, int64_t N,
                          const double *noise_all, int16_t *adv_i16, double *adver_f64, double *trace,
                          int *n_trace, int *success_flag) {
+  if (e) e->bench_it = -1;
   if (!audio || !adv_i16 || !success_flag) return fb_fail(FB_E_ARG, "null argument");
   FBCHK(check_params(e, p, N));
   if (p->max_iter <= 0) return fb_fail(FB_E_ARG, "max_iter must be > 0");
@@ -1558,6 +1566,7 @@ extern "C" int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p_in, do
                                      const double *audio, int64_t N, const double *noise_all, int max_total_iters,
                                      double *score_out, int *n_iters_out, int *n_outer_out, double *thr_final,
                                      double *adver_f64) {
+  if (e) e->bench_it = -1;
   if (!audio || !score_out) return fb_fail(FB_E_ARG, "null argument");
   if (!p_in) return fb_fail(FB_E_ARG, "null params");
   if (p_in->task == FB_TASK_CSI) return fb_fail(FB_E_ARG, "no threshold to estimate for CSI (FAKEBOB.py:41-43)");
@@ -1791,21 +1800,33 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
   FBCHK(check_params(e, p, N));
   HIPCHK(hipSetDevice(e->device));
   const int half = p->samples_per_draw / 2, B = 2 * half + 1;
-  FBCHK(prepare_nes_batch(e, N, B));
-  FBCHK(ensure_nes_buffers(e, N, B));
-  FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
-  HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
-  HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
+  const bool resume = warmup < 0;  // continue the attack a previous call left on the device: nothing is uploaded or reset
+  if (resume) {
+    if (e->bench_N != N || e->bench_B != B || e->bench_it < 0)
+      return fb_fail(FB_E_STATE, "fb_bench_nes(warmup < 0): no attack of this shape is resident on the engine");
+    warmup = 0;
+  } else {
+    FBCHK(prepare_nes_batch(e, N, B));
+    FBCHK(ensure_nes_buffers(e, N, B));
+    FBCHK(h2d(e, e->audio.p, audio, sizeof(double) * (size_t)N));
+    HIPCHK(hipMemcpyAsync(e->adver.p, e->audio.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->grad_m.p, 0, sizeof(double) * (size_t)N, e->stream));
+    e->bench_it = 0;
+  }
   double gmm_ms = 0.0;
   int64_t vrows = 0;
   // identical work to fb_attack's loop (early stop disabled for timing)
-  FBCHK(run_attack_core(e, p, N, nullptr, 0, warmup > 0 ? warmup : 0, true, true, nullptr));
+  if (!resume) FBCHK(run_attack_core(e, p, N, nullptr, 0, warmup, true, true, nullptr));
+  const int it0 = (int)e->bench_it + warmup;
   FBCHK(sync_stream(e));
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   e->time_gmm = time_gmm != 0;
   e->gmm_ms_acc = 0.0;
   e->gmm_launches = 0;
-  FBCHK(run_attack_core(e, p, N, nullptr, warmup > 0 ? warmup : 0, iters, warmup <= 0, true, nullptr));
+  FBCHK(run_attack_core(e, p, N, nullptr, it0, iters, false, true, nullptr));
+  e->bench_it = it0 + iters;
+  e->bench_N = N;
+  e->bench_B = B;
   e->nes_iters += warmup + iters;
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from fakebob_amd.engine import Engine, nes_params
-from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+from fakebob_amd.models import stack_models, synthetic_audio, synthetic_gmm_system, synthetic_ivector_system
 
 pytestmark = pytest.mark.gpu
 
@@ -97,5 +97,53 @@ def test_ivector_scores_do_not_depend_on_batch_composition():
         assert np.array_equal(llr_p, llr_all[perm])             # no atomics anywhere: bit-identical
         llr_1, _ = e.score_raw([wavs[1]])
         assert np.abs(llr_1[0] - llr_all[1]).max() <= 1e-6      # (other chunking of the diagonal pre-selection)
+    finally:
+        e.close()
+
+
+def test_fused_and_unfused_launch_chains_are_bit_identical(monkeypatch):
+    """The 5-launch NES chain (k_update_perturb, k_vad_delta_cmvn, k_gmm_finalize_loss) and the 8-launch chain
+    (FB_NO_FUSE=1) run the same arithmetic in the same orders: adversarial audio, float64 state and the whole trace
+    must be bit-identical, early stop included."""
+    ubm, spk = synthetic_gmm_system(n_speakers=3, C=128, D=72)
+    audio = synthetic_audio(9, 16000)
+    outs = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("FB_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("FB_NO_FUSE", raising=False)
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            e.set_system("OSI")
+            s0 = e.system_scores(e.score_raw([(audio * 32768).astype(np.int16)])[0])[0]
+            for kw in (dict(max_iter=9, threshold=float(s0.max()) + 0.5, target=int(np.argmin(s0))),     # runs to max_iter
+                       dict(max_iter=40, threshold=float(s0.min()) - 1.0, target=int(np.argsort(s0)[1]))):  # stops early
+                p = nes_params("OSI", "targeted", samples_per_draw=12, seed=17, stream=2, **kw)
+                outs.append(e.attack(p, audio))
+        finally:
+            e.close()
+    for a, b in zip(outs[:2], outs[2:]):
+        assert a[1] == b[1] and a[3].shape == b[3].shape
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert outs[1][3].shape[0] < 40                      # the second attack really stopped early
+
+
+def test_more_utterances_than_compute_units(oracle):
+    """700 short utterances in one scoring batch: k_vad_delta_cmvn's workgroups (one per utterance, indices from a
+    ticket, row offsets from the published counts of all earlier utterances) cannot all be resident at once."""
+    ubm, spk = synthetic_gmm_system(n_speakers=2, C=64, D=72)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        wavs = [(synthetic_audio(u % 11, 4000 + 160 * (u % 13)) * (0.4 + 0.05 * (u % 9)) * 32768).astype(np.int16)
+                for u in range(700)]
+        for _ in range(2):                                # twice: the epoch tags of the first launch are stale now
+            raw_g, tv_g = e.score_raw(wavs)
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, tv_o = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=16)
+        assert np.array_equal(tv_g, tv_o)
+        assert np.abs(raw_g - raw_o).max() <= 1e-4
     finally:
         e.close()
