@@ -489,7 +489,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
           }
         }
       }
-    FBCHK(e->gmm_images_fx.ensure(sizeof(uint16_t) * fx.size()));
+    FBCHK(e->gmm_images_fx.ensure(sizeof(uint16_t) * fx.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
     HIPCHK(hipMemcpy(e->gmm_images_fx.p, fx.data(), sizeof(uint16_t) * fx.size(), hipMemcpyHostToDevice));
   }
   if (mode == FB_GMM_MODE_BX3) {

@@ -584,6 +584,44 @@ __device__ __forceinline__ void fb_glds16(const void *gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// N (1 .. 4) consecutive 1 KB pieces with one M0 set-up: the instruction offset moves the global source AND the LDS
+// destination (tools/probes/glds_offset_probe.hip)
+template <int N>
+__device__ __forceinline__ void fb_glds16_run(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+#define FB_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+#define FB_GLDS_AT(o) "global_load_lds_dwordx4 %1, off offset:" #o "\n\t"
+#define FB_GLDS_TAIL "s_mov_b32 m0, %0"
+  if constexpr (N == 1)
+    asm volatile(FB_GLDS_HEAD FB_GLDS_TAIL : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if constexpr (N == 2)
+    asm volatile(FB_GLDS_HEAD FB_GLDS_AT(1024) FB_GLDS_TAIL : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if constexpr (N == 3)
+    asm volatile(FB_GLDS_HEAD FB_GLDS_AT(1024) FB_GLDS_AT(2048) FB_GLDS_TAIL : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile(FB_GLDS_HEAD FB_GLDS_AT(1024) FB_GLDS_AT(2048) FB_GLDS_AT(3072) FB_GLDS_TAIL
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#undef FB_GLDS_HEAD
+#undef FB_GLDS_AT
+#undef FB_GLDS_TAIL
+}
+// A group of NITEMS consecutive parameter items (NPIECE KB each, contiguous in the image buffer) -> LDS: wave wv brings
+// the pieces [wv PW, (wv + 1) PW), PW = ceil(total / 4) -- up to 3 pieces past the group's end when the total is not
+// a multiple of four (the slots are padded for them, the image buffer is allocated 4 KB longer).
+template <int NITEMS, int NPIECE>
+__device__ __forceinline__ void fb_fxw_fetch(const u32x4 *__restrict__ group_lane, unsigned lds_dst, int wv) {
+  constexpr int TOT = NITEMS * NPIECE, PW = (TOT + 3) / 4;
+  const u32x4 *src = group_lane + (size_t)wv * (PW * 64);
+  const unsigned dst = lds_dst + (unsigned)wv * (PW * 1024);
+#pragma unroll
+  for (int u = 0; u < PW; u += 4) {
+    const int n = PW - u;
+    if (n >= 4) fb_glds16_run<4>(src + u * 64, dst + u * 1024);
+    else if (n == 3) fb_glds16_run<3>(src + u * 64, dst + u * 1024);
+    else if (n == 2) fb_glds16_run<2>(src + u * 64, dst + u * 1024);
+    else fb_glds16_run<1>(src + u * 64, dst + u * 1024);
+  }
+}
 
 template <int NK>
 __device__ __forceinline__ void fb_fxw_frags(const u32x4 *__restrict__ cur4, int lane, u32x4 (&a1)[NK], u32x4 (&a2)[NK]) {
@@ -613,6 +651,142 @@ __device__ __forceinline__ void fb_fxw_pair(const u32x4 (&a1)[NK], const u32x4 (
   out1 = x1;
 }
 
+// Single vector instructions, pinned where they are written (volatile): the update slices below must stay in their
+// MFMA gaps, and they must NOT be packed -- a v_pk_fma_f32 / v_pk_add_f32 behind an MFMA costs the wave ~4 ns where
+// four plain v_fma_f32 are free (tools/probes/valu_cost_probe.hip).
+__device__ __forceinline__ float fb_v_fma(float a, float b, float c) {
+  float d;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fb_v_exp(float a) {  // 2^a; its consumer stands at least one gap later (no trans hazard)
+  float d;
+  asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a));
+  return d;
+}
+__device__ __forceinline__ float fb_v_add(float a, float b) {
+  float d;
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float fb_v_mul(float a, float b) {
+  float d;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float fb_v_max3(float a, float b, float c) {
+  float d;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// One item step with the logsumexp update of ANOTHER accumulator set threaded between the MFMAs, by construction.
+// One wave per SIMD issues in order; about five plain vector instructions behind an MFMA are free, what exceeds them
+// adds to the step.  Left alone hipcc lumps the ~160 vector instructions of an update behind the 30 MFMAs (kernel time =
+// MFMA time + update time, measured), so the step is cut into one scheduling region per MFMA
+// (__builtin_amdgcn_sched_barrier(0)) and each region gets its slice of the update of the pending set (p0, p1 = the two
+// halves' 16 values each, pm / ps their LDS state [2 halves][256]):
+//   gap  0       the state is requested from LDS (the pending values are still in the matrix pipe)
+//   gaps 2..9    four values are copied from the accumulation registers into vector registers, where they stay for
+//                the second pass (two reads per value would make the update the longer pipe); running maximum
+//   gaps 10, 11  new reference r = fl(m L), the old sums rescaled
+//   gaps 12..27  one value of each half: fma, exponential, and the ADD of the previous gap's exponentials (so that
+//                no exponential is consumed right behind itself); even and odd values are summed apart and joined at
+//                the end, which is fb_lse_update16's order
+//   gaps 28, 29  last adds, state written back
+// The parameter fragments are streamed with the K chunks -- chunk c + 1 is read from LDS while the six MFMAs of chunk
+// c run (two alternating register sets for the chunks 1 .. NK-1; chunk 0 has its own, z1 / z2, refilled with the NEXT
+// item's chunk 0 when pf0) -- 24 registers instead of two whole items' 80: that is what leaves room for the 32
+// pending values.
+// The LDS-DMA pieces [dq0, dq0 + dn) of this wave's share of the next parameter group go out one per chunk.
+// UPD = false: no pending set (the first items of the first tile).
+template <int NK, bool UPD>
+__device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, const u32x4 *__restrict__ nxt4, const bool pf0,
+                                            int lane, u32x4 &z1, u32x4 &z2, const u32x4 (&b1)[2][NK],
+                                            const u32x4 (&b2)[2][NK], const f32x16 &init0, const f32x16 &init1,
+                                            f32x16 &out0, f32x16 &out1, const f32x16 &p0, const f32x16 &p1,
+                                            float *__restrict__ pm, float *__restrict__ ps, float ls,
+                                            const u32x4 *__restrict__ dsrc, unsigned ddst, const int dq0, const int dn) {
+  constexpr int NG = 6 * NK;
+  static_assert(NG >= 30, "slice layout");
+  f32x16 x0 = init0, x1 = init1;
+  u32x4 s1[2], s2[2];  // fragment sets of the chunks 1 .. NK-1: chunk c uses set c & 1
+  float v0[16], v1[16];
+  float t0 = FB_GMM_NEG, t1 = FB_GMM_NEG, mo0 = 0.f, mo1 = 0.f, so0 = 0.f, so1 = 0.f, mn0 = 0.f, mn1 = 0.f;
+  float nr0 = 0.f, nr1 = 0.f, d0 = 0.f, d1 = 0.f;
+  float se0 = 0.f, se1 = 0.f, sd0 = 0.f, sd1 = 0.f;  // sums of the even / odd values, halves 0 / 1
+  float e0 = 0.f, e1 = 0.f;                          // the previous gap's exponentials
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = g / 6, k = g % 6;
+    if (k == 0) {
+      if (c + 1 < NK) {
+        s1[(c + 1) & 1] = cur4[(0 * NK + c + 1) * 64 + lane];
+        s2[(c + 1) & 1] = cur4[(1 * NK + c + 1) * 64 + lane];
+      }
+    }
+    const u32x4 &a1 = c == 0 ? z1 : s1[c & 1], &a2 = c == 0 ? z2 : s2[c & 1];
+    if (k == 0) FB_FX_MFMA(a2, b1[0][c], x0);
+    else if (k == 1) FB_FX_MFMA(a2, b1[1][c], x1);
+    else if (k == 2) FB_FX_MFMA(a1, b2[0][c], x0);
+    else if (k == 3) FB_FX_MFMA(a1, b2[1][c], x1);
+    else if (k == 4) FB_FX_MFMA(a1, b1[0][c], x0);
+    else FB_FX_MFMA(a1, b1[1][c], x1);
+    if (pf0 && g == 7) {  // chunk 0's registers are free: the next item's chunk 0 (pf0 is a constant after unrolling)
+      z1 = nxt4[(0 * NK + 0) * 64 + lane];
+      z2 = nxt4[(1 * NK + 0) * 64 + lane];
+    }
+    if (k == 3 && c < dn) fb_glds16(dsrc + (dq0 + c) * 64, ddst + (unsigned)(dq0 + c) * 1024u);
+    if constexpr (UPD) {
+      if (g == 0) { mo0 = pm[0]; mo1 = pm[256]; so0 = ps[0]; so1 = ps[256]; }
+      if (g >= 2 && g < 10) {
+        const int r = 2 * (g - 2);
+        v0[r] = p0[r]; v0[r + 1] = p0[r + 1]; v1[r] = p1[r]; v1[r + 1] = p1[r + 1];
+        // the copies are the compiler's (it knows the matrix pipe's hazards); the empty asm keeps them HERE and in
+        // vector registers
+        asm volatile("" : "+v"(v0[r]), "+v"(v0[r + 1]), "+v"(v1[r]), "+v"(v1[r + 1]));
+        t0 = fb_v_max3(t0, v0[r], v0[r + 1]);
+        t1 = fb_v_max3(t1, v1[r], v1[r + 1]);
+      } else if (g == 10) {
+        mn0 = fb_v_max3(mo0, t0, t0); mn1 = fb_v_max3(mo1, t1, t1);
+        const float rn0 = fb_v_mul(mn0, ls), rn1 = fb_v_mul(mn1, ls);
+        nr0 = -rn0; nr1 = -rn1;
+        d0 = fb_v_fma(mo0, ls, nr0); d1 = fb_v_fma(mo1, ls, nr1);  // r_old - r_new; r_old = -inf at the start
+      } else if (g == 11) {
+        e0 = fb_v_exp(d0); e1 = fb_v_exp(d1);
+      } else if (g >= 12 && g < 28) {
+        const int r = g - 12;
+        const float u0 = fb_v_fma(v0[r], ls, nr0), u1 = fb_v_fma(v1[r], ls, nr1);
+        const float f0 = fb_v_exp(u0), f1 = fb_v_exp(u1);
+        if (r == 0) { se0 = fb_v_mul(so0, e0); se1 = fb_v_mul(so1, e1); }      // s_old * 2^(r_old - r_new)
+        else if (r == 1) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // + value 0
+        else if (r == 2) { sd0 = e0; sd1 = e1; }                                 // value 1 starts the odd sums
+        else if (r & 1) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // value r - 1 is even
+        else { sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1); }
+        e0 = f0; e1 = f1;
+      } else if (g == 28) {
+        sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1);                       // value 15
+      } else if (g == 29) {
+        pm[0] = mn0; pm[256] = mn1;
+        ps[0] = fb_v_add(se0, sd0); ps[256] = fb_v_add(se1, sd1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("" : "+a"(x0), "+a"(x1));
+  out0 = x0;
+  out1 = x1;
+}
+
+#ifdef FB_FXW_TIMERS
+__device__ unsigned long long fb_fxw_timers[8];
+extern "C" int fb_debug_fxw_timers(unsigned long long *out8) {
+  return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(fb_fxw_timers), 64);
+}
+#define FB_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define FB_T(i)
+#endif
 template <int NK, int M>
 __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__restrict__ feats,
                                                      const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
@@ -638,8 +812,10 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   if (strip0 >= n_rows) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
+  constexpr int PAD4 = 192;                    // 3 KB behind each slot: fb_fxw_fetch rounds a group up to whole waves
+  constexpr int SLOTB4 = GA * IMG4 + PAD4;     // slot A = items 0 .. GA-1 at 0, slot B = the rest
   const u32x4 *slot0 = reinterpret_cast<const u32x4 *>(lds);
-  float *st_m = lds + NI * IMG4 * 4;           // [M][2 halves][256]
+  float *st_m = lds + (NI * IMG4 + 2 * PAD4) * 4;  // [M][2 halves][256]
   float *st_s = st_m + M * 512;                // [M][2 halves][256]
 
   // ---- frame fragments of the two 32-frame halves (layout and range guard as in k_gmm_fx2; the power-of-two shift
@@ -711,24 +887,14 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
 
   // ---- parameter stream.  A workgroup barrier per item costs ~400 cycles at one wave per SIMD (the probe's mode 12
   // against 11), so the barrier is taken twice per TILE: slot A holds items 0 .. GA-1, slot B items GA .. NI-1.
-  // While group A of tile t is processed the LDS-DMA fills slot B with group B of the same tile, while group B is
-  // processed it fills slot A with group A of tile t + 1; the pieces (1 KB each, NPIECE per item) are dealt over the
-  // steps of the group and the four waves, issued in front of each step's MFMAs (issuing them behind costs 200 cycles
-  // more per step, probe modes 14 / 15), awaited with vmcnt(0) + barrier where the group ends.
+  // ALL of group B of tile t is requested (LDS-DMA, fb_fxw_fetch) in front of the first step of group A, all of group A
+  // of tile t + 1 in front of the first step of group B -- a group of steps (~2 us) ahead of the vmcnt(0) + barrier
+  // that publishes it.  (Round 2's first form dealt the pieces over the steps, the last ones right in front of that
+  // wait: every barrier then sat out an L2 / HBM round trip, 34 of 112 us.)
   constexpr int NPIECE = IMG4 / 64;
-  constexpr int PPS_A = (GB * NPIECE + 4 * GA - 1) / (4 * GA);  // pieces per wave and step while group A runs (fills B)
-  constexpr int PPS_B = GB > 0 ? (GA * NPIECE + 4 * GB - 1) / (4 * GB) : 0;  // ... while group B runs (fills A)
   const int wv = __builtin_amdgcn_readfirstlane(w);
   const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
-  // piece q of the group that starts at item `first` (n_items_grp items) -> LDS slot offset slot4 (16-byte units)
-  auto dma = [&](int first, int n_items_grp, int slot4, int step, int pps) {
-#pragma unroll
-    for (int u = 0; u < pps; ++u) {
-      const int q = min((step * pps + u) * 4 + wv, n_items_grp * NPIECE - 1);
-      const int item_i = min(first + q / NPIECE, total_items - 1), pc = q % NPIECE;
-      fb_glds16(gimg + (size_t)item_i * IMG4 + pc * 64 + lane, ring_lds + (unsigned)((slot4 + (q / NPIECE) * IMG4 + pc * 64) * 16));
-    }
-  };
+  auto item4 = [&](int jj) { return jj < GA ? jj * IMG4 : SLOTB4 + (jj - GA) * IMG4; };
   auto update = [&](const f32x16 &v0, const f32x16 &v1, int model) {
     fb_lse_update16(v0, st_m + (2 * model) * 256 + tid, st_s + (2 * model) * 256 + tid, ls);
     fb_lse_update16(v1, st_m + (2 * model + 1) * 256 + tid, st_s + (2 * model + 1) * 256 + tid, ls);
@@ -744,35 +910,77 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     hq[0][r] = 0.f; hq[1][r] = 0.f; zero[r] = 0.f;
     acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
   }
-  {  // group A of the first tile
-    constexpr int P0 = (GA * NPIECE + 3) / 4;
-    dma(0, GA, 0, 0, P0);
-    publish();
+  {
+    // The quadratic step of the FIRST tile has no finished model to carry, and a branch for it costs more than a bogus
+    // update (nothing hides an instruction fetch at one wave per SIMD): it "updates" the last model with 16 sentinel
+    // values -2^60 / unscale, whose scaled form is exactly -2^60 fl(log2 e) -- the state becomes (that maximum, 16),
+    // and the first real update rescales those 16 by 2^(-1.6e18) = 0.
+    const float sentinel = -fb_pow2f(60 - sh + g.kacc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[(M - 1) & 1][0][r] = sentinel; acc[(M - 1) & 1][1][r] = sentinel; }
   }
-  u32x4 f1[2][NK], f2[2][NK];  // parameter fragment sets: item j of a tile uses set j & 1
+  fb_fxw_fetch<GA, NPIECE>(gimg + lane, ring_lds, wv);  // group A of the first tile
+  publish();
+  u32x4 z1, z2;  // chunk 0 of the item in front (fb_fxw_step)
+  constexpr int PW_A = (GA * NPIECE + 3) / 4, PW_B = (GB * NPIECE + 3) / 4;  // LDS-DMA pieces per wave for a group
+#ifdef FB_FXW_TIMERS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   for (int t = 0; t < n_t; ++t) {
     const int it0 = t * NI;
+    // this wave's share of the groups requested during this tile: group B of this tile (while A runs), group A of the
+    // next one (while B runs); past the chunk's end the last group is read again and never used
+    const u32x4 *srcB = gimg + (size_t)min(it0 + GA, total_items - GB) * IMG4 + (size_t)wv * (PW_B * 64) + lane;
+    const u32x4 *srcA = gimg + (size_t)min(it0 + NI, total_items - GA) * IMG4 + (size_t)wv * (PW_A * 64) + lane;
+    const unsigned dstB = ring_lds + SLOTB4 * 16 + (unsigned)wv * (PW_B * 1024), dstA = ring_lds + (unsigned)wv * (PW_A * 1024);
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {   // compile-time item index within the tile: 0 = Q, 1 + m = model m
-      const int fs = jj & 1;
       const bool first_of_group = (jj == 0 || jj == GA);
-      if (first_of_group)  // its image was published by the barrier just passed: these reads are not prefetched
-        fb_fxw_frags<NK>(slot0 + jj * IMG4, lane, f1[fs], f2[fs]);
-      if (jj < GA) dma(it0 + GA, GB, GA * IMG4, jj, PPS_A);
-      else dma(it0 + NI, GA, 0, jj - GA, PPS_B);
-      if (jj == 0) fb_fxw_pair<NK>(f1[fs], f2[fs], bq1, bq2, zero, zero, hq[0], hq[1]);
-      else fb_fxw_pair<NK>(f1[fs], f2[fs], bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1]);
-      // everything below is issued behind the queued MFMAs and runs in their shadow
-      if (jj + 1 < NI && jj + 1 != GA)
-        fb_fxw_frags<NK>(slot0 + (jj + 1) * IMG4, lane, f1[fs ^ 1], f2[fs ^ 1]);
-      if (jj == 0) {
-        if (t > 0) update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);  // last model of the previous tile
-      } else if (jj >= 2) {
-        update(acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], jj - 2);
+      const u32x4 *cur4 = slot0 + item4(jj);
+      if (first_of_group) {  // its image was published by the barrier just passed: chunk 0 is not prefetched
+        z1 = cur4[(0 * NK + 0) * 64 + lane];
+        z2 = cur4[(1 * NK + 0) * 64 + lane];
+#ifdef FB_FXW_TIMERS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FB_T(0)
+#endif
       }
+      // the pieces of the other slot's next content: five per step from the group's first step on
+      const int gs = jj < GA ? jj : jj - GA;                      // step within the group
+      const int pw = jj < GA ? PW_B : PW_A, dq0 = 5 * gs;
+      int dn = dq0 < pw ? (pw - dq0 < 5 ? pw - dq0 : 5) : 0;
+      const u32x4 *dsrc = jj < GA ? srcB : srcA;
+      const unsigned ddst = jj < GA ? dstB : dstA;
+      if (first_of_group) {  // behind the chunk-0 reads just issued: their latency is there anyway
+#pragma unroll
+        for (int q = 0; q < dn; ++q) fb_glds16(dsrc + q * 64, ddst + (unsigned)q * 1024u);
+        dn = 0;
+      }
+      // the MFMAs of this item with the update of the pending accumulator set threaded between them (fb_fxw_step):
+      // the quadratic item carries the previous tile's last model, model m >= 1 carries model m - 1
+      const bool pf0 = (jj + 1 < NI && jj + 1 != GA);
+      const u32x4 *nxt4 = slot0 + item4(jj + 1 < NI ? jj + 1 : 0);
+      if (jj == 0) {
+        float *pm = st_m + (2 * (M - 1)) * 256 + tid, *ps = st_s + (2 * (M - 1)) * 256 + tid;
+        fb_fxw_step<NK, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+      } else if (jj == 1) {
+        fb_fxw_step<NK, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[0][0], acc[0][1], zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
+      } else {
+        float *pm = st_m + (2 * (jj - 2)) * 256 + tid, *ps = st_s + (2 * (jj - 2)) * 256 + tid;
+        fb_fxw_step<NK, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                              acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+      }
+#ifdef FB_FXW_TIMERS
+      if (jj == 0) FB_T(1) else if (jj == GA) FB_T(2) else FB_T(3)
+      if (jj == GA - 1 || jj == NI - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FB_T(4) __syncthreads(); FB_T(5) }
+#else
       if (jj == GA - 1 || jj == NI - 1) publish();
+#endif
     }
   }
+#ifdef FB_FXW_TIMERS
+  if (blockIdx.x == 8 && tid == 0) for (int i = 0; i < 8; ++i) fb_fxw_timers[i] = tacc[i];
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);
 
@@ -805,7 +1013,7 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
     grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
     xcd_map = n_chunks;
   }
-  const size_t ldsb = (size_t)(M + 1) * 2 * NK * 64 * 16 + (size_t)2 * M * 512 * sizeof(float);  // one tile + the state
+  const size_t ldsb = ((size_t)(M + 1) * 2 * NK * 64 + 2 * 192) * 16 + (size_t)2 * M * 512 * sizeof(float);  // one tile (two padded slots) + the state
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (ldsb > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {

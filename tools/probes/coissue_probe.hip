@@ -51,7 +51,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void probe(float *out, long long *cyc, int iters, float ls, const u32x4 *gsrc = nullptr) {
   const int lane = threadIdx.x & 63;
-  __shared__ __attribute__((aligned(16))) u32x4 sm[4 * 640];  // 4 slots x 10 KB
+  extern __shared__ __attribute__((aligned(16))) u32x4 sm[];  // 4 slots x 10 KB used; 100 KB requested so that ONE workgroup fits a CU
   if (MODE >= 13) { for (int i = threadIdx.x; i < 4 * 640; i += 256) sm[i] = u32x4{0x3c003c00u, 0x3c003c00u, 0x38003800u, 0x34003400u}; __syncthreads(); }
   f16x8 a[5], b[5];
 #pragma unroll
@@ -230,10 +230,12 @@ void run(const char *name, int blocks, int iters) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   static u32x4 *gsrc = nullptr;
   if (!gsrc) { hipMalloc(&gsrc, 1024 * 64 * 16); hipMemset(gsrc, 0x3c, 1024 * 64 * 16); }
-  probe<MODE><<<blocks, 256>>>(out, cyc, iters, 0.0056f, gsrc);
+  const size_t ldsb = blocks > 256 ? 60 * 1024 : 100 * 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  probe<MODE><<<blocks, 256, ldsb>>>(out, cyc, iters, 0.0056f, gsrc);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  probe<MODE><<<blocks, 256>>>(out, cyc, iters, 0.0056f, gsrc);
+  probe<MODE><<<blocks, 256, ldsb>>>(out, cyc, iters, 0.0056f, gsrc);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   long long h[4]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
