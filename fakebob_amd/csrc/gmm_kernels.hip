@@ -555,30 +555,31 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
 // speaker models; items per tile = Q, m_0 .. m_{M-1}) -- one wave per SIMD, 64 frames per wave, software-pipelined,
 // the whole tile as straight-line code.
 //
-// Why (tools/probes/coissue_probe.hip, cycles per two items = 30 MFMAs + two logsumexp updates):
+// What the design rests on (tools/probes/coissue_probe.hip, valu_cost_probe.hip; one wave per SIMD):
 //   * MFMAs on ONE accumulator issue only as fast as they execute (the wave sits at the next dependent MFMA), so in
-//     k_gmm_fx2 an item's update (~2/3 of its MFMA time in vector instructions) starts when its 15 MFMAs are done: 1549.
-//   * MFMAs that alternate between two INDEPENDENT accumulators are queued by the matrix pipe and the wave goes on
-//     issuing behind them: with the update of the PREVIOUS item's values placed after the current item's MFMAs the
-//     same work takes 1061 (969 = the MFMA time alone with a finer interleave).
+//     k_gmm_fx2 an item's update starts when its 15 MFMAs are done.  MFMAs that alternate between two INDEPENDENT
+//     accumulators are queued by the matrix pipe and the wave goes on issuing behind them.
+//   * The wave issues in order: a vector instruction overlaps the matrix pipe only if it stands behind an MFMA in the
+//     instruction stream.  About five plain VALU instructions per MFMA are free (16.5 ns per MFMA with 0 .. 4
+//     v_fma_f32 behind it, 18.5 with 6, 23 with 8); 2 v_fma + 2 v_exp + 2 v_add cost 20 ns.
+//   * A PACKED f32 instruction behind an MFMA stalls the wave: MFMA + one v_pk_fma_f32 = 20.6 ns, the packed form of
+//     the update's gap 30.7 ns against 20.3 ns unpacked.  The update is written with single instructions.
 // The two independent chains of an item are the two 32-frame halves of the wave's 64 frames: both use the SAME
 // parameter fragments (half the LDS reads per MFMA) and every item, the quadratic one included, is a pair.  That needs
-// 160 registers of frame operands + 96 of accumulators (hq, in flight, being consumed; two halves each) + two sets of
-// parameter fragments: the 512-register budget of one wave per SIMD -- 4 waves (256 frames) per workgroup, one
-// workgroup per CU, component chunks chosen so that a launch is one round of <= 256 workgroups.  An empty asm pins the
-// accumulators to AGPRs (left alone hipcc parks the FRAME operands there and copies them back in front of every
-// MFMA: 1190 v_accvgpr moves).
+// 160 registers of frame operands + 96 of accumulators (hq, in flight, being consumed; two halves each) + 32 for
+// the values being consumed + 24 of parameter fragments: the 512-register budget of one wave per SIMD -- 4 waves
+// (256 frames) per workgroup, one workgroup per CU, component chunks chosen so that a launch is one round of <= 256
+// workgroups.  An empty asm pins the accumulators to AGPRs (left alone hipcc parks the FRAME operands there and
+// copies them back in front of every MFMA: 1190 v_accvgpr moves).
 // With one wave per SIMD nothing hides instruction fetch after a branch (a loop over items with the item kind,
 // pending update and padding decided by branches ran at ~1500 cycles per item with an EMPTY body), hence the
-// specialisation: M is a template parameter, accumulator sets and fragment sets have static roles (model m writes set
-// m & 1 while set (m - 1) & 1 is updated behind its MFMAs; the quadratic item overlaps the update of the previous
-// tile's last model), and a tile is one basic block.  Models with C % 32 != 0, several variance groups or other M
-// run on k_gmm_fx2.
-// Parameter items arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): wave w brings
-// the 1 KB pieces w, w + 4, w + 8 of the 10 KB image (clamped: every wave issues NPW loads per item, which keeps the
-// vmcnt bookkeeping uniform) three items ahead into a ring of four slots; the fragments of item i + 1 are read into
-// the second fragment set while the MFMAs of item i run, so an image must be in LDS and published by a barrier two
-// iterations before its MFMAs.
+// specialisation: M is a template parameter, accumulator sets have static roles (model m writes set m & 1 while set
+// (m - 1) & 1 is updated in the gaps between its MFMAs, fb_fxw_step; the quadratic item carries the update of the
+// previous tile's last model), and a tile is one basic block.  Models with C % 32 != 0, several variance groups or
+// other M run on k_gmm_fx2.
+// Parameter items arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS
+// slots, a group of items each, requested a whole group of steps ahead of the barrier that publishes them
+// (fb_fxw_fetch and the loop below).
 __device__ __forceinline__ void fb_glds16(const void *gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -621,34 +622,6 @@ __device__ __forceinline__ void fb_fxw_fetch(const u32x4 *__restrict__ group_lan
     else if (n == 2) fb_glds16_run<2>(src + u * 64, dst + u * 1024);
     else fb_glds16_run<1>(src + u * 64, dst + u * 1024);
   }
-}
-
-template <int NK>
-__device__ __forceinline__ void fb_fxw_frags(const u32x4 *__restrict__ cur4, int lane, u32x4 (&a1)[NK], u32x4 (&a2)[NK]) {
-#pragma unroll
-  for (int c = 0; c < NK; ++c) {
-    a1[c] = cur4[(0 * NK + c) * 64 + lane];
-    a2[c] = cur4[(1 * NK + c) * 64 + lane];
-  }
-}
-// the 2 x 3 NK MFMAs of one item: out0/out1 = init0/init1 + a (x) b[half], halves alternating
-template <int NK>
-__device__ __forceinline__ void fb_fxw_pair(const u32x4 (&a1)[NK], const u32x4 (&a2)[NK], const u32x4 (&b1)[2][NK],
-                                            const u32x4 (&b2)[2][NK], const f32x16 &init0, const f32x16 &init1,
-                                            f32x16 &out0, f32x16 &out1) {
-  f32x16 x0 = init0, x1 = init1;
-#pragma unroll
-  for (int c = 0; c < NK; ++c) {
-    FB_FX_MFMA(a2[c], b1[0][c], x0);
-    FB_FX_MFMA(a2[c], b1[1][c], x1);
-    FB_FX_MFMA(a1[c], b2[0][c], x0);
-    FB_FX_MFMA(a1[c], b2[1][c], x1);
-    FB_FX_MFMA(a1[c], b1[0][c], x0);
-    FB_FX_MFMA(a1[c], b1[1][c], x1);
-  }
-  asm volatile("" : "+a"(x0), "+a"(x1));
-  out0 = x0;
-  out1 = x1;
 }
 
 // Single vector instructions, pinned where they are written (volatile): the update slices below must stay in their
@@ -778,15 +751,6 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
   out1 = x1;
 }
 
-#ifdef FB_FXW_TIMERS
-__device__ unsigned long long fb_fxw_timers[8];
-extern "C" int fb_debug_fxw_timers(unsigned long long *out8) {
-  return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(fb_fxw_timers), 64);
-}
-#define FB_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; }
-#else
-#define FB_T(i)
-#endif
 template <int NK, int M>
 __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__restrict__ feats,
                                                      const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
@@ -887,10 +851,11 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
 
   // ---- parameter stream.  A workgroup barrier per item costs ~400 cycles at one wave per SIMD (the probe's mode 12
   // against 11), so the barrier is taken twice per TILE: slot A holds items 0 .. GA-1, slot B items GA .. NI-1.
-  // ALL of group B of tile t is requested (LDS-DMA, fb_fxw_fetch) in front of the first step of group A, all of group A
-  // of tile t + 1 in front of the first step of group B -- a group of steps (~2 us) ahead of the vmcnt(0) + barrier
-  // that publishes it.  (Round 2's first form dealt the pieces over the steps, the last ones right in front of that
-  // wait: every barrier then sat out an L2 / HBM round trip, 34 of 112 us.)
+  // While group A of tile t runs the LDS-DMA fills slot B with group B of the same tile, while group B runs it fills
+  // slot A with group A of tile t + 1: a group is one contiguous piece of the image buffer, wave w brings the 1 KB
+  // pieces [w PW, (w + 1) PW) of it, five per step (one behind the fourth MFMA of each K chunk) in the group's first
+  // two steps -- at least a step ahead of the vmcnt(0) + barrier that publishes the slot (measured with s_memtime
+  // stamps: the wait is 16 cycles, the barrier ~90, of ~5 000 per group).
   constexpr int NPIECE = IMG4 / 64;
   const int wv = __builtin_amdgcn_readfirstlane(w);
   const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
@@ -923,9 +888,6 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   publish();
   u32x4 z1, z2;  // chunk 0 of the item in front (fb_fxw_step)
   constexpr int PW_A = (GA * NPIECE + 3) / 4, PW_B = (GB * NPIECE + 3) / 4;  // LDS-DMA pieces per wave for a group
-#ifdef FB_FXW_TIMERS
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
   for (int t = 0; t < n_t; ++t) {
     const int it0 = t * NI;
     // this wave's share of the groups requested during this tile: group B of this tile (while A runs), group A of the
@@ -940,10 +902,6 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       if (first_of_group) {  // its image was published by the barrier just passed: chunk 0 is not prefetched
         z1 = cur4[(0 * NK + 0) * 64 + lane];
         z2 = cur4[(1 * NK + 0) * 64 + lane];
-#ifdef FB_FXW_TIMERS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        FB_T(0)
-#endif
       }
       // the pieces of the other slot's next content: five per step from the group's first step on
       const int gs = jj < GA ? jj : jj - GA;                      // step within the group
@@ -970,17 +928,9 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
         fb_fxw_step<NK, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
                               acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
       }
-#ifdef FB_FXW_TIMERS
-      if (jj == 0) FB_T(1) else if (jj == GA) FB_T(2) else FB_T(3)
-      if (jj == GA - 1 || jj == NI - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FB_T(4) __syncthreads(); FB_T(5) }
-#else
       if (jj == GA - 1 || jj == NI - 1) publish();
-#endif
     }
   }
-#ifdef FB_FXW_TIMERS
-  if (blockIdx.x == 8 && tid == 0) for (int i = 0; i < 8; ++i) fb_fxw_timers[i] = tacc[i];
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);
 
