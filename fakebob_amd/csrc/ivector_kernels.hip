@@ -918,16 +918,59 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // --------------------------------------------------------- solve (K10c)
 // One workgroup per utterance: A = I + unpack(quad), rhs = sum of lin partials (+ prior offset).
 // Right-looking blocked Cholesky (panel 32) in global scratch (L2 resident).  Everything serial is kept
-// out of LDS-latency chains: the 32x32 diagonal block is factored by one wave in registers (lane =
-// row, pivots/columns broadcast with v_readlane), its inverse is formed with lane = column, and both the
-// panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain mat-vec /
-// mat-mat products.  ivec = solution with the prior offset removed from component 0.
+// out of LDS-latency chains: the 32x32 diagonal block is factored AND inverted by one wave in registers
+// (fb_chol32_fused: rows in the lower half of the wave, columns of the inverse in the upper half, one instruction
+// stream), and both the panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain
+// mat-vec / mat-mat products.  ivec = solution with the prior offset removed from component 0.
 #define FB_IV_NB 32
 __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src);
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
+}
+// Cholesky factor AND inverse of a 32 x 32 block by one wave, fused: lanes 0..31 hold the rows of A (lane = row: the
+// factor's right-looking column loop), lanes 32..63 the columns of the identity (lane - 32 = column: the forward
+// substitution L X = I).  Both halves run the SAME instructions: column c is scaled by 1/L[c][c] (= the new column of
+// L below, = row c of L^-1 above), broadcast from the lower half, and subtracted from the later columns -- in the
+// upper half that is exactly the substitution step, so the inverse costs no instruction of its own and 64 registers
+// hold everything (round 1: separate passes, the inverse reading L back from LDS; 49 % of the solve's cycles).
+// The broadcast goes through LDS (one ds_write of the column, then reads of one address by all lanes; bc = 2 x 32
+// doubles, alternating): two v_readlane + wait states per element made every update a 20-cycle affair, and hipcc
+// turned the loop left-looking to save the scalar registers -- c dependent fmas in front of every pivot.  The empty
+// asm keeps it right-looking: the 31 - c updates of a column are independent, a pivot waits for ONE of them.
+// X: in = A[rr][c] (lower triangle, zeros above; identity rows beyond a short block) / delta(r, rr);
+// out = L[rr][c] / Linv[r][rr].  Returns true on a non-positive pivot.
+__device__ __forceinline__ bool fb_chol32_fused(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane) {
+  static_assert(FB_IV_NB == 32, "the asm operand lists below name 32 registers");
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < FB_IV_NB; ++c) {
+    const double d = fb_readlane_f64(X[c], c);
+    bad |= !(d > 0.0);
+    // 1/sqrt(d) by v_rsq_f64 + two Newton steps (full double precision): no sqrt, no division in the column loop
+    const double dd = d > 0.0 ? d : 1.0;
+    double ri = __builtin_amdgcn_rsq(dd);
+    ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+    ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+    const double l = X[c] * ri;  // lower half: L[rr][c] (0 above the diagonal, d * ri on it); upper half: Linv[c][rr]
+    X[c] = l;
+    if (c + 1 < FB_IV_NB) {
+      double *col = bc + (c & 1) * FB_IV_NB;
+      if (lane < FB_IV_NB) col[lane] = l;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int cc = c + 1; cc < FB_IV_NB; ++cc) X[cc] = fma(-l, col[cc], X[cc]);
+      // the column's updates are finished HERE (two statements: an asm takes 30 operands at most)
+      asm volatile("" : "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]),
+                        "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]), "+v"(X[16]));
+      asm volatile("" : "+v"(X[17]), "+v"(X[18]), "+v"(X[19]), "+v"(X[20]), "+v"(X[21]), "+v"(X[22]), "+v"(X[23]), "+v"(X[24]),
+                        "+v"(X[25]), "+v"(X[26]), "+v"(X[27]), "+v"(X[28]), "+v"(X[29]), "+v"(X[30]), "+v"(X[31]));
+    }
+  }
+  return bad;
 }
 // The factorisation runs IN PLACE on the packed lower triangle the contraction produced (a dense copy cost 126 us of
 // unpacking per batch), with the right-hand side carried along as row R of the matrix so that the forward
@@ -969,68 +1012,34 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
   }
   __syncthreads();
   // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
-  // registers (lane = row for the factor, lane = column for the inverse; pivots and columns are broadcast
-  // with v_readlane).  Leaves L11 in Dg and in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
+  // registers (fb_chol32_fused).  Leaves L11 in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
   // fixed-size code valid for a short last block.
   auto factor_block = [&](int j0, int nb, int pi) {
-    double row[FB_IV_NB];
+    double X[FB_IV_NB];
     const int rr = lane & 31;
-    {
+    if (lane < FB_IV_NB) {
       const int rl = min(rr, nb - 1);
       const double *ar = rowp(j0 + rl) + j0;
 #pragma unroll
       for (int c = 0; c < FB_IV_NB; ++c) {
         const double v = ar[min(c, rl)];  // never past the end of the packed row
-        row[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
+        X[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
       }
-    }
-    bool bad = false;
-    double rinv_mine = 1.0;  // lane c keeps 1 / L11[c][c]
+    } else {
 #pragma unroll
-    for (int c = 0; c < FB_IV_NB; ++c) {
-      const double d = fb_readlane_f64(row[c], c);
-      bad |= !(d > 0.0);
-      // 1/sqrt(d) by v_rsq_f64 + two Newton steps (full double precision) instead of a sqrt and 32
-      // divisions on the critical path of the column loop
-      const double dd = d > 0.0 ? d : 1.0;
-      double ri = __builtin_amdgcn_rsq(dd);
-      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-      ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-      const double piv = dd * ri;
-      if (rr == c) rinv_mine = ri;
-      const double l = (rr == c) ? piv : row[c] * ri;
-      row[c] = (rr >= c) ? l : 0.0;
-#pragma unroll
-      for (int cc = c + 1; cc < FB_IV_NB; ++cc) row[cc] = fma(-l, fb_readlane_f64(l, cc), row[cc]);
+      for (int c = 0; c < FB_IV_NB; ++c) X[c] = (rr == c) ? 1.0 : 0.0;
     }
+    const bool bad = fb_chol32_fused(X, Dg, lane);
     if (bad && lane == 0) atomicMax(fail, b + 1);
     if (lane < FB_IV_NB) {
 #pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) {
-        Dg[rr * LD + c] = row[c];
-        if (rr < nb && c <= rr) rowp(j0 + rr)[j0 + c] = row[c];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // invert: lane c holds column c of L11^-1 (forward substitution on e_c; L11 reads are broadcasts)
-    // (column updates: once li[q] is known it is subtracted from every later row at once -- 31 - q independent
-    //  fmas -- instead of one 496-long dependent chain; the operations and their order per entry are unchanged)
-    double li[FB_IV_NB], ac[FB_IV_NB];
-#pragma unroll
-    for (int r = 0; r < FB_IV_NB; ++r) ac[r] = (r == rr) ? 1.0 : 0.0;
-#pragma unroll
-    for (int q = 0; q < FB_IV_NB; ++q) {
-      li[q] = ac[q] * fb_readlane_f64(rinv_mine, q);
-#pragma unroll
-      for (int r = q + 1; r < FB_IV_NB; ++r) ac[r] = fma(-Dg[r * LD + q], li[q], ac[r]);
-    }
-    if (lane < FB_IV_NB) {
+      for (int c = 0; c < FB_IV_NB; ++c)
+        if (rr < nb && c <= rr) rowp(j0 + rr)[j0 + c] = X[c];
+    } else {
 #pragma unroll
       for (int r = 0; r < FB_IV_NB; ++r) {
-        Di[r * LD + rr] = li[r];
-        Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = li[r];
+        Di[r * LD + rr] = X[r];
+        Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = X[r];
       }
     }
   };
@@ -1177,6 +1186,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__r
   }
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
+
 void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                         int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
   const int R = iv.R;
