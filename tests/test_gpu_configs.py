@@ -268,3 +268,36 @@ def test_pipeline_round_trips_are_constructor_options(tmp_path, oracle):
     finally:
         e.set_frontend(text_scores=0)
         e.close()
+
+
+@pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5])
+def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers):
+    """k_gmm_fx2w is instantiated per model count M = 2 .. 6 (SV: UBM + 1; OSI: UBM + speakers): each instantiation
+    has its own LDS slot split, LDS-DMA piece schedule and accumulator rotation.  Several component chunks per strip
+    (C = 1024 -> tiles streamed through both slots many times), a ragged last strip, against the oracle and against
+    the general kernel on the same inputs."""
+    monkeypatch.delenv("FB_GMM_NARROW", raising=False)
+    monkeypatch.delenv("FB_GMM_MODE", raising=False)
+    cfg = oracle.default_cfg()
+    ubm, spk = synthetic_gmm_system(n_speakers=n_speakers, C=1024, D=72)
+    wavs = [_wav(u, 16000 + 1234 * u) for u in range(7)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, tv_o = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel == "fx2"
+        raw_w, tv_w = e.score_raw(wavs)
+    finally:
+        e.close()
+    monkeypatch.setenv("FB_GMM_NARROW", "1")
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        raw_n, _ = e.score_raw(wavs)
+    finally:
+        e.close()
+    assert np.array_equal(tv_w, tv_o)
+    assert np.abs(raw_w - raw_o).max() <= 2e-5, np.abs(raw_w - raw_o).max()
+    assert np.abs(raw_w - raw_n).max() <= 2e-5
+    assert not np.array_equal(raw_w, raw_n)   # two different kernels really ran (different summation order)
