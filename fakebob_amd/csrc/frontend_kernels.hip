@@ -1069,41 +1069,39 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
 #pragma unroll
       for (int j = 0; j < 2 * ORDER * WIN + 1; ++j) creg[i][j] = s_sc[i * (2 * ORDER * WIN + 1) + j];
   }
-  // ---- add-deltas: half-wave = frame, lane = coefficient (no divisions); float64 taps in order
-  for (int d0 = 0; d0 < nc; d0 += 32) {
-    const int d = d0 + (lane & 31);
-    for (int t = 2 * w + (lane >> 5); t < T; t += 32) {
-      if (d < nc) {
-        if constexpr (ORDER > 0) {
+  // ---- add-deltas: thread = (frame, coefficient) pairs in flat order -- every lane busy (nc = 24 fills 3/4 of a
+  //      half-wave), consecutive lanes on consecutive LDS words; float64 taps in order
+  for (int idx = tid; idx < T * nc; idx += 1024) {
+    const int t = idx / nc, d = idx - t * nc;
+    if constexpr (ORDER > 0) {
 #pragma unroll
-          for (int i = 0; i <= ORDER; ++i) {
-            constexpr int ML = 2 * ORDER * WIN + 1;
-            const int off = i * WIN;
-            float x[ML];
-            const float *row = s_mf + (t + ctx - off) * nc + d;
+      for (int i = 0; i <= ORDER; ++i) {
+        constexpr int ML = 2 * ORDER * WIN + 1;
+        const int off = i * WIN;
+        float x[ML];
+        const float *row = s_mf + (t + ctx - off) * nc + d;
 #pragma unroll
-            for (int j = 0; j < ML; ++j)
-              if (j <= 2 * off) x[j] = row[j * nc];
-            double acc = 0.0;
+        for (int j = 0; j < ML; ++j)
+          if (j <= 2 * off) x[j] = row[j * nc];
+        double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < ML; ++j)
-              if (j <= 2 * off) acc = __dadd_rn(acc, __dmul_rn(creg[i][j], (double)x[j]));
-            s_df[t * dim + i * nc + d] = (float)acc;
-          }
-        } else {
-          for (int i = 0; i <= order; ++i) {
-            const double *sc = s_sc + i * maxlen;
-            const int off = i * dwin;
-            double acc = 0.0;
-            for (int j = 0; j <= 2 * off; ++j)
-              acc = __dadd_rn(acc, __dmul_rn(sc[j], (double)s_mf[(t + ctx - off + j) * nc + d]));
-            s_df[t * dim + i * nc + d] = (float)acc;
-          }
-        }
+        for (int j = 0; j < ML; ++j)
+          if (j <= 2 * off) acc = __dadd_rn(acc, __dmul_rn(creg[i][j], (double)x[j]));
+        s_df[t * dim + i * nc + d] = (float)acc;
+      }
+    } else {
+      for (int i = 0; i <= order; ++i) {
+        const double *sc = s_sc + i * maxlen;
+        const int off = i * dwin;
+        double acc = 0.0;
+        for (int j = 0; j <= 2 * off; ++j)
+          acc = __dadd_rn(acc, __dmul_rn(sc[j], (double)s_mf[(t + ctx - off + j) * nc + d]));
+        s_df[t * dim + i * nc + d] = (float)acc;
       }
     }
   }
   __syncthreads();
+  const double alpha = (double)(float)(-1.0 / (double)T);
   if (tid < dim) {  // frames in order; the loads of 8 frames are issued before their (dependent) adds
     double acc = 0.0;
     int t = 0;
@@ -1115,18 +1113,22 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
       for (int u = 0; u < 8; ++u) acc += (double)x[u];
     }
     for (; t < T; ++t) acc += (double)s_df[t * dim + tid];
-    s_sum[tid] = acc;
+    s_sum[tid] = __dmul_rn(alpha, acc);  // the shift CMVN adds
   }
-  // ---- row offset: voiced counts of the utterances before this one (published above by their workgroups)
+  // ---- row offset: voiced counts of the utterances before this one (published above by their workgroups), read by
+  //      the waves the sums leave idle (dim <= 128 here: waves 2 .. 15; otherwise by everybody, after the sums)
   {
+    const int first = dim <= 128 ? 128 : 0, nth = 1024 - first;
     int mine = 0;
-    for (int i = tid; i < b; i += 1024) {
-      unsigned long long v;
-      do {
-        v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((unsigned)(v >> 32) != epoch);
-      const int c = (int)(unsigned)v;
-      mine += c > 0 ? c : 0;
+    if (tid >= first) {
+      for (int i = tid - first; i < b; i += nth) {
+        unsigned long long v;
+        do {
+          v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(v >> 32) != epoch);
+        const int c = (int)(unsigned)v;
+        mine += c > 0 ? c : 0;
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
@@ -1141,16 +1143,13 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
     if (b == B - 1) row_off[B] = a + (n_voiced > 0 ? n_voiced : 0);
   }
   __syncthreads();
-  // ---- CMVN + voiced-row compaction: wave = frame, lane = dimension
+  // ---- CMVN + voiced-row compaction: thread = (frame, dimension) pairs in flat order (dim = 72 leaves 8 of the 64
+  //      lanes of a second pass busy otherwise); voiced frames follow each other, so do their output rows
   const int rbase = s_rbase;
-  const double alpha = (double)(float)(-1.0 / (double)T);
-  for (int d = lane; d < dim; d += 64) {
-    const double shift = __dmul_rn(alpha, s_sum[d]);
-#pragma unroll 4
-    for (int t = w; t < T; t += 16) {
-      const int r = s_vr[t];
-      if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[t * dim + d], shift);
-    }
+  for (int idx = tid; idx < T * dim; idx += 1024) {
+    const int t = idx / dim, d = idx - t * dim;
+    const int r = s_vr[t];
+    if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[idx], s_sum[d]);
   }
 }
 size_t fb_delta_cmvn_lds_bytes(const FbFrontendDev &fe, int t_cap) {

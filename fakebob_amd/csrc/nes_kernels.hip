@@ -283,8 +283,15 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
 // Philox normals for iteration iter + 1, overwrites its zbuf entries (read in phase 1 by this block only) and writes
 // the two int16 columns; thread = sample writes the clean column and the distance partial.  Same arithmetic as the
 // two kernels, so trajectories are bit-identical.  Device-controlled attacks only (lr / stop from the control block).
+// Workgroup = 256 samples (the unit of the distance partials and of the LDS-staged normals) worked on by FB_UP_THREADS
+// threads: the update (phase 1) is one thread per sample, the next iteration's columns (phase 2: 64 sample quads x
+// spd/2 pairs of Philox + Box-Muller items) are dealt over all of them -- with 256 threads the 188 workgroups of a 3 s
+// utterance put fewer waves on the chip than it has SIMDs.  Measured (same box, 1 attack / 3 in flight): 256 threads
+// 19.1 us, 4 930 / 7 900 it/s; 512: 5 040 / 7 930; 1024: 13.1 us, 5 110 / 7 300 (the wide workgroups get in the way of
+// the other attacks' kernels).
+#define FB_UP_THREADS 512
 template <bool SMALL>
-__global__ __launch_bounds__(256) void k_update_perturb(const double *__restrict__ loss, int64_t N, int half,
+__global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *__restrict__ loss, int64_t N, int half,
                                                         double sigma, float *__restrict__ zbuf, double momentum,
                                                         double one_minus_m, double epsilon,
                                                         const double *__restrict__ audio, double *__restrict__ grad_m,
@@ -298,14 +305,16 @@ __global__ __launch_bounds__(256) void k_update_perturb(const double *__restrict
   double *s_a = s_loss + spd;
   float *s_z = reinterpret_cast<float *>(s_a + 256);
   for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  {
-    const int64_t nc = n < N ? n : N - 1;
-    for (int j = 0; j < half; ++j) s_z[j * 256 + threadIdx.x] = zbuf[(int64_t)j * N + nc];
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;  // phase 1: threads 0 .. 255
+  for (int e = threadIdx.x; e < half * 256; e += blockDim.x) {
+    const int64_t ns = (int64_t)blockIdx.x * 256 + (e & 255);
+    s_z[e] = zbuf[(int64_t)(e >> 8) * N + (ns < N ? ns : N - 1)];
   }
   __syncthreads();
   double dmax = 0.0;
-  if (n < N) {
+  if (threadIdx.x >= 256) {
+    // phase 2 only
+  } else if (n < N) {
     auto el = [&](int i) -> D1 {
       const int j = i < half ? i : i - half;
       double z = (double)s_z[j * 256 + threadIdx.x];
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void k_update_perturb(const double *__restrict
   {  // distance partial of the NEXT iteration's trace row (max |audio - adver|, as k_perturb reports it)
     __shared__ double red[4];
     double m = fb_wave_max(dmax);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = m;  // waves 0 .. 3 hold the samples
     __syncthreads();  // also: s_a complete
     if (threadIdx.x == 0) {
       double r = red[0];
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void k_update_perturb(const double *__restrict
   }
   // ---- phase 2: the perturbed columns of iteration next_iter for this block's samples
   const int64_t n4_0 = (int64_t)blockIdx.x * 64;  // first sample quad of the block
-  for (int idx = threadIdx.x; idx < 64 * half; idx += 256) {
+  for (int idx = threadIdx.x; idx < 64 * half; idx += blockDim.x) {
     const int n4l = idx & 63, j = idx >> 6;
     const int64_t n0 = (n4_0 + n4l) * 4;
     if (n0 >= N) continue;
@@ -381,11 +390,12 @@ int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int h
                              int16_t *q, double *dist_part) {
   const int blocks = (int)((N + 255) / 256);
   const size_t shm = sizeof(double) * (size_t)(2 * half + 256) + sizeof(float) * 256 * (size_t)(half > 0 ? half : 1);
+  const int nthr = FB_UP_THREADS;
   if (2 * half <= 128)
-    hipLaunchKernelGGL(k_update_perturb<true>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, momentum,
+    hipLaunchKernelGGL(k_update_perturb<true>, dim3(blocks), dim3(nthr), shm, s, loss, N, half, sigma, zbuf, momentum,
                        one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
   else
-    hipLaunchKernelGGL(k_update_perturb<false>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, momentum,
+    hipLaunchKernelGGL(k_update_perturb<false>, dim3(blocks), dim3(FB_UP_THREADS), shm, s, loss, N, half, sigma, zbuf, momentum,
                        one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
   return blocks;
 }
