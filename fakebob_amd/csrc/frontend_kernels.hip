@@ -326,15 +326,6 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
   float *s_lift = reinterpret_cast<float *>(smem + lo.lift);
   int *s_mfirst = reinterpret_cast<int *>(smem + lo.melidx), *s_mlen = s_mfirst + nb, *s_moff = s_mlen + nb;
   double2 *X = reinterpret_cast<double2 *>(smem + lo.wave0) + ((size_t)w * 4 + fq) * FB_R16_SLOTS;  // this frame's buffer
-  for (int i = tid; i < Nc; i += NT) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
-  for (int i = tid; i <= Nc; i += NT) s_twf[i] = reinterpret_cast<const double2 *>(fe.tw_full)[i];
-  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
-  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
-  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
-  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
-  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
-  __syncthreads();
-
   const int n_groups = (total_frames + 3) >> 2;
   const int w_glob = blockIdx.x * FB_R16_WAVES + w, w_step = gridDim.x * FB_R16_WAVES;
   const int t_lane = t;
@@ -357,21 +348,40 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
       }
     } else {
       const int16_t *wv = wav + (abs_start - start);
-      auto sample = [&](int sidx) -> int {  // reflected at the utterance edges
-        int64_t k = (int64_t)start + sidx;
-        while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
-        return wv[k];
-      };
-#pragma unroll 1
+      // samples reflected at the utterance edges
+      // (a wave with an edge frame used to walk these 16 points one global round trip at a time -- 16 x ~1.5 us, the
+      //  longest path of the whole launch; the indices first, then all 32 loads in flight)
+      int64_t kk[32];
+#pragma unroll
       for (int a = 0; a < 16; ++a) {
         const int s0 = 32 * a + 2 * tl;
-        const int lo16 = sample(min(s0, L - 1)), hi16 = sample(min(s0 + 1, L - 1));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int64_t k = (int64_t)start + min(s0 + u, L - 1);
+          while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
+          kk[2 * a + u] = k;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const int lo16 = wv[kk[2 * a]], hi16 = wv[kk[2 * a + 1]];
         xq[a] = (hi16 << 16) | (lo16 & 0xffff);
       }
     }
   };
+  // the first group's samples are requested BEFORE the tables are staged: their two dependent global round trips
+  // (frame record, then samples) run in the shadow of the staging loads and the barrier
   int xn[16];
   if (w_glob < n_groups) load_group(w_glob, t_lane, xn);
+  for (int i = tid; i < Nc; i += NT) s_tw[i] = reinterpret_cast<const double2 *>(fe.tw_half)[i];
+  for (int i = tid; i <= Nc; i += NT) s_twf[i] = reinterpret_cast<const double2 *>(fe.tw_full)[i];
+  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
+  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
+  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
+  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
+  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
+  __syncthreads();
+
   for (int g = w_glob; g < n_groups; g += w_step) {
     // Everything below that depends only on the lane (clamped sample indices, window weights, twiddles: > 150
     // registers) is loop-invariant; hoisted it spills, so the lane index is laundered through an empty asm per trip.
