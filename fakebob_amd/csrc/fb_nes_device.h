@@ -92,19 +92,58 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                               double *__restrict__ trace, int it) {
   const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
-  __shared__ int s_err;
-  if (threadIdx.x == 0) s_err = 0;
-  __syncthreads();
+  __shared__ int s_errw[16];
+  // The decisions at the end are one thread's work: everything it needs from global memory is requested HERE and
+  // arrives while the block computes the losses; nothing below waits for it before it is used (no barrier up here: the
+  // "no voiced frames" flag is reduced over the waves at the end instead of being initialised in LDS first).  Read
+  // where they were used, the control block, the window of recent losses, the raw scores (a run-time loop: one L2
+  // round trip per model) and the losses were ~20 dependent round trips, 9 of the fused kernel's 18 us.
+  constexpr int FB_LS_LOCAL = 8, FB_LOSS_LDS = 1024, FB_SC_LDS = 2048;
+  __shared__ double s_lv[FB_LOSS_LDS];  // the losses of this iteration (B <= FB_LOSS_LDS; otherwise read back from `loss`)
+  __shared__ double s_sc[FB_SC_LDS];    // the scores while the loss is formed from them (B S <= FB_SC_LDS; otherwise in `scores`)
+  const bool sc_lds = (size_t)B * S <= FB_SC_LDS;
+  const double dist_first = (int)threadIdx.x < n_dist_part ? dist_part[threadIdx.x] : 0.0;  // in flight with the rest
+  FbCtlDev c = {};
+  double lsv[FB_LS_LOCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (threadIdx.x == 0) {
+    if (ctl) {
+      c = *ctl;
+      if (c.plateau_length > 0 && c.plateau_length <= FB_LS_LOCAL) {
+#pragma unroll
+        for (int i = 0; i < FB_LS_LOCAL; ++i) lsv[i] = c.ls[i < c.plateau_length ? i : c.plateau_length - 1];
+      }
+    }
+  }
+  int my_err = 0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    if (tv && tv[b] <= 0) atomicMax(&s_err, b + 1);
-    auto r = [&](int m) -> double { return FUSED ? fb_ld_agent_f64(raw + (size_t)b * M + m) : raw[(size_t)b * M + m]; };
-    double *sc = scores + (size_t)b * S;
+    if (tv && tv[b] <= 0) my_err = b + 1 > my_err ? b + 1 : my_err;
+    constexpr int FB_RAW_LOCAL = 8;  // all raw scores of the utterance in one batch of loads
+    double rv[FB_RAW_LOCAL];
+    if (M <= FB_RAW_LOCAL) {
+#pragma unroll
+      for (int m = 0; m < FB_RAW_LOCAL; ++m) {
+        const double *rp = raw + (size_t)b * M + (m < M ? m : M - 1);
+        rv[m] = FUSED ? fb_ld_agent_f64(rp) : *rp;
+      }
+    }
+    auto r = [&](int m) -> double {
+      if (M <= FB_RAW_LOCAL) {
+        double v = rv[0];
+#pragma unroll
+        for (int q = 1; q < FB_RAW_LOCAL; ++q) v = m == q ? rv[q] : v;
+        return v;
+      }
+      return FUSED ? fb_ld_agent_f64(raw + (size_t)b * M + m) : raw[(size_t)b * M + m];
+    };
+    double *sc = sc_lds ? s_sc + (size_t)b * S : scores + (size_t)b * S;
     if (task == FB_TASK_CSI || znorm_all) {
       // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
       for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r(m), z_mean[m]), z_std[m]);
     } else {
-      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r(1 + m), r(0));  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
+      const double r_ubm = r(0);
+      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r(1 + m), r_ubm);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
     }
+    if (sc_lds) for (int m = 0; m < S; ++m) scores[(size_t)b * S + m] = sc[m];
     double l;
     if (task == FB_TASK_SV) {
       l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
@@ -127,54 +166,92 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
       l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
     }
     loss[b] = l;
+    if (b < FB_LOSS_LDS) s_lv[b] = l;
   }
   // max |audio - adver| over the perturb kernel's per-workgroup partials (order-independent: every thread takes a
   // strided share instead of thread 0 walking up to N / 256 entries alone)
   __shared__ double s_dmax[4];
   {
-    double dm = 0.0;
-    for (int i = threadIdx.x; i < n_dist_part; i += blockDim.x) { const double v = dist_part[i]; dm = v > dm ? v : dm; }
+    double dm = dist_first > 0.0 ? dist_first : 0.0;
+    for (int i = threadIdx.x + blockDim.x; i < n_dist_part; i += blockDim.x) { const double v = dist_part[i]; dm = v > dm ? v : dm; }
     dm = fb_wave_max(dm);
     if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dm;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(my_err, o, 64); my_err = v > my_err ? v : my_err; }
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) s_errw[threadIdx.x >> 6] = my_err;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int spd = B - 1;
-    out->adver_loss = loss[0];
-    auto el = [&](int i) { return D1{loss[1 + i]}; };
-    const double lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    const bool lds_l = B <= FB_LOSS_LDS;
+    int s_err = 0;
+    for (int i = 0; i < (int)((blockDim.x + 63) >> 6) && i < 16; ++i) s_err = s_errw[i] > s_err ? s_errw[i] : s_err;
+    const double al = lds_l ? s_lv[0] : loss[0];
+    out->adver_loss = al;
+    double lsum;
+    if (lds_l) {
+      auto el = [&](int i) { return D1{s_lv[1 + i]}; };
+      lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    } else {
+      auto el = [&](int i) { return D1{loss[1 + i]}; };
+      lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+    }
     // np.mean :243 -- of an empty slice when samples_per_draw < 2: NaN, like NumPy
-    out->final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
-    for (int m = 0; m < S && m < 62; ++m) out->score0[m] = scores[m];
+    const double final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
+    out->final_loss = final_loss;
+    const double *sc0 = sc_lds ? s_sc : scores;  // row 0 = the clean adver
+    for (int m = 0; m < S && m < 62; ++m) out->score0[m] = sc0[m];
     double d = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
     out->distance = d;
     out->err = s_err;
     if (ctl) {
       double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
-      const double al = loss[0];
+      double lr = c.lr;
       if (s_err) {
         ctl->err = s_err;
         ctl->stop = 1;
       } else {
-        if (al < 0.0 && !ctl->disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
+        if (al < 0.0 && !c.disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
           ctl->stop = 1;
           ctl->broke = 1;
           ctl->stop_iter = it;
         } else {  // :195-200
-          const int PL = ctl->plateau_length;
+          const int PL = c.plateau_length;
           if (PL > 0) {
-            int n = ctl->n_ls;
-            if (n < PL) {
-              ctl->ls[n++] = out->final_loss;
+            int n = c.n_ls;
+            bool up = false;
+            if (PL <= FB_LS_LOCAL) {  // the window of recent losses in registers (fetched at the top)
+              if (n < PL) {
+#pragma unroll
+                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == n) lsv[i] = final_loss;
+                c.ls[n++] = final_loss;
+              } else {
+#pragma unroll
+                for (int i = 1; i < FB_LS_LOCAL; ++i) if (i < PL) lsv[i - 1] = lsv[i];
+#pragma unroll
+                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) lsv[i] = final_loss;
+#pragma unroll
+                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i < PL) c.ls[i] = lsv[i];
+              }
+              double last = lsv[0];
+#pragma unroll
+              for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) last = lsv[i];
+              up = n == PL && last > lsv[0];
             } else {
-              for (int i = 1; i < PL; ++i) ctl->ls[i - 1] = ctl->ls[i];
-              ctl->ls[PL - 1] = out->final_loss;
+              if (n < PL) {
+                c.ls[n++] = final_loss;
+              } else {
+                for (int i = 1; i < PL; ++i) c.ls[i - 1] = c.ls[i];
+                c.ls[PL - 1] = final_loss;
+              }
+              up = n == PL && c.ls[PL - 1] > c.ls[0];
             }
-            if (n == PL && ctl->ls[PL - 1] > ctl->ls[0]) {
-              if (ctl->lr > ctl->min_lr) {
-                const double l2 = __ddiv_rn(ctl->lr, ctl->plateau_drop);
-                ctl->lr = l2 > ctl->min_lr ? l2 : ctl->min_lr;
+            if (up) {
+              if (lr > c.min_lr) {
+                const double l2 = __ddiv_rn(lr, c.plateau_drop);
+                lr = l2 > c.min_lr ? l2 : c.min_lr;
+                ctl->lr = lr;
               }
               n = 0;
             }
@@ -182,8 +259,8 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
           }
         }
         if (row) {
-          row[0] = d; row[1] = al; row[2] = ctl->lr;
-          for (int m = 0; m < S; ++m) row[3 + m] = scores[m];
+          row[0] = d; row[1] = al; row[2] = lr;
+          for (int m = 0; m < S; ++m) row[3 + m] = sc0[m];
         }
         ctl->iters_done = it + 1;
       }

@@ -1053,11 +1053,26 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
   double acc = 0.0;
   for (int r = r0 + threadIdx.x; r < r1; r += 256) {
     float mx = FB_GMM_NEG;
-    for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
     double ssum = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-      const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
-      ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+    constexpr int MC = 8;
+    if (n_chunks <= MC) {  // every partial of the row requested at once (a loop over a run-time count walks them one
+      float pm[MC], ps[MC];  // L2 round trip at a time); same operations in the same order
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const size_t o = ((size_t)min(c, n_chunks - 1) * g.M + m) * rows_cap + r;
+        pm[c] = part_m[o];
+        ps[c] = part_s[o];
+      }
+#pragma unroll
+      for (int c = 0; c < MC; ++c) if (c < n_chunks) mx = fmaxf(mx, pm[c]);
+#pragma unroll
+      for (int c = 0; c < MC; ++c) if (c < n_chunks) ssum += (double)ps[c] * exp((double)(pm[c] - mx));
+    } else {
+      for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
+      for (int c = 0; c < n_chunks; ++c) {
+        const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
+        ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+      }
     }
     const float ll = (float)((double)mx + log(ssum));
     acc += (double)ll;
@@ -1079,8 +1094,9 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
 // k_gmm_finalize + k_loss in one launch (GMM systems inside the NES loop): every workgroup finishes one (utterance,
 // model) average as k_gmm_finalize does; the workgroup that finishes last (device counter, left at zero) then runs the
 // loss / loop-control body on the complete raw matrix.  Same arithmetic and orders as the two kernels.
+#define FB_FIN_THREADS 512
 template <bool SMALL>
-__global__ __launch_bounds__(256) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
+__global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,
                                                            int n_chunks, const int *__restrict__ row_off, int B,
                                                            double *__restrict__ raw, int *__restrict__ counter,
@@ -1097,19 +1113,48 @@ __global__ __launch_bounds__(256) void k_gmm_finalize_loss(FbGmmDev g, const flo
   const int r0 = row_off[b], r1 = row_off[b + 1];
   __shared__ double red[256];
   __shared__ int s_last;
+  // FB_FIN_THREADS threads work out the frame log-likelihoods (four float64 exp and a log each: with 256 threads an
+  // utterance of 257 .. 512 voiced frames costs two passes), threads 0 .. 255 then add them up in the order the
+  // 256-thread form had: thread t takes frames t, t + 256, ... (bit-identical averages)
+  constexpr int FB_LL_LDS = 2048;
+  __shared__ float s_ll[FB_LL_LDS];
+  const bool wide = r1 - r0 <= FB_LL_LDS;
   double acc = 0.0;
-  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+  for (int r = r0 + threadIdx.x; r < r1; r += (wide ? (int)blockDim.x : 256)) {
+    if (!wide && threadIdx.x >= 256) break;
+
     float mx = FB_GMM_NEG;
-    for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
     double ssum = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-      const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
-      ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+    constexpr int MC = 8;
+    if (n_chunks <= MC) {  // every partial of the row requested at once (a loop over a run-time count walks them one
+      float pm[MC], ps[MC];  // L2 round trip at a time); same operations in the same order
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const size_t o = ((size_t)min(c, n_chunks - 1) * g.M + m) * rows_cap + r;
+        pm[c] = part_m[o];
+        ps[c] = part_s[o];
+      }
+#pragma unroll
+      for (int c = 0; c < MC; ++c) if (c < n_chunks) mx = fmaxf(mx, pm[c]);
+#pragma unroll
+      for (int c = 0; c < MC; ++c) if (c < n_chunks) ssum += (double)ps[c] * exp((double)(pm[c] - mx));
+    } else {
+      for (int c = 0; c < n_chunks; ++c) mx = fmaxf(mx, part_m[((size_t)c * g.M + m) * rows_cap + r]);
+      for (int c = 0; c < n_chunks; ++c) {
+        const size_t o = ((size_t)c * g.M + m) * rows_cap + r;
+        ssum += (double)part_s[o] * exp((double)(part_m[o] - mx));
+      }
     }
     const float ll = (float)((double)mx + log(ssum));
-    acc += (double)ll;
+    if (wide) s_ll[r - r0] = ll;
+    else acc += (double)ll;
   }
-  red[threadIdx.x] = acc;
+  if (wide) {
+    __syncthreads();
+    if (threadIdx.x < 256)
+      for (int r = threadIdx.x; r < r1 - r0; r += 256) acc += (double)s_ll[r];
+  }
+  if (threadIdx.x < 256) red[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -1138,11 +1183,11 @@ void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *
                                  const double *dist_part, int n_dist_part, double *scores, double *loss, FbNesDev *out,
                                  FbCtlDev *ctl, double *trace, int it) {
   if (B - 1 <= 128)
-    hipLaunchKernelGGL(k_gmm_finalize_loss<true>, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
+    hipLaunchKernelGGL(k_gmm_finalize_loss<true>, dim3(B, g.M), dim3(FB_FIN_THREADS), 0, s, g, part_m, part_s, rows_cap, n_chunks,
                        row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
                        true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
   else
-    hipLaunchKernelGGL(k_gmm_finalize_loss<false>, dim3(B, g.M), dim3(256), 0, s, g, part_m, part_s, rows_cap, n_chunks,
+    hipLaunchKernelGGL(k_gmm_finalize_loss<false>, dim3(B, g.M), dim3(FB_FIN_THREADS), 0, s, g, part_m, part_s, rows_cap, n_chunks,
                        row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
                        true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
 }
