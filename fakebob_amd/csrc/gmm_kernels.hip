@@ -1094,7 +1094,10 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
 // k_gmm_finalize + k_loss in one launch (GMM systems inside the NES loop): every workgroup finishes one (utterance,
 // model) average as k_gmm_finalize does; the workgroup that finishes last (device counter, left at zero) then runs the
 // loss / loop-control body on the complete raw matrix.  Same arithmetic and orders as the two kernels.
-#define FB_FIN_THREADS 512
+// 256 threads: with 512 an utterance of up to 512 voiced frames would take one pass instead of two, but the kernel is
+// no faster (its time is the last workgroup's chain of small global round trips) and the wider workgroups get in the
+// way of the other attacks' kernels: 7.3 k against 8.0 k it/s with three attacks in flight, measured.
+#define FB_FIN_THREADS 256
 template <bool SMALL>
 __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,
@@ -1113,9 +1116,9 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
   const int r0 = row_off[b], r1 = row_off[b + 1];
   __shared__ double red[256];
   __shared__ int s_last;
-  // FB_FIN_THREADS threads work out the frame log-likelihoods (four float64 exp and a log each: with 256 threads an
-  // utterance of 257 .. 512 voiced frames costs two passes), threads 0 .. 255 then add them up in the order the
-  // 256-thread form had: thread t takes frames t, t + 256, ... (bit-identical averages)
+  // the workgroup's threads work out the frame log-likelihoods (four float64 exp and a log each), threads 0 .. 255
+  // then add them up in a fixed order: thread t takes frames t, t + 256, ... (the average does not depend on the
+  // workgroup size)
   constexpr int FB_LL_LDS = 2048;
   __shared__ float s_ll[FB_LL_LDS];
   const bool wide = r1 - r0 <= FB_LL_LDS;
