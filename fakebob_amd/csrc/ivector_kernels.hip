@@ -935,41 +935,82 @@ __device__ __forceinline__ double fb_readlane_f64(double v, int src) {
 // L below, = row c of L^-1 above), broadcast from the lower half, and subtracted from the later columns -- in the
 // upper half that is exactly the substitution step, so the inverse costs no instruction of its own and 64 registers
 // hold everything (round 1: separate passes, the inverse reading L back from LDS; 49 % of the solve's cycles).
-// The broadcast goes through LDS (one ds_write of the column, then reads of one address by all lanes; bc = 2 x 32
+// The broadcast goes through LDS (one ds_write of the column, then reads of one address by all lanes; bc = 2 x 64
 // doubles, alternating): two v_readlane + wait states per element made every update a 20-cycle affair, and hipcc
-// turned the loop left-looking to save the scalar registers -- c dependent fmas in front of every pivot.  The empty
-// asm keeps it right-looking: the 31 - c updates of a column are independent, a pivot waits for ONE of them.
+// turned the loop left-looking to save the scalar registers -- c dependent fmas in front of every pivot.  Scheduling
+// regions keep it right-looking: the 31 - c updates of a column are independent, a pivot waits for ONE of them.
 // X: in = A[rr][c] (lower triangle, zeros above; identity rows beyond a short block) / delta(r, rr);
 // out = L[rr][c] / Linv[r][rr].  Returns true on a non-positive pivot.
-__device__ __forceinline__ bool fb_chol32_fused(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane) {
-  static_assert(FB_IV_NB == 32, "the asm operand lists below name 32 registers");
-  bool bad = false;
+// column C of fb_chol32_fused (compile-time recursion: the register array X must never be indexed at run time).
+// l = column C, scaled, already in the broadcast buffer C & 1.  The broadcast values of column C are read into
+// registers; first the next pivot's column is updated, then that pivot's chain -- v_readlane, v_rsq_f64, two Newton steps,
+// the scaling: ten dependent operations, issued in order -- runs with the other 30 - C updates of column C dealt into
+// its nine gaps (one scheduling region each): they are independent of the chain and fill its latency.  (In one piece
+// the chain ran back to back and the updates behind it: ~900 cycles per column, 12 us per block, the longest path of
+// the whole solve.)
+template <int C, int S>
+__device__ __forceinline__ void fb_chol32_gap(double (&X)[FB_IV_NB], const double (&col)[FB_IV_NB], double l) {
+  constexpr int P = FB_IV_NB - 2 - C, Q = (P + 8) / 9;
 #pragma unroll
-  for (int c = 0; c < FB_IV_NB; ++c) {
-    const double d = fb_readlane_f64(X[c], c);
-    bad |= !(d > 0.0);
-    // 1/sqrt(d) by v_rsq_f64 + two Newton steps (full double precision): no sqrt, no division in the column loop
-    const double dd = d > 0.0 ? d : 1.0;
-    double ri = __builtin_amdgcn_rsq(dd);
-    ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-    ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-    const double l = X[c] * ri;  // lower half: L[rr][c] (0 above the diagonal, d * ri on it); upper half: Linv[c][rr]
-    X[c] = l;
-    if (c + 1 < FB_IV_NB) {
-      double *col = bc + (c & 1) * FB_IV_NB;
-      if (lane < FB_IV_NB) col[lane] = l;
+  for (int u = 0; u < Q; ++u) {
+    constexpr int base = C + 2 + S * Q;
+    if (base + u < FB_IV_NB) X[base + u] = fma(-l, col[base + u], X[base + u]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int C>
+__device__ __forceinline__ void fb_chol32_col(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane, double l, bool &bad) {
+  if constexpr (C + 1 < FB_IV_NB) {
+    double col[FB_IV_NB];  // the broadcast values of column C, all requested before the chain starts
+#pragma unroll
+    for (int cc = C + 1; cc < FB_IV_NB; ++cc) col[cc] = bc[(C & 1) * 64 + cc];
+    X[C + 1] = fma(-l, col[C + 1], X[C + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const double d = fb_readlane_f64(X[C + 1], C + 1);
+    fb_chol32_gap<C, 0>(X, col, l);
+    bad |= !(d > 0.0);  // off the chain: a non-positive pivot yields NaNs below and is reported
+    double ri = __builtin_amdgcn_rsq(d);  // 1/sqrt(d): v_rsq_f64 + two Newton steps (full double precision)
+    fb_chol32_gap<C, 1>(X, col, l);
+    const double hd = -0.5 * d;           // (independent of the rsq result)
+    double t = hd * ri;
+    fb_chol32_gap<C, 2>(X, col, l);
+    double u1 = fma(t, ri, 1.5);
+    fb_chol32_gap<C, 3>(X, col, l);
+    ri = ri * u1;
+    fb_chol32_gap<C, 4>(X, col, l);
+    t = hd * ri;
+    fb_chol32_gap<C, 5>(X, col, l);
+    u1 = fma(t, ri, 1.5);
+    fb_chol32_gap<C, 6>(X, col, l);
+    ri = ri * u1;
+    fb_chol32_gap<C, 7>(X, col, l);
+    const double l_next = X[C + 1] * ri;  // lower half: L[rr][C+1]; upper half: Linv[C+1][rr]
+    X[C + 1] = l_next;
+    fb_chol32_gap<C, 8>(X, col, l);       // (reads buffer C & 1; the write below goes to the other one)
+    if constexpr (C + 2 < FB_IV_NB) {
+      bc[((C + 1) & 1) * 64 + lane] = l_next;  // all 64 lanes write (the upper half into the buffer's unused half): no branch
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int cc = c + 1; cc < FB_IV_NB; ++cc) X[cc] = fma(-l, col[cc], X[cc]);
-      // the column's updates are finished HERE (two statements: an asm takes 30 operands at most)
-      asm volatile("" : "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]),
-                        "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]), "+v"(X[16]));
-      asm volatile("" : "+v"(X[17]), "+v"(X[18]), "+v"(X[19]), "+v"(X[20]), "+v"(X[21]), "+v"(X[22]), "+v"(X[23]), "+v"(X[24]),
-                        "+v"(X[25]), "+v"(X[26]), "+v"(X[27]), "+v"(X[28]), "+v"(X[29]), "+v"(X[30]), "+v"(X[31]));
     }
+    fb_chol32_col<C + 1>(X, bc, lane, l_next, bad);
   }
+}
+__device__ __forceinline__ bool fb_chol32_fused(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane) {
+  bool bad = false;
+  const double d = fb_readlane_f64(X[0], 0);
+  bad |= !(d > 0.0);
+  const double dd = d > 0.0 ? d : 1.0;
+  double ri = __builtin_amdgcn_rsq(dd);
+  ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+  ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
+  const double l = X[0] * ri;
+  X[0] = l;
+  bc[lane] = l;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  fb_chol32_col<0>(X, bc, lane, l, bad);
   return bad;
 }
 // The factorisation runs IN PLACE on the packed lower triangle the contraction produced (a dense copy cost 126 us of
