@@ -270,6 +270,28 @@ def test_pipeline_round_trips_are_constructor_options(tmp_path, oracle):
         e.close()
 
 
+@pytest.mark.parametrize("C", [32, 96])
+@pytest.mark.parametrize("n_speakers", [1, 5])
+def test_wide_scoring_kernel_single_tile_chunks(oracle, monkeypatch, n_speakers, C):
+    """One to three component tiles in all: a chunk is a single tile, so the LDS-DMA schedule of k_gmm_fx2w only ever
+    re-requests its last group (the clamp at the chunk's end) -- against the oracle."""
+    monkeypatch.delenv("FB_GMM_NARROW", raising=False)
+    monkeypatch.delenv("FB_GMM_MODE", raising=False)
+    cfg = oracle.default_cfg()
+    ubm, spk = synthetic_gmm_system(n_speakers=n_speakers, C=C, D=72)
+    wavs = [_wav(u, 9000 + 3111 * u) for u in range(5)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, tv_o = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=4)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        raw_g, tv_g = e.score_raw(wavs)
+    finally:
+        e.close()
+    assert np.array_equal(tv_g, tv_o)
+    assert np.abs(raw_g - raw_o).max() <= 2e-5
+
+
 @pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5])
 def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers):
     """k_gmm_fx2w is instantiated per model count M = 2 .. 6 (SV: UBM + 1; OSI: UBM + speakers): each instantiation
