@@ -351,14 +351,16 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
       // samples reflected at the utterance edges
       // (a wave with an edge frame used to walk these 16 points one global round trip at a time -- 16 x ~1.5 us, the
       //  longest path of the whole launch; the indices first, then all 32 loads in flight)
-      int64_t kk[32];
+      int kk[32];
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
         const int s0 = 32 * a + 2 * tl;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          int64_t k = (int64_t)start + min(s0 + u, L - 1);
-          while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * (int64_t)n - 1 - k; }
+          int k = start + min(s0 + u, L - 1);
+          // (2 n - 1 - k in unsigned arithmetic: n < 2^31, the result is in [-(L), n))
+          k = k < 0 ? -k - 1 : (k >= n ? (int)(2u * (unsigned)n - 1u - (unsigned)k) : k);  // one reflection: all but tiny utterances
+          while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = (int)(2u * (unsigned)n - 1u - (unsigned)k); }
           kk[2 * a + u] = k;
         }
       }
