@@ -307,6 +307,10 @@ __device__ __forceinline__ void fb_dft16(double2 (&v)[16]) {
     for (int j = i + 1; j < 4; ++j) { const double2 tmp = v[4 * i + j]; v[4 * i + j] = v[4 * j + i]; v[4 * j + i] = tmp; }
 }
 
+// NFULL: the points a < NFULL lie inside the frame for every lane (32 a + 31 < L: NFULL <= L / 32), so their window /
+// validity selects and mask multiplications are dropped at compile time (12 of 16 points for the recipe's L = 400:
+// ~ 12 % of a group's instructions; the kernel is bound by its float64 instruction count); 0 = no assumption.
+template <int NFULL>
 __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev fe, int melw_n,
                                                                    const int16_t *__restrict__ wav,
                                                                    const int4 *__restrict__ frame_rec,
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
 #pragma unroll
       for (int a = 0; a < 16; ++a) {  // unconditional loads on clamped indices, masked afterwards
         const int s0 = 32 * a + 2 * tl;
-        const int lo16 = fr[min(s0, L - 1)], hi16 = fr[min(s0 + 1, L - 1)];
+        const int lo16 = fr[a < NFULL ? s0 : min(s0, L - 1)], hi16 = fr[a < NFULL ? s0 + 1 : min(s0 + 1, L - 1)];
         xq[a] = (hi16 << 16) | (lo16 & 0xffff);
       }
     } else {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       const int s0 = 32 * a + 2 * t;
-      isum += (s0 < L ? (int)(short)xp[a] : 0) + (s0 + 1 < L ? (xp[a] >> 16) : 0);
+      isum += (a < NFULL || s0 < L ? (int)(short)xp[a] : 0) + (a < NFULL || s0 + 1 < L ? (xp[a] >> 16) : 0);
     }
     // DC: the samples are integers, |sum| < 2^24: exact in int32 in any order
     const double mean = fe.remove_dc ? (double)fb_row_sum_i32(isum) / (double)L : 0.0;
@@ -413,10 +417,12 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
       const int rot = fb_dpp_i32<0x121, 0xf>(xa1);  // row_ror:1: lane t gets lane (t - 1) & 15
       const int xprev = t == 0 ? (a == 0 ? xa0 : prev_rot) : rot;  // Kaldi: sample 0 is pre-emphasised with itself
       prev_rot = rot;
-      const float2 wq = *reinterpret_cast<const float2 *>(&s_win[min(s0, (L - 1) & ~1)]);  // L even: the pair exists
-      const double w0 = s0 < L ? (double)wq.x : 0.0, w1 = s0 + 1 < L ? (double)wq.y : 0.0;
-      const double m0 = s0 < L ? 1.0 : 0.0, m1 = s0 + 1 < L ? 1.0 : 0.0;
-      const double av = ((double)xa0 - mean) * m0, cv = ((double)xa1 - mean) * m1;
+      const bool inside = a < NFULL;  // compile time
+      const float2 wq = *reinterpret_cast<const float2 *>(&s_win[inside ? s0 : min(s0, (L - 1) & ~1)]);  // L even: the pair exists
+      const double w0 = inside || s0 < L ? (double)wq.x : 0.0, w1 = inside || s0 + 1 < L ? (double)wq.y : 0.0;
+      const double m0 = inside || s0 < L ? 1.0 : 0.0, m1 = inside || s0 + 1 < L ? 1.0 : 0.0;
+      const double av = inside ? (double)xa0 - mean : ((double)xa0 - mean) * m0;
+      const double cv = inside ? (double)xa1 - mean : ((double)xa1 - mean) * m1;
       const double pm = (double)xprev - mean;
       en = fma(av, av, en);
       en = fma(cv, cv, en);
@@ -523,15 +529,20 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
     unsigned long long bit16 = 0;
     bool ok16 = true;
     if (fb_device_needs_optin(optin16, &bit16)) {
-      ok16 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      ok16 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       if (ok16) optin16.fetch_or(bit16, std::memory_order_release);
     }
     if (ok16 && shm16 <= 160 * 1024) {
       const int n_groups = (total_frames + 3) / 4;
       const int rounds = (n_groups + 256 * FB_R16_WAVES - 1) / (256 * FB_R16_WAVES);
       const int blocks = (n_groups + rounds * FB_R16_WAVES - 1) / (rounds * FB_R16_WAVES);
-      hipLaunchKernelGGL(k_mfcc_r16, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
-                         reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
+      if (fe.L / 32 >= 12)
+        hipLaunchKernelGGL(k_mfcc_r16<12>, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
+                           reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
+      else
+        hipLaunchKernelGGL(k_mfcc_r16<0>, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
+                           reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
       return;
     }
   }
