@@ -310,7 +310,8 @@ __device__ __forceinline__ void fb_dft16(double2 (&v)[16]) {
 // NFULL: the points a < NFULL lie inside the frame for every lane (32 a + 31 < L: NFULL <= L / 32), so their window /
 // validity selects and mask multiplications are dropped at compile time (12 of 16 points for the recipe's L = 400:
 // ~ 12 % of a group's instructions; the kernel is bound by its float64 instruction count); 0 = no assumption.
-template <int NFULL>
+// RAW: which of the two frame energies is wanted (--raw-energy): the other one's 32 fmas are not issued.
+template <int NFULL, bool RAW>
 __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev fe, int melw_n,
                                                                    const int16_t *__restrict__ wav,
                                                                    const int4 *__restrict__ frame_rec,
@@ -424,15 +425,19 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
       const double av = inside ? (double)xa0 - mean : ((double)xa0 - mean) * m0;
       const double cv = inside ? (double)xa1 - mean : ((double)xa1 - mean) * m1;
       const double pm = (double)xprev - mean;
-      en = fma(av, av, en);
-      en = fma(cv, cv, en);
+      if constexpr (RAW) {
+        en = fma(av, av, en);
+        en = fma(cv, cv, en);
+      }
       const double y0 = (av - fe.preemph * pm) * w0;
       const double y1 = (cv - fe.preemph * av) * w1;
-      en2 = fma(y0, y0, en2);
-      en2 = fma(y1, y1, en2);
+      if constexpr (!RAW) {
+        en2 = fma(y0, y0, en2);
+        en2 = fma(y1, y1, en2);
+      }
       v[a] = make_double2(y0, y1);
     }
-    const double energy = fb_row_sum_f64(fe.raw_energy ? en : en2);  // its log is taken with the mel logs below
+    const double energy = fb_row_sum_f64(RAW ? en : en2);  // its log is taken with the mel logs below
 
     // ---- 256-point FFT = radix-16 over a, twiddle W256^(t k1), transpose, radix-16 over b
     fb_dft16(v);
@@ -529,20 +534,23 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
     unsigned long long bit16 = 0;
     bool ok16 = true;
     if (fb_device_needs_optin(optin16, &bit16)) {
-      ok16 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void *>(k_mfcc_r16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      const void *fns[] = {reinterpret_cast<const void *>(k_mfcc_r16<12, true>), reinterpret_cast<const void *>(k_mfcc_r16<12, false>),
+                           reinterpret_cast<const void *>(k_mfcc_r16<0, true>), reinterpret_cast<const void *>(k_mfcc_r16<0, false>)};
+      for (const void *fn : fns)
+        ok16 = ok16 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       if (ok16) optin16.fetch_or(bit16, std::memory_order_release);
     }
     if (ok16 && shm16 <= 160 * 1024) {
       const int n_groups = (total_frames + 3) / 4;
       const int rounds = (n_groups + 256 * FB_R16_WAVES - 1) / (256 * FB_R16_WAVES);
       const int blocks = (n_groups + rounds * FB_R16_WAVES - 1) / (rounds * FB_R16_WAVES);
-      if (fe.L / 32 >= 12)
-        hipLaunchKernelGGL(k_mfcc_r16<12>, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
-                           reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
-      else
-        hipLaunchKernelGGL(k_mfcc_r16<0>, dim3(blocks), dim3(64 * FB_R16_WAVES), shm16, s, fe, melw_n, wav,
-                           reinterpret_cast<const int4 *>(frame_rec), total_frames, mfcc);
+      const dim3 grid(blocks), blk(64 * FB_R16_WAVES);
+      const int4 *rec = reinterpret_cast<const int4 *>(frame_rec);
+      const bool full12 = fe.L / 32 >= 12;
+      if (full12 && fe.raw_energy) hipLaunchKernelGGL((k_mfcc_r16<12, true>), grid, blk, shm16, s, fe, melw_n, wav, rec, total_frames, mfcc);
+      else if (full12) hipLaunchKernelGGL((k_mfcc_r16<12, false>), grid, blk, shm16, s, fe, melw_n, wav, rec, total_frames, mfcc);
+      else if (fe.raw_energy) hipLaunchKernelGGL((k_mfcc_r16<0, true>), grid, blk, shm16, s, fe, melw_n, wav, rec, total_frames, mfcc);
+      else hipLaunchKernelGGL((k_mfcc_r16<0, false>), grid, blk, shm16, s, fe, melw_n, wav, rec, total_frames, mfcc);
       return;
     }
   }

@@ -22,6 +22,9 @@ FRONTENDS = [
     dict(delta_order=0),                                             # no deltas, D = 24
     dict(sample_freq=8000.0, frame_length=200, frame_shift=80, padded_length=256, high_freq=3700.0),  # generic k_mfcc
     dict(num_ceps=20, num_mel_bins=23, delta_order=3, delta_window=2),  # D = 80
+    dict(raw_energy=0),                                              # energy after pre-emphasis and windowing (k_mfcc_r16<12, false>)
+    dict(raw_energy=0, frame_length=320, frame_shift=160),           # ... with a short window (k_mfcc_r16<0, false>)
+    dict(frame_length=320, frame_shift=160),                         # k_mfcc_r16<0, true>
 ]
 
 
