@@ -463,13 +463,15 @@ __global__ __launch_bounds__(64 * FB_R16_WAVES, 1) void k_mfcc_r16(FbFrontendDev
       const int kc = k2 < 16 ? t + 16 * k2 : Nc;
       const double2 zk = k2 < 16 ? v[k2 & 15] : X[fb_r16_phys(0)];
       const double2 zr = X[fb_r16_phys((Nc - kc) & (Nc - 1))];
-      const double er = 0.5 * (zk.x + zr.x), ei = 0.5 * (zk.y - zr.y);
+      // X[k] = E + W O with E = (Z[k] + conj Z[N-k]) / 2, O = -i (Z[k] - conj Z[N-k]) / 2: the four halvings are
+      // taken out of the sums and applied once, as 1/4 of the power -- exact (a power of two commutes with every
+      // rounding here), so the result is the same double
+      const double er = zk.x + zr.x, ei = zk.y - zr.y;
       const double dr = zk.x - zr.x, di = zk.y + zr.y;
-      const double orr = 0.5 * di, oi = -0.5 * dr;
       const double2 wk = s_twf[kc];
-      const double xr = er + (wk.x * orr - wk.y * oi);
-      const double xi = ei + (wk.x * oi + wk.y * orr);
-      pwv[k2] = xr * xr + xi * xi;
+      const double xr = er + (wk.x * di + wk.y * dr);
+      const double xi = ei + (wk.y * di - wk.x * dr);
+      pwv[k2] = 0.25 * (xr * xr + xi * xi);
       if ((k2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     fb_wave_sync();
