@@ -287,16 +287,20 @@ __device__ __forceinline__ void fb_dft16(double2 (&v)[16]) {
   for (int n2 = 0; n2 < 4; ++n2) fb_dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);  // -> A[n2][k1] at v[4 k1 + n2]
   constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;
   // W16^m = (cos(pi m / 8), -sin(pi m / 8)), m = n2 * k1
-  const double2 W1 = make_double2(C1, -S1), W2 = make_double2(R2, -R2), W3 = make_double2(S1, -C1),
-                W4 = make_double2(0.0, -1.0), W6 = make_double2(-R2, -R2), W9 = make_double2(-C1, S1);
+  const double2 W1 = make_double2(C1, -S1), W3 = make_double2(S1, -C1), W9 = make_double2(-C1, S1);
+  // W2 = (1 - i) / sqrt 2, W4 = -i, W6 = -(1 + i) / sqrt 2: a swap, or two additions and two multiplications, instead of
+  // the general product's four and two (the compiler may not fold a multiplication by 0 or by equal constants)
+  auto mul_w2 = [&](double2 a) { return make_double2(R2 * (a.x + a.y), R2 * (a.y - a.x)); };
+  auto mul_w4 = [&](double2 a) { return make_double2(a.y, -a.x); };
+  auto mul_w6 = [&](double2 a) { return make_double2(R2 * (a.y - a.x), -(R2 * (a.x + a.y))); };
   v[4 * 1 + 1] = fb_cmul(v[4 * 1 + 1], W1);
-  v[4 * 1 + 2] = fb_cmul(v[4 * 1 + 2], W2);
+  v[4 * 1 + 2] = mul_w2(v[4 * 1 + 2]);
   v[4 * 1 + 3] = fb_cmul(v[4 * 1 + 3], W3);
-  v[4 * 2 + 1] = fb_cmul(v[4 * 2 + 1], W2);
-  v[4 * 2 + 2] = fb_cmul(v[4 * 2 + 2], W4);
-  v[4 * 2 + 3] = fb_cmul(v[4 * 2 + 3], W6);
+  v[4 * 2 + 1] = mul_w2(v[4 * 2 + 1]);
+  v[4 * 2 + 2] = mul_w4(v[4 * 2 + 2]);
+  v[4 * 2 + 3] = mul_w6(v[4 * 2 + 3]);
   v[4 * 3 + 1] = fb_cmul(v[4 * 3 + 1], W3);
-  v[4 * 3 + 2] = fb_cmul(v[4 * 3 + 2], W6);
+  v[4 * 3 + 2] = mul_w6(v[4 * 3 + 2]);
   v[4 * 3 + 3] = fb_cmul(v[4 * 3 + 3], W9);
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) fb_dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);  // X[k1 + 4 k2] at v[4 k1 + k2]
