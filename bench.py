@@ -319,31 +319,39 @@ TRAFFIC_FILE = "r02_traffic.json"
 MFMA16_POWER_LIMITED_TFLOPS = 1660.0
 
 
-def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows):
+def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"):
     """Roofline of the dominant kernel.  `achieved` = ALGORITHMIC flops ((S+1)*C*4D per voiced frame,
     two length-D dot products per component per model as Kaldi evaluates them) / average launch duration;
     `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16 / bf16: 2.5 PF), so `frac` is a true
-    fraction.  `executed_*`: the products the kernel really issues -- (1+M)/(2M) of
-    the algorithmic ones because the quadratic term is shared by the 6 models, times 3 (fx2) / 6 (bx3) partial
-    products per f32 product, times the K padding."""
+    fraction.  `executed_*`: the products the kernel really issues per (frame, component), K padded to 16*nk:
+    k_gmm_fx2w -- the shared quadratic item and the base model with 3 partial products each, every other model as a
+    delta item with P partial products; k_gmm_fx2 / k_gmm_bx3 -- quadratic item + one item per model, 3 / 6 partial
+    products each."""
     M = S_SPK + 1
-    shared = (1 + M) / (2.0 * M)
     per_s = 1.0 / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
     achieved = flops_launch * per_s
+    alg_per_fc = M * 4.0 * D_FEAT                                  # algorithmic flops per (frame, component)
     if GMM_MODE == "fx2":
         nk = (D_FEAT + 1 + 15) // 16
-        ex, pipe, peak = flops_launch * shared * 3 * (16.0 * nk / D_FEAT), "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
-        name = ("k_gmm_fx2w<5,6> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split accurate "
-                "to half an f32 ulp, 3 partial products on v_mfma_f32_32x32x16_f16, f32 accumulate; one wave per SIMD, "
-                "64 frames per wave, software-pipelined)")
+        pipe, peak = "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
+        if variant.startswith("fx2w/"):
+            P = int(variant.split("/")[1])
+            ex = flops_launch * (3 + 3 + (M - 1) * P) * 2.0 * 16 * nk / alg_per_fc
+            name = ("k_gmm_fx2w<5,6,%d> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split, "
+                    "f32 accumulate on v_mfma_f32_32x32x16_f16: shared quadratic item and the UBM with 3 partial "
+                    "products, the 5 speaker models as deltas from the UBM's accumulator with %d; one wave per SIMD, "
+                    "64 frames per wave, software-pipelined)" % (P, P))
+        else:
+            ex = flops_launch * (1 + M) * 3 * 2.0 * 16 * nk / alg_per_fc
+            name = "k_gmm_fx2<5,false> (two-term f16 split, 3 partial products per item, quadratic item shared)"
     else:
         nk = (D_FEAT + 3 + 15) // 16
-        ex, pipe, peak = flops_launch * shared * 6 * (16.0 * nk / D_FEAT), "bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_F16_MFMA_TFLOPS
+        ex, pipe, peak = flops_launch * (1 + M) * 6 * 2.0 * 16 * nk / alg_per_fc, "bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_F16_MFMA_TFLOPS
         name = ("k_gmm_bx3<5,false> (diag-GMM log-likelihood + logsumexp; f32 operands as an exact 3-way bf16 split, "
                 "6 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": None, "avg_launch_ms": gmm_ms_avg, "algorithmic_flops_per_launch": flops_launch,
-         "kernel": name, "peak_pipe": pipe,
+         "kernel": name, "kernel_variant": variant, "peak_pipe": pipe,
          "executed_flops_per_launch": ex, "executed_tflops": ex * per_s, "executed_frac": ex * per_s / peak}
     r["executed_frac_of_power_limited_ceiling"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS
     if solo_ms and solo_ms > 0:
@@ -462,7 +470,7 @@ def main():
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
-            "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows),
+            "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, engs[0].gmm_kernel_variant),
                              gmm_share_of_stream_time=ms_gmm / ms_dev if ms_dev > 0 else None,
                              note="avg_launch_ms: HIP events around every launch of the timed region on each attack's own "
                                   "stream; with several attacks in flight a launch shares the chip with other attacks' "

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfakebob_hip.so")
+# FAKEBOB_HIP_LIB: a library built elsewhere (an install prefix, a profiling build); default: the in-tree build
+LIB_PATH = os.environ.get("FAKEBOB_HIP_LIB") or os.path.join(_HERE, "lib", "libfakebob_hip.so")
 
 FB_OK = 0
 FB_E_ARG, FB_E_HIP, FB_E_STATE, FB_E_NO_VOICED, FB_E_NOMEM, FB_E_LIMIT, FB_E_CALLBACK = -1, -2, -3, -4, -5, -6, -7
@@ -62,7 +63,7 @@ EXPORTS = [
     "fb_last_error", "fb_version", "fb_device_count", "fb_engine_create", "fb_engine_destroy",
     "fb_default_frontend", "fb_set_frontend", "fb_load_gmm", "fb_load_ivector", "fb_set_system", "fb_num_speakers",
     "fb_score_i16", "fb_score_f64", "fb_system_scores", "fb_get_grad", "fb_attack", "fb_get_grad_ext", "fb_attack_ext",
-    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_iv_active", "fb_stats", "fb_gmm_acc_stats", "fb_last_ivectors", "fb_gmm_kernel_mode",
+    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_iv_active", "fb_stats", "fb_gmm_acc_stats", "fb_last_ivectors", "fb_gmm_kernel_mode", "fb_gmm_kernel_variant",
     "fb_bench_gmm_kernel", "fb_bench_nes",
 ]
 

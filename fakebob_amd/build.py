@@ -15,8 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libfakebob_hip.so")
-SOURCES = ["nes_kernels.hip", "frontend_kernels.hip", "gmm_kernels.hip", "ivector_kernels.hip",
+SOURCES = ["nes_kernels.hip", "frontend_kernels.hip", "gmm_kernels.hip", "gmm_wide_kernel.hip", "ivector_kernels.hip",
            "fb_engine.hip"]
+# per-source flags.  k_gmm_fx2w keeps its MFMA accumulators in vector registers (the logsumexp update reads them in
+# place) and its parked frame operands in accumulation registers: hipcc picks that form of the MFMA with this option
+SOURCE_FLAGS = {"gmm_wide_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -55,7 +58,7 @@ def build(force=False, verbose=False):
     def comp(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         extra = os.environ.get("FB_EXTRA_HIPCC_FLAGS", "").split()
-        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return src, obj, r.returncode, r.stdout
 

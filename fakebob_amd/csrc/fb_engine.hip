@@ -85,7 +85,8 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_items, gmm_images_bx, gmm_images_fx;
+  DevBuf gmm_items, gmm_images_bx, gmm_images_fx, gmm_images_fd;
+  double gmm_delta_rms = 0.0;  // fb_load_gmm's shift statistic behind gmm.delta_p
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
@@ -223,7 +224,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
@@ -425,7 +426,10 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
-  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0;
+  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0;
+  // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
+  // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
+  const bool want_delta = G == 1 && M >= 2 && (C & 31) == 0 && NKF == 5;
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -438,6 +442,12 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
     for (size_t i = 0; i < (size_t)M * C; ++i) {
       max_g = std::max(max_g, fabsf(gconsts[i]));
       finite = finite && std::isfinite(gconsts[i]);
+    }
+    if (want_delta && finite) {  // the deltas share the scaling of the full parameters
+      for (int m = 1; m < M; ++m) {
+        for (size_t i = 0; i < (size_t)C * D; ++i) max_l = std::max(max_l, fabsf(miv[(size_t)m * C * D + i] - miv[i]));
+        for (int c = 0; c < C; ++c) max_g = std::max(max_g, fabsf(gconsts[(size_t)m * C + c] - gconsts[c]));
+      }
     }
     if (!finite || max_l >= lim || max_g >= lim || max_q >= lim || NKF > 6) {
       mode = FB_GMM_MODE_BX3;
@@ -489,8 +499,63 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
           }
         }
       }
-    FBCHK(e->gmm_images_fx.ensure(sizeof(uint16_t) * fx.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
+    FBCHK(e->gmm_images_fx.ensure(sizeof(uint16_t) * fx.size()));
     HIPCHK(hipMemcpy(e->gmm_images_fx.p, fx.data(), sizeof(uint16_t) * fx.size(), hipMemcpyHostToDevice));
+    if (want_delta) {
+      // Delta images of k_gmm_fx2w: items {Q, model 0, delta_1 .. delta_{M-1}} per tile.  Mean-only MAP adaptation
+      // (build_spk_models.py:170, gmm-global-est-map.cc:81) leaves weights and variances alone, so
+      //   ll_m,k(x) = ll_0,k(x) + (gconst_m,k - gconst_0,k) + (means_invvars_m,k - means_invvars_0,k) . x
+      // and the second line is small: the kernel continues the base model's finished accumulator with the delta
+      // item.  The deltas are float32 differences (exact by Sterbenz's lemma for the close values adaptation
+      // produces, correctly rounded otherwise), split into two f16 terms like every other parameter.
+      std::vector<uint16_t> fd((size_t)n_tiles * n_items * per_item, 0);
+      for (int t = 0; t < n_tiles; ++t)
+        for (int it = 0; it < n_items; ++it) {
+          uint16_t *im = &fd[((size_t)t * n_items + it) * per_item];
+          if (it < 2) {  // Q and the base model: as in the full images (the item list is {Q, 0, 1, ..})
+            memcpy(im, &fx[((size_t)t * n_items + it) * per_item], sizeof(uint16_t) * per_item);
+            continue;
+          }
+          const int m = it - 1;
+          for (int cc = 0; cc < 32; ++cc) {
+            const int c = t * 32 + cc;
+            for (int k = 0; k < 16 * NKF; ++k) {
+              uint16_t sp[2] = {0, 0};
+              if (k < D) split2(lscale * (miv[((size_t)m * C + c) * D + k] - miv[(size_t)c * D + k]), sp);
+              else if (k == D) split2(lscale * (gconsts[(size_t)m * C + c] - gconsts[c]), sp);
+              const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
+              for (int s2 = 0; s2 < 2; ++s2) im[(((size_t)s2 * NKF + ch) * 64 + lane) * 8 + i] = sp[s2];
+            }
+          }
+        }
+      FBCHK(e->gmm_images_fd.ensure(sizeof(uint16_t) * fd.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
+      HIPCHK(hipMemcpy(e->gmm_images_fd.p, fd.data(), sizeof(uint16_t) * fd.size(), hipMemcpyHostToDevice));
+      // Products per K chunk of the delta items.  Dropping the frames' second f16 term (P = 2) leaves an error of
+      // 2^-12 |delta . x| per (frame, component), random in sign from frame to frame; P = 1 also drops the deltas'
+      // second term.  b_k = 2^-12 |delta_k * (|mu_k| + 3 sigma_k)|_2 bounds it where component k matters (x within
+      // 3 sigma of its mean); on the utterance averages the measured error is ~0.07 rms(b) for P = 2 and ~0.14 rms(b)
+      // for P = 1 (scratch numpy model).  The thresholds keep the prediction below 4e-6, i.e.
+      // inside the f32 rounding of the ~-150 results; models adapted further than that (few-frame enrolment with a
+      // small tau, unrelated means) run the full three products -- the arithmetic of the non-delta kernels.
+      double sumsq = 0.0;
+      for (int m = 1; m < M; ++m)
+        for (int c = 0; c < C; ++c)
+          for (int k = 0; k < D; ++k) {
+            const double ivk = (double)iv[(size_t)c * D + k];
+            const double reach = (fabs((double)miv[(size_t)c * D + k]) + 3.0 * sqrt(ivk)) / ivk;  // |mu| + 3 sigma
+            const double dl = (double)miv[((size_t)m * C + c) * D + k] - (double)miv[(size_t)c * D + k];
+            sumsq += dl * dl * reach * reach;
+          }
+      const double rms_b = ldexp(sqrt(sumsq / ((double)(M - 1) * C)), -12);
+      delta_p = rms_b <= 2.5e-5 ? 1 : (rms_b <= 6.0e-5 ? 2 : 3);
+      const char *pe = getenv("FB_GMM_DELTA_P");  // tests: force the number of products
+      if (pe && *pe) {
+        const int v = atoi(pe);
+        if (v < 1 || v > 3) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_P must be 1, 2 or 3 (got '%s')", pe);
+        delta_p = v;
+      }
+      e->gmm_delta_rms = rms_b;
+    }
   }
   if (mode == FB_GMM_MODE_BX3) {
     const size_t per_item = (size_t)3 * NK * 64 * 8;  // bf16 values
@@ -546,6 +611,8 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.NKF = NKF;
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
+  g.delta_p = mode == FB_GMM_MODE_FX2 ? delta_p : 0;
+  g.images_fd = g.delta_p ? reinterpret_cast<decltype(g.images_fd)>(e->gmm_images_fd.p) : nullptr;
   g.item_model = e->gmm_items.as<int>();
   g.item_model_host_q_first = (G == 1) ? 1 : 0;  // one group: the list built above is {Q, 0, 1, ..., M-1}
   e->n_groups = G;
@@ -1732,6 +1799,14 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
 extern "C" int fb_gmm_kernel_mode(fb_engine *e) {
   if (!e) return fb_fail(FB_E_ARG, "null engine");
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  return e->gmm.mode;
+}
+
+extern "C" int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  if (shift_rms) *shift_rms = e->gmm_delta_rms;
+  if (e->kind == 0 && fb_gmm_use_wide(e->gmm)) return 10 + e->gmm.delta_p;
   return e->gmm.mode;
 }
 

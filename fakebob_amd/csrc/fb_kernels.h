@@ -128,6 +128,11 @@ struct FbGmmDev {
   // power-of-two operand scalings (exact): frames x * 2^kx, x^2 * 2^kx2; the accumulators hold ll * 2^kacc
   int kx, kx2, kacc;
   const unsigned int __attribute__((ext_vector_type(4))) * images_fx;
+  // k_gmm_fx2w (one variance group): images [n_tiles][1 + M][2][NKF][64] x 16 B of {Q, base model 0, delta_1 ..
+  // delta_{M-1}}, delta_m = (means_invvars, gconst) of model m MINUS the base model's, in the same scaling; delta_p =
+  // partial products per K chunk the delta items are evaluated with (1 .. 3; 0: no delta images)
+  const unsigned int __attribute__((ext_vector_type(4))) * images_fd;
+  int delta_p;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
@@ -153,6 +158,9 @@ static inline bool fb_device_needs_optin(std::atomic<unsigned long long> &mask, 
 // true when fb_launch_gmm runs the one-wave-per-SIMD scoring kernel k_gmm_fx2w (256-frame strips, one round of <= 256
 // workgroups): the engine sizes the component chunks for it
 bool fb_gmm_use_wide(const FbGmmDev &g);
+// gmm_wide_kernel.hip: the launch of k_gmm_fx2w (tpc = component tiles per chunk); called by fb_launch_gmm
+void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
+                        int n_chunks, int tpc, float *part_m, float *part_s);
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

@@ -1,0 +1,66 @@
+// gmm_split.h -- device helpers shared by the diagonal-GMM kernels (gmm_kernels.hip, gmm_wide_kernel.hip): the
+// two-term f16 split of f32 operands and the online logsumexp in the log2 domain.
+#pragma once
+#include "fb_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define FB_GMM_NEG (-3.0e38f)
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fb_pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+
+__device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2 a, b;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float x = v[2 * i + u];
+      const _Float16 x1 = (_Float16)x;                                   // round to nearest even
+      const float r = __fsub_rn(x, (float)x1);  // exact; possibly a subnormal f16, which the matrix pipe keeps
+      a[u] = x1;
+      b[u] = (_Float16)r;
+    }
+    f1[i] = __builtin_bit_cast(unsigned, a);
+    f2[i] = __builtin_bit_cast(unsigned, b);
+  }
+}
+
+#define FB_FX_MFMA(A, B, ACC) \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+
+// online logsumexp of k_gmm_fx2: fold 16 values into the state (m, s) at (stm, sts).
+// The state lives in the log2 domain so that one value costs one (packed) fma, one v_exp_f32 and one (packed) add:
+//   m = running maximum (a value, exact),  r = fl(m * L),  s = sum 2^(v * L - r),   L = fl(log2 e)
+//   => logsumexp = ln2 * (r + log2 s); fb_lse_to_natural() converts to the (m, sum exp(v - m)) convention the
+//   chunk merge / k_gmm_finalize use.  The reference point r only has to be the same for every term of s.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define FB_LOG2E_F 1.44269502162933349609375f  // fl(log2 e)
+__device__ __forceinline__ void fb_lse_update16(const f32x16 &pv, float *__restrict__ stm, float *__restrict__ sts,
+                                                float ls = FB_LOG2E_F) {  // ls = fl(log2 e) * 2^-kacc for scaled values
+  float tm = FB_GMM_NEG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, pv[r]);
+  const float m_old = *stm, s_old = *sts;
+  const float m_new = fmaxf(m_old, tm);
+  const float r_new = __fmul_rn(m_new, ls), r_old = __fmul_rn(m_old, ls);  // r_old = -inf at the start
+  const f32x2 l2 = {ls, ls}, nr2 = {-r_new, -r_new};
+  f32x2 acc = {s_old * __builtin_amdgcn_exp2f(r_old - r_new), 0.0f};
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const f32x2 v2 = {pv[2 * r], pv[2 * r + 1]};
+    const f32x2 t = __builtin_elementwise_fma(v2, l2, nr2);
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    acc += e;
+  }
+  *stm = m_new;
+  *sts = acc[0] + acc[1];
+}
+// s (log2-domain state, see above) -> sum exp(v - m):  s * 2^(r - L m), evaluated in float64 (|r - L m| < 1e-4)
+__device__ __forceinline__ float fb_lse_to_natural(float m, float s, float ls = FB_LOG2E_F) {
+  const double d = (double)__fmul_rn(m, ls) - (double)ls * (double)m;
+  return (float)((double)s * (1.0 + d * 0.6931471805599453 * (1.0 + d * 0.34657359027997264)));
+}
+

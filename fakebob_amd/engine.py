@@ -121,6 +121,25 @@ class Engine(object):
             N.check(rc)
         return {1: "bx3", 2: "fx2"}[rc]
 
+    @property
+    def gmm_kernel_variant(self):
+        """The kernel the loaded GMM system is scored with: 'bx3', 'fx2', or 'fx2w/P' -- the one-wave-per-SIMD
+        kernel with the speaker models as deltas from model 0, P = 1 .. 3 partial products per delta item
+        (fb_gmm_kernel_variant)."""
+        rc = self._L.fb_gmm_kernel_variant(self._h, None)
+        if rc < 0:
+            N.check(rc)
+        return {1: "bx3", 2: "fx2"}.get(rc) or "fx2w/%d" % (rc - 10)
+
+    @property
+    def gmm_shift_rms(self):
+        """fb_load_gmm's measure of how far the models were adapted from model 0 (what P is chosen from)."""
+        v = C.c_double()
+        rc = self._L.fb_gmm_kernel_variant(self._h, C.byref(v))
+        if rc < 0:
+            N.check(rc)
+        return v.value
+
     def debug_iv_active(self):
         n = C.c_int()
         N.check(self._L.fb_debug_iv_active(self._h, C.byref(n)))

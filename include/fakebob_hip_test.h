@@ -30,6 +30,12 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
  * range; FB_GMM_MODE=bx3 forces it).  Negative FB_E_* without a model.
  * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
 int fb_gmm_kernel_mode(fb_engine *e);
+/* The kernel fb_score_* / the NES loop launch for the loaded GMM system: 1 = k_gmm_bx3, 2 = k_gmm_fx2 (any number of
+ * variance groups, partial tiles, more than 6 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 6 models: the
+ * speaker models are scored as deltas from model 0 with P = 1 .. 3 partial products per K chunk; P is chosen by
+ * fb_load_gmm from how far the models were adapted -- *shift_rms (nullable) returns that statistic -- and
+ * FB_GMM_DELTA_P forces it; FB_GMM_NARROW=1 selects k_gmm_fx2 instead).  Negative FB_E_* without a model. */
+int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms);
 
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */

@@ -288,6 +288,7 @@ def test_wide_scoring_kernel_single_tile_chunks(oracle, monkeypatch, n_speakers,
     e = Engine(0)
     try:
         e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel_variant.startswith("fx2w/")
         raw_g, tv_g = e.score_raw(wavs)
     finally:
         e.close()
@@ -295,14 +296,17 @@ def test_wide_scoring_kernel_single_tile_chunks(oracle, monkeypatch, n_speakers,
     assert np.abs(raw_g - raw_o).max() <= 2e-5
 
 
+@pytest.mark.parametrize("delta_p", [1, 2, 3])
 @pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5])
-def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers):
-    """k_gmm_fx2w is instantiated per model count M = 2 .. 6 (SV: UBM + 1; OSI: UBM + speakers): each instantiation
-    has its own LDS slot split, LDS-DMA piece schedule and accumulator rotation.  Several component chunks per strip
-    (C = 1024 -> tiles streamed through both slots many times), a ragged last strip, against the oracle and against
-    the general kernel on the same inputs."""
+def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers, delta_p):
+    """k_gmm_fx2w is instantiated per model count M = 2 .. 6 (SV: UBM + 1; OSI: UBM + speakers) and per number of
+    partial products of the delta items: each instantiation has its own LDS slot split, LDS-DMA piece schedule,
+    accumulator rotation and update-slice schedule.  Several component chunks per strip (C = 1024 -> tiles streamed
+    through both slots many times), a ragged last strip, against the oracle and against the general kernel on the
+    same inputs."""
     monkeypatch.delenv("FB_GMM_NARROW", raising=False)
     monkeypatch.delenv("FB_GMM_MODE", raising=False)
+    monkeypatch.setenv("FB_GMM_DELTA_P", str(delta_p))
     cfg = oracle.default_cfg()
     ubm, spk = synthetic_gmm_system(n_speakers=n_speakers, C=1024, D=72)
     wavs = [_wav(u, 16000 + 1234 * u) for u in range(7)]
@@ -311,7 +315,7 @@ def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers):
     e = Engine(0)
     try:
         e.load_gmm([ubm] + spk)
-        assert e.gmm_kernel == "fx2"
+        assert e.gmm_kernel_variant == "fx2w/%d" % delta_p
         raw_w, tv_w = e.score_raw(wavs)
     finally:
         e.close()
@@ -319,9 +323,31 @@ def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers):
     e = Engine(0)
     try:
         e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel_variant == "fx2"
         raw_n, _ = e.score_raw(wavs)
     finally:
         e.close()
     assert np.array_equal(tv_w, tv_o)
     assert np.abs(raw_w - raw_o).max() <= 2e-5, np.abs(raw_w - raw_o).max()
     assert np.abs(raw_w - raw_n).max() <= 2e-5
+
+
+def test_wide_scoring_kernel_csi_base_is_the_first_speaker(oracle, monkeypatch):
+    """CSI has no UBM in its model list (gmm_ubm_CSI.py:49): k_gmm_fx2w then scores speakers 1 .. as deltas from
+    speaker 0 (two independent adaptations apart, so the shift statistic is ~sqrt 2 of the OSI one)."""
+    for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
+        monkeypatch.delenv(k, raising=False)
+    cfg = oracle.default_cfg()
+    ubm, spk = synthetic_gmm_system(n_speakers=5, C=2048, D=72)
+    wavs = [_wav(u, 20000 + 4321 * u) for u in range(4)]
+    gc, miv, iv = stack_models(spk)
+    raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
+    e = Engine(0)
+    try:
+        e.load_gmm(spk)
+        e.set_system("CSI", np.zeros(5), np.ones(5))
+        assert e.gmm_kernel_variant in ("fx2w/2", "fx2w/3"), (e.gmm_kernel_variant, e.gmm_shift_rms)
+        raw_g, _ = e.score_raw(wavs)
+    finally:
+        e.close()
+    assert np.abs(raw_g - raw_o).max() <= 2e-5

@@ -68,19 +68,24 @@ def test_score_parity_full_size(engine, oracle, full_system):
 
 def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
     """Every f32 product of the GMM log-likelihood is evaluated on the 16-bit matrix pipe: 3 partial products of a
-    two-term f16 split (k_gmm_fx2w, the one-wave-per-SIMD scoring kernel, and k_gmm_fx2, FB_GMM_NARROW=1) or the 6
-    partial products of an EXACT three-term bf16 split (k_gmm_bx3, FB_GMM_MODE=bx3).  Against the float64-accumulating
-    oracle all three must stay within float32 rounding of the ~-150 results (ulp 1.5e-5), and the f16 forms must be
-    as close as the exact split -- i.e. no precision is given up."""
+    two-term f16 split (k_gmm_fx2, FB_GMM_NARROW=1), the 6 partial products of an EXACT three-term bf16 split
+    (k_gmm_bx3, FB_GMM_MODE=bx3), or -- the default, k_gmm_fx2w -- the base model with the 3 partial products and the
+    speaker models as DELTAS from it with P = 1 .. 3 partial products (fb_load_gmm picks P from how far the models
+    were adapted: 2 for the synthetic speakers of SURVEY.md 8(d); FB_GMM_DELTA_P forces it).  Against the
+    float64-accumulating oracle all of them must stay within float32 rounding of the ~-150 results (ulp 1.5e-5), and
+    the default must be as close as the exact split -- i.e. no precision is given up."""
     from fakebob_amd.engine import Engine
     ubm, spk = full_system
     cfg = oracle.default_cfg()
     wavs = [_wav(0), _wav(1), _wav(2, 20000), _wav(5, 30000)]
     gc, miv, iv = stack_models([ubm] + spk)
     raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
-    errs, raws = {}, {}
-    for name, env in (("fx2w", {}), ("fx2", {"FB_GMM_NARROW": "1"}), ("bx3", {"FB_GMM_MODE": "bx3"})):
-        for k in ("FB_GMM_NARROW", "FB_GMM_MODE"):
+    errs, raws, sys_errs = {}, {}, {}
+    variants = (("fx2w", {}, "fx2w/2"), ("fx2w/1", {"FB_GMM_DELTA_P": "1"}, "fx2w/1"),
+                ("fx2w/3", {"FB_GMM_DELTA_P": "3"}, "fx2w/3"), ("fx2", {"FB_GMM_NARROW": "1"}, "fx2"),
+                ("bx3", {"FB_GMM_MODE": "bx3"}, "bx3"))
+    for name, env, variant in variants:
+        for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -88,15 +93,69 @@ def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
         try:
             e.load_gmm([ubm] + spk)
             assert e.gmm_kernel == ("bx3" if name == "bx3" else "fx2")
+            assert e.gmm_kernel_variant == variant        # the kernel that really runs, not only its arithmetic
             raws[name], _ = e.score_raw(wavs)
         finally:
             e.close()
         errs[name] = float(np.abs(raws[name] - raw_o).max())
-    print("max |err| vs float64 oracle:", errs)
+        # what the OSI / SV systems use: speaker minus UBM
+        sys_errs[name] = float(np.abs((raws[name][:, 1:] - raws[name][:, :1]) - (raw_o[:, 1:] - raw_o[:, :1])).max())
+    print("max |err| vs float64 oracle: raw", errs, "speaker - UBM", sys_errs)
     assert max(errs.values()) <= 2e-5, errs
-    assert errs["fx2w"] <= 2.0 * errs["bx3"] + 2e-6 and errs["fx2"] <= 2.0 * errs["bx3"] + 2e-6, errs
-    assert not np.array_equal(raws["fx2w"], raws["bx3"])      # three different kernels really ran
+    for name in ("fx2w", "fx2w/3", "fx2"):
+        assert errs[name] <= 2.0 * errs["bx3"] + 2e-6, errs
+        assert sys_errs[name] <= 2.0 * sys_errs["bx3"] + 2e-6, sys_errs
+    assert len({raws[n].tobytes() for n in raws}) == len(raws)  # five different kernels really ran
     assert np.abs(raws["fx2w"] - raws["fx2"]).max() <= 2e-5
+
+
+def test_far_adapted_models_keep_three_products(oracle, monkeypatch):
+    """The reduced delta products of k_gmm_fx2w are only for speaker models close to model 0.  A model adapted from a
+    few frames with a small tau (alpha -> 1: means moved by ~0.3 sigma in every component) must be given the full
+    three products by fb_load_gmm on its own, and stay inside the float32-rounding bound; forcing P = 1 on it shows
+    what the selection rule protects against."""
+    from fakebob_amd.engine import Engine
+    from fakebob_amd.models import DiagGmm, synthetic_speaker_means, synthetic_ubm_moments
+    w, mu, var = synthetic_ubm_moments(2048, 72, 2001)
+    ubm = DiagGmm.from_moments(w, mu, var)
+    spk = [DiagGmm.from_internal(w, (synthetic_speaker_means(w, mu, s, 2100, tau=0.1) / var).astype(np.float32),
+                                 ubm.inv_vars) for s in range(2)]
+    cfg = oracle.default_cfg()
+    wavs = [_wav(0), _wav(2, 20000)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
+    err = {}
+    for name, env in (("auto", {}), ("p1", {"FB_GMM_DELTA_P": "1"})):
+        monkeypatch.delenv("FB_GMM_DELTA_P", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            if name == "auto":
+                assert e.gmm_kernel_variant == "fx2w/3", (e.gmm_kernel_variant, e.gmm_shift_rms)
+                assert e.gmm_shift_rms > 6e-5
+            raw, _ = e.score_raw(wavs)
+        finally:
+            e.close()
+        err[name] = float(np.abs(raw - raw_o).max())
+    print("far-adapted models, max |err|:", err)
+    assert err["auto"] <= 2e-5, err
+    assert err["p1"] > 2.0 * err["auto"], err      # the rule is not vacuous
+    # a model list whose first entry is unrelated to the others (not an adaptation of it) is the same case
+    monkeypatch.delenv("FB_GMM_DELTA_P", raising=False)
+    ubm2 = DiagGmm.from_internal(synthetic_ubm_moments(2048, 72, 77)[0],
+                                 (synthetic_ubm_moments(2048, 72, 77)[1] / var).astype(np.float32), ubm.inv_vars)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm2] + spk)
+        assert e.gmm_kernel_variant == "fx2w/3"
+        raw, _ = e.score_raw(wavs)
+    finally:
+        e.close()
+    gc2, miv2, iv2 = stack_models([ubm2] + spk)
+    raw_o2, _ = oracle.gmm_score_batch(cfg, wavs, gc2, miv2, iv2, nthreads=8)
+    assert np.abs(raw - raw_o2).max() <= 1e-4 * max(1.0, np.abs(raw_o2).max() / 200.0)
 
 
 def test_score_float_input_and_ragged(engine, oracle, small_system):
