@@ -110,14 +110,15 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(audio, models, params_kw):
+def cpu_baseline(audio, models, params_kw, faithful=False):
     """Times the CPU oracle (the build's C restatement of the identical computation; Kaldi itself
     cannot be installed offline) on one full NES iteration of the same workload, 1 thread --
     the reference's default n_jobs=1 (attackMain.sh:34)."""
     from oracle import oracle as O
     from fakebob_amd.models import stack_models
     gc, miv, iv = stack_models(models)
-    ctx = O.GmmSystemCtx(O.default_cfg(), "OSI", gc, miv, iv, nthreads=1)
+    ocfg = O.default_cfg(compress_feats=1, text_scores=1) if faithful else O.default_cfg()
+    ctx = O.GmmSystemCtx(ocfg, "OSI", gc, miv, iv, nthreads=1)
     po = O.nes_params("OSI", "targeted", ctx.S, **params_kw)
     t0 = time.perf_counter()
     O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=0, stream=0)
@@ -130,7 +131,7 @@ def cpu_baseline(audio, models, params_kw):
     try:
         nthr = max(1, len(os.sched_getaffinity(0)))
         if nthr > 1:
-            ctx = O.GmmSystemCtx(O.default_cfg(), "OSI", gc, miv, iv, nthreads=nthr)
+            ctx = O.GmmSystemCtx(ocfg, "OSI", gc, miv, iv, nthreads=nthr)
             O.get_grad(po, ctx.fn, ctx.ctx, audio, seed=42, it=0, stream=0)        # warm the thread pool / caches
             t0 = time.perf_counter()
             n = 0
@@ -378,6 +379,10 @@ def main():
     ap.add_argument("--precondition", type=int, default=60,
                     help="untimed iterations per attack run once before the declared warm-up (module load, first-touch "
                          "allocations, clock ramp of a cold GPU); reported in config.precondition_steps")
+    ap.add_argument("--faithful", action="store_true",
+                    help="run the reference pipeline's two file round trips on the device (MFCCs through Kaldi's "
+                         "CompressedMatrix, scores through 6-digit text: gmm_ubm_kaldiHelper.py:138-140, 236-248) -- "
+                         "the drop-in modules' default; the headline line is measured without them")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even with one rank (exercises RCCL on a 1-GPU box)")
     args = ap.parse_args()
@@ -399,6 +404,8 @@ def main():
     engs, auds, prms = [], [], []
     for k in range(K):
         e = Engine(dev_index)
+        if args.faithful:
+            e.set_frontend(compress_feats=1, text_scores=1)
         e.load_gmm(models)
         e.set_system("OSI")
         engs.append(e)
@@ -466,7 +473,9 @@ def main():
             "per_attack": [{"host_ms": 1e3 * (b - a), "device_ms": r[0], "gmm_ms": r[1]} for (a, b), r in zip(windows, results)],
             "config": {"workload": "GMM-UBM OSI targeted, 5 speakers+UBM, C=2048, D=72, spd=50, "
                                    "N=48000 (3 s @ 16 kHz), %d attacks in flight per GPU "
-                                   "(1 step = 1 NES iteration of each)" % K,
+                                   "(1 step = 1 NES iteration of each)%s" % (K, "; reference-pipeline round trips ON "
+                                   "(compress_feats, text_scores)" if args.faithful else ""),
+                       "faithful_pipeline": bool(args.faithful),
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
@@ -486,7 +495,7 @@ def main():
             pass
         if world == 1 and not args.no_cpu_baseline:
             ckw = dict(kw)
-            out["cpu_baseline"] = cpu_baseline(audio, models, ckw)
+            out["cpu_baseline"] = cpu_baseline(audio, models, ckw, args.faithful)
             out["gpu_over_cpu_port"] = its / out["cpu_baseline"]["value"]
         emit(out)
     if dist is not None:

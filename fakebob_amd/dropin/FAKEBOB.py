@@ -1,2 +1,5 @@
 """Drop-in for the reference's FAKEBOB.py (same module and class name)."""
 from fakebob_amd.attack import FakeBob, UNTARGETED  # noqa: F401
+from fakebob_amd.systems import use_reference_pipeline_defaults as _ref_defaults
+
+_ref_defaults()  # this module name is the reference's: behave like its pipeline (dropin/README.md)

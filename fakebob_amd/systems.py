@@ -14,19 +14,36 @@ from .engine import Engine
 from .kaldi_io import load_gmm_any
 
 
+# What a system does when neither the constructor keyword nor the environment variable says otherwise.  The library
+# default keeps full precision; importing a class through its reference module name (fakebob_amd/dropin/) switches to
+# the reference pipeline's own behaviour, see use_reference_pipeline_defaults().
+PIPELINE_DEFAULT = {"text_scores": False, "compress_feats": False}
+
+
+def use_reference_pipeline_defaults(on=True):
+    """The two file round trips of the reference's pipeline as the default of every system constructed afterwards:
+    `copy-feats --compress=true` inside steps/make_mfcc.sh (gmm_ubm_kaldiHelper.py:138-140) and the
+    6-significant-digit score text the helpers parse (gmm_ubm_kaldiHelper.py:236-248).  Called by the drop-in modules
+    (fakebob_amd/dropin/*.py): an unmodified attackMain.py then computes what it computes with a stock Kaldi recipe."""
+    PIPELINE_DEFAULT["text_scores"] = bool(on)
+    PIPELINE_DEFAULT["compress_feats"] = bool(on)
+
+
 def _pipeline_options(text_scores, compress_feats):
-    """The two round trips the reference's pipeline takes through files and the engine reproduces on request:
+    """The two round trips the reference's pipeline takes through files and the engine reproduces on the device:
     text_scores (Kaldi prints scores with 6 significant digits and the helpers parse that text) and compress_feats
-    (make_mfcc.sh stores the MFCCs through Kaldi's lossy CompressedMatrix).  Constructor keywords win over the
-    FB_TEXT_SCORES / FB_COMPRESS_FEATS environment variables; both default to off (fakebob_amd/dropin/README.md)."""
-    out = {}
-    ts = text_scores if text_scores is not None else os.environ.get("FB_TEXT_SCORES", "0") == "1"
-    cf = compress_feats if compress_feats is not None else os.environ.get("FB_COMPRESS_FEATS", "0") == "1"
-    if ts:
-        out["text_scores"] = 1
-    if cf:
-        out["compress_feats"] = 1
-    return out
+    (make_mfcc.sh stores the MFCCs through Kaldi's lossy CompressedMatrix).  Precedence: constructor keyword (True or
+    False), then FB_TEXT_SCORES / FB_COMPRESS_FEATS = 0 | 1, then PIPELINE_DEFAULT.  Both keys are always returned, so
+    an explicit False also clears a flag an earlier system left on a shared engine."""
+    def pick(kw, env, key):
+        if kw is not None:
+            return bool(kw)
+        ev = os.environ.get(env)
+        if ev in ("0", "1"):
+            return ev == "1"
+        return PIPELINE_DEFAULT[key]
+    return {"text_scores": int(pick(text_scores, "FB_TEXT_SCORES", "text_scores")),
+            "compress_feats": int(pick(compress_feats, "FB_COMPRESS_FEATS", "compress_feats"))}
 
 
 def default_device():

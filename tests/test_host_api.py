@@ -417,3 +417,42 @@ def test_kaldi_default_dither_is_reported():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         frontend_overrides(mf + "--dither=0\n", "", "")
+
+
+def test_pipeline_option_precedence_and_dropin_defaults(monkeypatch):
+    """text_scores / compress_feats: constructor keyword (True OR False) > FB_TEXT_SCORES / FB_COMPRESS_FEATS > the
+    module default, which the reference-named drop-in modules switch to the reference pipeline's behaviour
+    (fakebob_amd/dropin/README.md).  Both keys are always passed on, so an explicit False clears a flag left on a
+    shared engine."""
+    import importlib
+    import subprocess
+    import sys
+    from fakebob_amd import systems
+    for k in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setitem(systems.PIPELINE_DEFAULT, "text_scores", False)
+    monkeypatch.setitem(systems.PIPELINE_DEFAULT, "compress_feats", False)
+    assert systems._pipeline_options(None, None) == {"text_scores": 0, "compress_feats": 0}
+    assert systems._pipeline_options(True, None) == {"text_scores": 1, "compress_feats": 0}
+    monkeypatch.setenv("FB_TEXT_SCORES", "1")
+    monkeypatch.setenv("FB_COMPRESS_FEATS", "1")
+    assert systems._pipeline_options(None, None) == {"text_scores": 1, "compress_feats": 1}
+    assert systems._pipeline_options(False, False) == {"text_scores": 0, "compress_feats": 0}   # keyword wins, both ways
+    monkeypatch.setenv("FB_TEXT_SCORES", "0")
+    systems.use_reference_pipeline_defaults()
+    assert systems._pipeline_options(None, None) == {"text_scores": 0, "compress_feats": 1}     # env wins over default
+    monkeypatch.delenv("FB_TEXT_SCORES")
+    monkeypatch.delenv("FB_COMPRESS_FEATS")
+    assert systems._pipeline_options(None, None) == {"text_scores": 1, "compress_feats": 1}
+    # a fresh interpreter: importing a reference module name is what flips the default
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from fakebob_amd import systems\n"
+            "assert systems._pipeline_options(None, None) == {'text_scores': 0, 'compress_feats': 0}\n"
+            "import gmm_ubm_OSI, FAKEBOB\n"
+            "assert gmm_ubm_OSI.gmm_OSI is systems.gmm_OSI\n"
+            "assert systems._pipeline_options(None, None) == {'text_scores': 1, 'compress_feats': 1}\n"
+            % (os.path.join(root, "fakebob_amd", "dropin"), root))
+    env = {k: v for k, v in os.environ.items() if k not in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS")}
+    subprocess.run([sys.executable, "-c", code], check=True, env=env)
+    importlib.reload(systems)
