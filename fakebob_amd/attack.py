@@ -25,10 +25,13 @@ UNTARGETED = "untargeted"
 
 
 def _check_bits(bits_per_sample):
-    """The device NES path quantises with 2^15 (k_perturb / the final cast); the reference would use
-    2^(bits_per_sample-1) (gmm_ubm_OSI.py:85, FAKEBOB.py:220).  Anything but 16 is refused rather than ignored."""
-    if int(bits_per_sample) != 16:
-        raise ValueError("bits_per_sample=%r: the NES path supports 16-bit audio only" % (bits_per_sample,))
+    """bits_per_sample scales the int16 casts of the NES path exactly as in the reference -- every sample of the
+    batch before scoring (gmm_ubm_OSI.py:85) and the returned adversarial audio (FAKEBOB.py:220) use
+    2^(bits_per_sample-1); the container stays int16, so 2 .. 16."""
+    b = int(bits_per_sample)
+    if b < 2 or b > 16:
+        raise ValueError("bits_per_sample=%r: the int16 casts take 2 .. 16" % (bits_per_sample,))
+    return b
 
 
 def _col(audio):
@@ -79,13 +82,14 @@ class FakeBob(object):
         self._n_spk = None
 
     # ------------------------------------------------------------------ helpers
-    def _params(self, attack_type=None, max_iter=None, stream=None):
+    def _params(self, attack_type=None, max_iter=None, stream=None, bits_per_sample=16):
         return nes_params(self.task, attack_type or self.attack_type, adver_thresh=self.adver_thresh,
                           epsilon=self.epsilon, max_iter=self.max_iter if max_iter is None else max_iter,
                           max_lr=self.max_lr, min_lr=self.min_lr, samples_per_draw=self.samples_per_draw,
                           sigma=self.sigma, momentum=self.momentum, plateau_length=self.plateau_length,
                           plateau_drop=self.plateau_drop, threshold=self.threshold, target=self.target,
-                          true=self.true, seed=self.seed, stream=self._stream if stream is None else stream)
+                          true=self.true, seed=self.seed, stream=self._stream if stream is None else stream,
+                          bits_per_sample=bits_per_sample)
 
     def _score_shape(self, sc):
         S = self.model.engine.n_speakers if self._native else self._speakers()
@@ -102,16 +106,17 @@ class FakeBob(object):
             self._own_engine = Engine(default_device())
         return self._own_engine
 
-    def _speakers(self, probe_audio=None):
+    def _speakers(self, probe_audio=None, **score_kw):
         """Number of score columns of a foreign model: 1 for SV, len(model.spk_ids) when the model has the
-        attribute the reference's drivers read (attackMain.py:95), else the width of one score call."""
+        attribute the reference's drivers read (attackMain.py:95), else the width of ONE extra score call made the
+        way the reference calls score (same keywords); a model that counts its queries should carry spk_ids."""
         if self._n_spk is None:
             if self.task == "SV":
                 self._n_spk = 1
             elif hasattr(self.model, "spk_ids"):
                 self._n_spk = len(self.model.spk_ids)
             elif probe_audio is not None:
-                self._n_spk = int(np.asarray(self.model.score(probe_audio)).size)
+                self._n_spk = int(np.asarray(self.model.score(probe_audio, **score_kw)).size)
             else:
                 raise ValueError("cannot tell how many speakers the model scores: give it a spk_ids attribute")
         return self._n_spk
@@ -126,9 +131,11 @@ class FakeBob(object):
         gradient (fb_get_grad_ext); the momentum / plateau / sign-step bookkeeping is a few length-N numpy lines."""
         kw = dict(fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
         eng = self._engine()
-        init = self.model.score(audio, **kw)
-        S = self._speakers(audio)
-        init = float(np.max(init)) if self.task == "OSI" else float(init)
+        init = np.asarray(self.model.score(audio, **kw), np.float64)   # FAKEBOB.py:53
+        if self._n_spk is None and self.task != "SV" and not hasattr(self.model, "spk_ids"):
+            self._n_spk = int(init.size)                               # its width tells S: no extra query
+        S = self._speakers(audio, **kw)
+        init = float(np.max(init)) if self.task == "OSI" else float(init.reshape(-1)[0])
         delta = abs(init / 10)
         self.delta = delta
         self.threshold = init + delta
@@ -145,7 +152,7 @@ class FakeBob(object):
             while True:
                 t0 = time.time()
                 decision, score = self.model.make_decisions(adver, **kw)
-                score = float(np.max(score)) if self.task == "OSI" else float(score)
+                score = float(np.max(score)) if self.task == "OSI" else float(np.asarray(score).reshape(-1)[0])
                 if decision != -1:
                     if self.verbose:
                         print("--- return at iter_outer:%d, return thresh:%f ---" % (n_outer, score))
@@ -155,7 +162,7 @@ class FakeBob(object):
                     break
                 if n_iters >= max_total_iters:
                     raise RuntimeError("estimate_threshold: max_total_iters %d reached" % max_total_iters)
-                p = self._params(attack_type=UNTARGETED)
+                p = self._params(attack_type=UNTARGETED, bits_per_sample=bits_per_sample)
                 noise = None if noise_all is None else noise_all[n_iters]
                 loss, g, _, _ = eng.get_grad_ext(p, S, fn, adver[:, 0], it=n_iters, noise_pos=noise)
                 velocity = self.momentum * velocity + (1.0 - self.momentum) * g[:, np.newaxis]
@@ -180,12 +187,12 @@ class FakeBob(object):
             print("--- Warning: no need to estimate threshold for CSI, quitting ---")
             return
         audio = _col(audio)
-        _check_bits(bits_per_sample)
+        bits = _check_bits(bits_per_sample)
         if not self._native:
             self._stream += 1
             return self._estimate_threshold_foreign(audio, fs, bits_per_sample, n_jobs, debug, max_total_iters, noise_all)
         t0 = time.time()
-        p = self._params(attack_type=UNTARGETED)
+        p = self._params(attack_type=UNTARGETED, bits_per_sample=bits)
         self._stream += 1
         score, n_iters, n_outer, thr, _adv = self.model.engine.estimate_threshold(
             p, float(self.model.threshold), audio[:, 0], noise_all=noise_all, max_total_iters=max_total_iters)
@@ -202,29 +209,33 @@ class FakeBob(object):
                bits_per_sample=16, n_jobs=10, debug=False, noise_all=None):
         """FAKEBOB.py:139-221.  Returns (int16 adversarial audio (N,1), success_flag +-1) and
         writes the per-iteration trace [distance, adver_loss, score, used_time] to
-        checkpoint_path (pickle protocol -1), like the reference.  The loop runs inside the library, so
-        used_time is the attack's wall time divided evenly over its iterations (0. on the early-stop row, :187).
+        checkpoint_path (pickle protocol -1), like the reference.  used_time is each iteration's own time, read from
+        the device clock where its loss is evaluated (fb_attack_iter_seconds; the loop runs inside the library), 0. on
+        the early-stop row (:187).
         noise_all (extension): (max_iter, N, samples_per_draw//2) normals to replay a NumPy run."""
         audio = _col(audio)
-        _check_bits(bits_per_sample)
+        bits = _check_bits(bits_per_sample)
         self.threshold = threshold
         self.true = true
         self.target = target
-        p = self._params()
+        p = self._params(bits_per_sample=bits)
         self._stream += 1
         t0 = time.time()
+        kw = dict(fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
         if self._native:
-            adv, flag, _advf, trace = self.model.engine.attack(p, audio[:, 0], noise_all=noise_all)
+            eng = self.model.engine
+            adv, flag, _advf, trace = eng.attack(p, audio[:, 0], noise_all=noise_all)
         else:
-            adv, flag, _advf, trace = self._engine().attack_ext(
-                p, self._speakers(audio), self._score_fn(fs, bits_per_sample, n_jobs, debug), audio[:, 0],
+            eng = self._engine()
+            adv, flag, _advf, trace = eng.attack_ext(
+                p, self._speakers(audio, **kw), self._score_fn(fs, bits_per_sample, n_jobs, debug), audio[:, 0],
                 noise_all=noise_all)
         dt = time.time() - t0
         n = trace.shape[0]
-        per_iter = dt / max(n, 1)
+        used_time = eng.attack_iter_seconds(n)
         cp_global = []
         for r in range(n):
-            used = 0. if (r == n - 1 and trace[r, 1] < 0) else per_iter  # the early-stop row stores 0. (:187)
+            used = 0. if (r == n - 1 and trace[r, 1] < 0) else float(used_time[r])  # the early-stop row stores 0. (:187)
             sc = trace[r, 3:]
             cp_global.append([trace[r, 0], np.array([trace[r, 1]]), sc[0] if self.task == "SV" else sc.copy(), used])
         if checkpoint_path:
@@ -239,13 +250,13 @@ class FakeBob(object):
     def get_grad(self, audio, fs=16000, bits_per_sample=16, n_jobs=10, debug=False, iteration=0, noise_pos=None):
         """FAKEBOB.py:223-246 -> (final_loss, grad (N,1), adver_loss (1,), score)."""
         audio = _col(audio)
-        _check_bits(bits_per_sample)
-        p = self._params()
+        p = self._params(bits_per_sample=_check_bits(bits_per_sample))
         if self._native:
             fl, grad, al, sc = self.model.engine.get_grad(p, audio[:, 0], it=iteration, noise_pos=noise_pos)
         else:
+            kw = dict(fs=fs, bits_per_sample=bits_per_sample, n_jobs=n_jobs, debug=debug)
             fl, grad, al, sc = self._engine().get_grad_ext(
-                p, self._speakers(audio), self._score_fn(fs, bits_per_sample, n_jobs, debug), audio[:, 0],
+                p, self._speakers(audio, **kw), self._score_fn(fs, bits_per_sample, n_jobs, debug), audio[:, 0],
                 it=iteration, noise_pos=noise_pos)
         return fl, grad[:, np.newaxis], np.array([al]), self._score_shape(sc)
 

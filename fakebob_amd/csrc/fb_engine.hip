@@ -102,7 +102,8 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter, vad_pub, fin_counter, ctl, ctl_ls, trace_dev, enr_ll, enr_aux, enr_stats;
+  DevBuf frame_rec, vad_counter, vad_pub, fin_counter, ctl, ctl_ls, trace_dev, ticks, enr_ll, enr_aux, enr_stats;
+  std::vector<double> iter_seconds;  // per-iteration device times of the last fb_attack / fb_attack_ext
   long long bench_it = -1;  // fb_bench_nes: next iteration index of the attack left resident (-1: none)
   int64_t bench_N = 0;
   int bench_B = 0;
@@ -225,7 +226,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -659,6 +660,7 @@ extern "C" int fb_num_speakers(fb_engine *e) {
 // Prepares offsets for a batch whose int16 samples are already in e->wav.
 static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
   e->bench_it = -1;  // whatever attack fb_bench_nes left resident is gone with the batch layout
+  if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));  // see run_attack_core
   e->h_wav_off.assign(off, off + B + 1);
   e->h_frame_off.resize(B + 1);
   e->h_chunk_off.resize(B + 1);
@@ -1225,9 +1227,12 @@ static int check_params(fb_engine *e, const fb_nes_params *p, int64_t N) {
   if (p->task == FB_TASK_CSI && p->attack_type == FB_UNTARGETED && (p->true_label < 0 || p->true_label >= S))
     return fb_fail(FB_E_ARG, "true label %d out of range", p->true_label);
   if (!(p->sigma > 0.0) && p->samples_per_draw >= 2) return fb_fail(FB_E_ARG, "sigma must be > 0");
+  if (p->bits_per_sample != 0 && (p->bits_per_sample < 2 || p->bits_per_sample > 16))
+    return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported (2 .. 16)", p->bits_per_sample);
   if (num_frames(e->cfg, N) <= 0) return fb_fail(FB_E_ARG, "audio shorter than one frame");
   return FB_OK;
 }
+static inline int nes_bits(const fb_nes_params *p) { return p->bits_per_sample ? p->bits_per_sample : 16; }
 
 // (re)builds the equal-length batch layout of B utterances of N samples
 static int prepare_nes_batch(fb_engine *e, int64_t N, int B) {
@@ -1274,7 +1279,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   } else {
     fb_launch_perturb(e->stream, e->adver.as<double>(), with_dist ? e->audio.as<double>() : nullptr, N, half,
                       p->sigma, p->seed, iter, p->stream, noise_dev, e->wav.as<int16_t>(),
-                      e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>(), stop);
+                      e->dist_part.as<double>(), &ndp, noise_dev ? nullptr : e->zbuf.as<float>(), stop, nes_bits(p));
   }
   e->pre_iter = -1;
   // GMM systems inside the device-controlled loop: finalisation and loss share one launch
@@ -1319,22 +1324,30 @@ static int attack_batch_size(const fb_engine *e) {
   return k < 1 ? 1 : (k > 16 ? 16 : k);
 }
 static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, const double *noise_all, int it_base,
-                           int count, bool reset, bool disable_stop, double *trace_dev) {
+                           int count, bool reset, bool disable_stop, double *trace_dev,
+                           unsigned long long *ticks = nullptr) {
   const int half = p->samples_per_draw / 2;
   FBCHK(e->ctl.ensure(sizeof(FbCtlDev)));
   FBCHK(e->ctl_ls.ensure(sizeof(double) * (size_t)(p->plateau_length > 0 ? p->plateau_length : 1)));
   FbCtlDev *ctl = e->ctl.as<FbCtlDev>();
   if (reset) {
     e->pre_iter = -1;
+    // The ticket of k_vad_delta_cmvn and the arrival counter of k_gmm_finalize_loss are left at zero by every launch
+    // that completes; one that was aborted or failed would leave them elsewhere and every later launch would then
+    // mis-assign utterances / skip its loss body.  A new attack starts them clean.
+    if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
+    if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
     FbCtlDev h;
     memset(&h, 0, sizeof(h));
     h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;
     h.ls = e->ctl_ls.as<double>();
     h.plateau_length = p->plateau_length;
     h.disable_stop = disable_stop ? 1 : 0;
+    h.ticks = ticks;
     *e->h_ctl = h;
     HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
     FBCHK(sync_stream(e));  // h_ctl is reused for the read-back below
+    if (ticks) fb_launch_stamp(e->stream, ticks);
   }
   const double one_minus_m = 1.0 - p->momentum;
   const int K = attack_batch_size(e);
@@ -1357,7 +1370,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
                                               p->momentum, one_minus_m, p->epsilon, e->audio.as<double>(),
                                               e->grad_m.as<double>(), e->adver.as<double>(), ctl, p->seed,
                                               (uint32_t)(it + 1), p->stream, e->wav.as<int16_t>(),
-                                              e->dist_part.as<double>());
+                                              e->dist_part.as<double>(), nes_bits(p));
         e->pre_iter = (long long)it + 1;
       } else {
         fb_launch_grad_update(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(), noise_dev,
@@ -1415,6 +1428,19 @@ extern "C" int fb_get_grad(fb_engine *e, const fb_nes_params *p, const double *a
 }
 
 
+// device clock stamps of the attack that just ran -> seconds per iteration (e->iter_seconds)
+static int collect_iter_seconds(fb_engine *e, int rows) {
+  e->iter_seconds.assign((size_t)(rows > 0 ? rows : 0), 0.0);
+  if (rows <= 0) return FB_OK;
+  std::vector<unsigned long long> t((size_t)rows + 1);
+  FBCHK(d2h(e, t.data(), e->ticks.p, sizeof(unsigned long long) * t.size()));
+  FBCHK(sync_stream(e));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) khz = 100000;
+  for (int i = 0; i < rows; ++i) e->iter_seconds[i] = (double)(t[i + 1] - t[i]) / (1.0e3 * khz);
+  return FB_OK;
+}
+
 // ------------------------------------------------- foreign models (plugin API)
 // The reference's FakeBob accepts ANY `model` with score / make_decisions (README.md:136; FAKEBOB.py:53,89,250).
 // For a model that is not one of this library's systems the scores come from a host callback; everything else of
@@ -1432,6 +1458,8 @@ static int check_params_ext(fb_engine *e, const fb_nes_params *p, int64_t N, int
   if (p->task == FB_TASK_CSI && p->attack_type == FB_UNTARGETED && (p->true_label < 0 || p->true_label >= S))
     return fb_fail(FB_E_ARG, "true label %d out of range", p->true_label);
   if (!(p->sigma > 0.0) && p->samples_per_draw >= 2) return fb_fail(FB_E_ARG, "sigma must be > 0");
+  if (p->bits_per_sample != 0 && (p->bits_per_sample < 2 || p->bits_per_sample > 16))
+    return fb_fail(FB_E_ARG, "bits_per_sample %d unsupported (2 .. 16)", p->bits_per_sample);
   return FB_OK;
 }
 
@@ -1542,9 +1570,12 @@ extern "C" int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_sco
     h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;
     h.ls = e->ctl_ls.as<double>();
     h.plateau_length = p->plateau_length;
+    FBCHK(e->ticks.ensure(sizeof(unsigned long long) * ((size_t)p->max_iter + 1)));
+    h.ticks = e->ticks.as<unsigned long long>();
     *e->h_ctl = h;
     HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
     FBCHK(sync_stream(e));
+    fb_launch_stamp(e->stream, h.ticks);
   }
   const double one_minus_m = 1.0 - p->momentum;
   for (int it = 0; it < p->max_iter; ++it) {
@@ -1564,13 +1595,14 @@ extern "C" int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_sco
   const int rows = e->h_ctl->iters_done;
   const bool broke = e->h_ctl->broke != 0;
   e->nes_iters += rows;
+  FBCHK(collect_iter_seconds(e, rows));
   if (trace && rows > 0) FBCHK(d2h(e, trace, trace_dev, sizeof(double) * (size_t)rows * (3 + S)));
   const int last_iter = broke ? e->h_ctl->stop_iter : p->max_iter - 1;
   *success_flag = (last_iter < p->max_iter - 1) ? 1 : -1;  // FAKEBOB.py:219
   if (n_trace) *n_trace = rows;
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N));
   e->cached_B = -1;  // the scoring batch layout no longer describes e->wav
-  fb_launch_quantize(e->stream, e->adver.as<double>(), N, 16, e->wav.as<int16_t>());
+  fb_launch_quantize(e->stream, e->adver.as<double>(), N, p->bits_per_sample ? p->bits_per_sample : 16, e->wav.as<int16_t>());
   FBCHK(d2h(e, adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N));
   if (adver_f64) FBCHK(d2h(e, adver_f64, e->adver.p, sizeof(double) * (size_t)N));
   FBCHK(sync_stream(e));
@@ -1610,8 +1642,10 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
     FBCHK(e->trace_dev.ensure(sizeof(double) * (size_t)p->max_iter * (3 + S)));
     trace_dev = e->trace_dev.as<double>();
   }
-  FBCHK(run_attack_core(e, p, N, noise_all, 0, p->max_iter, true, false, trace_dev));
+  FBCHK(e->ticks.ensure(sizeof(unsigned long long) * ((size_t)p->max_iter + 1)));
+  FBCHK(run_attack_core(e, p, N, noise_all, 0, p->max_iter, true, false, trace_dev, e->ticks.as<unsigned long long>()));
   const int rows = e->h_ctl->iters_done;  // one trace row per executed iteration, the stopping one included
+  FBCHK(collect_iter_seconds(e, rows));
   const bool broke = e->h_ctl->broke != 0;
   const int it = e->h_ctl->stop_iter;
   e->nes_iters += rows;
@@ -1622,10 +1656,17 @@ extern "C" int fb_attack(fb_engine *e, const fb_nes_params *p, const double *aud
   if (n_trace) *n_trace = rows;
   // adver -> int16 (:220)
   FBCHK(e->wav.ensure(sizeof(int16_t) * (size_t)N * B));
-  fb_launch_quantize(e->stream, e->adver.as<double>(), N, 16, e->wav.as<int16_t>());
+  fb_launch_quantize(e->stream, e->adver.as<double>(), N, nes_bits(p), e->wav.as<int16_t>());
   FBCHK(d2h(e, adv_i16, e->wav.p, sizeof(int16_t) * (size_t)N));
   if (adver_f64) FBCHK(d2h(e, adver_f64, e->adver.p, sizeof(double) * (size_t)N));
   FBCHK(sync_stream(e));
+  return FB_OK;
+}
+
+extern "C" int fb_attack_iter_seconds(fb_engine *e, double *seconds, int n) {
+  if (!e || !seconds || n < 0) return fb_fail(FB_E_ARG, "bad argument");
+  if ((size_t)n > e->iter_seconds.size()) return fb_fail(FB_E_STATE, "the last attack ran %zu iterations (asked for %d)", e->iter_seconds.size(), n);
+  for (int i = 0; i < n; ++i) seconds[i] = e->iter_seconds[i];
   return FB_OK;
 }
 

@@ -36,10 +36,13 @@ void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, 
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
                        const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part,
                        float *zbuf /* nullable: float32 normals [half][N] for the gradient kernel */,
-                       const int *stop = nullptr /* nullable: device flag, != 0 -> the launch does nothing */);
+                       const int *stop = nullptr /* nullable: device flag, != 0 -> the launch does nothing */,
+                       int bits = 16 /* bits_per_sample of the cast: scale 2^(bits - 1) */);
 void fb_launch_perturb_f64(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                            double sigma, uint64_t seed, uint32_t iter, uint32_t stream, const double *noise_pos,
                            double *x, double *dist_part, int *n_dist_part, float *zbuf);
+// *t = the device's constant-rate clock (wall_clock64) when the stream gets there
+void fb_launch_stamp(hipStream_t s, unsigned long long *t);
 // plain quantisation of float64 audio (model.score on float input)
 void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q);
 // noise dump (tests)
@@ -55,6 +58,9 @@ struct FbCtlDev {
   double *ls;  // [plateau_length] recent losses
   int n_ls, plateau_length;
   int stop, broke, stop_iter, iters_done, err, disable_stop;
+  unsigned long long *ticks;  // nullable: [1 + max_iter] device constant-rate clock (wall_clock64): [0] = start of the
+                              // attack, [1 + it] = iteration it's loss evaluated -- the per-iteration times of the
+                              // reference's trace (FAKEBOB.py:205-212)
 };
 struct FbNesDev {  // device control/result block of one NES iteration
   double adver_loss, final_loss, distance;
@@ -75,7 +81,7 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
                              double *adver, const FbCtlDev *ctl, uint64_t seed, uint32_t next_iter, uint32_t stream,
-                             int16_t *q, double *dist_part);
+                             int16_t *q, double *dist_part, int bits = 16);
 // grad estimate (numpy-pairwise order) + optional momentum/sign/clip update.
 // do_update: 0 = only grad_out; 1 = momentum+update with lr.
 void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int half, double sigma,

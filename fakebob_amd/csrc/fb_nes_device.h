@@ -262,6 +262,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
           row[0] = d; row[1] = al; row[2] = lr;
           for (int m = 0; m < S; ++m) row[3 + m] = sc0[m];
         }
+        if (c.ticks) c.ticks[it + 1] = wall_clock64();  // [0] = the attack's start (k_stamp)
         ctl->iters_done = it + 1;
       }
     }

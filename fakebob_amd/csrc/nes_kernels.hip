@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
                                                  const double *__restrict__ noise_pos,
                                                  int16_t *__restrict__ q,
                                                  double *__restrict__ dist_part,
-                                                 float *__restrict__ zbuf, const int *__restrict__ stop) {
+                                                 float *__restrict__ zbuf, const int *__restrict__ stop,
+                                                 double qscale /* 2^(bits_per_sample - 1): gmm_ubm_OSI.py:85 */) {
   if (stop && *stop) return;
   const int64_t n4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
         // noise_audios = sigma * noise + audio            (FAKEBOB.py:237)
         double xp = __dadd_rn(__dmul_rn(sigma, z[k]), a[k]);
         double xm = __dadd_rn(__dmul_rn(sigma, -z[k]), a[k]);
-        vp[k] = fb_quantize(xp, 32768.0);
-        vm[k] = fb_quantize(xm, 32768.0);
+        vp[k] = fb_quantize(xp, qscale);
+        vm[k] = fb_quantize(xm, qscale);
       }
       if (cnt == 4 && ((N & 3) == 0)) {
         *reinterpret_cast<short4 *>(qp) = make_short4(vp[0], vp[1], vp[2], vp[3]);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
     }
     if (j == 0) {
       for (int k = 0; k < cnt; ++k) {
-        q[n0 + k] = fb_quantize(a[k], 32768.0);  // column 0: the clean adver
+        q[n0 + k] = fb_quantize(a[k], qscale);  // column 0: the clean adver
         if (audio) { double d = fabs(__dsub_rn(audio[n0 + k], a[k])); dmax = d > dmax ? d : dmax; }
       }
     }
@@ -85,12 +86,12 @@ __global__ __launch_bounds__(256) void k_perturb(const double *__restrict__ adve
 void fb_launch_perturb(hipStream_t s, const double *adver, const double *audio, int64_t N, int half,
                        double sigma, uint64_t seed, uint32_t iter, uint32_t stream,
                        const double *noise_pos, int16_t *q, double *dist_part, int *n_dist_part, float *zbuf,
-                       const int *stop) {
+                       const int *stop, int bits) {
   int64_t n4 = (N + 3) / 4;
   dim3 grid((unsigned)((n4 + 255) / 256), (unsigned)(half > 0 ? half : 1));
   if (n_dist_part) *n_dist_part = (int)grid.x;
   hipLaunchKernelGGL(k_perturb, grid, dim3(256), 0, s, adver, audio, N, half, sigma, seed, iter, stream,
-                     noise_pos, q, dist_part, zbuf, stop);
+                     noise_pos, q, dist_part, zbuf, stop, ldexp(1.0, bits - 1));
 }
 
 // Foreign-model path (the reference's plugin API, README.md:136: any `model` with score / make_decisions): the
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(256) void k_quantize(const double *__restrict__ x, 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) q[i] = fb_quantize(x[i], scale);
 }
+__global__ void k_stamp(unsigned long long *t) { *t = wall_clock64(); }
+void fb_launch_stamp(hipStream_t s, unsigned long long *t) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, t); }
 void fb_launch_quantize(hipStream_t s, const double *x, int64_t n, int bits, int16_t *q) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *
                                                         const double *__restrict__ audio, double *__restrict__ grad_m,
                                                         double *__restrict__ adver, const FbCtlDev *__restrict__ ctl,
                                                         uint64_t seed, uint32_t next_iter, uint32_t stream,
-                                                        int16_t *__restrict__ q, double *__restrict__ dist_part) {
+                                                        int16_t *__restrict__ q, double *__restrict__ dist_part,
+                                                        double qscale) {
   if (ctl->stop) return;
   const double lr = ctl->lr;
   extern __shared__ double s_loss[];  // loss[1..spd], the block's updated samples [256], the block's normals [half][256]
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *
     a = a > hi ? hi : a;
     adver[n] = a;
     s_a[threadIdx.x] = a;
-    q[n] = fb_quantize(a, 32768.0);  // column 0 of the next batch: the clean adver
+    q[n] = fb_quantize(a, qscale);  // column 0 of the next batch: the clean adver
     const double d = fabs(__dsub_rn(au, a));
     dmax = d;
   } else {
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const double a = s_a[4 * n4l + k], z = (double)zf[k];
-      vp[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, z), a), 32768.0);   // noise_audios = sigma * noise + audio (:237)
-      vm[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, -z), a), 32768.0);
+      vp[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, z), a), qscale);   // noise_audios = sigma * noise + audio (:237)
+      vm[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, -z), a), qscale);
     }
     if (cnt == 4 && ((N & 3) == 0)) {
       *reinterpret_cast<float4 *>(zp) = make_float4(zf[0], zf[1], zf[2], zf[3]);
@@ -387,16 +391,17 @@ __global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
                              double *adver, const FbCtlDev *ctl, uint64_t seed, uint32_t next_iter, uint32_t stream,
-                             int16_t *q, double *dist_part) {
+                             int16_t *q, double *dist_part, int bits) {
   const int blocks = (int)((N + 255) / 256);
+  const double qscale = ldexp(1.0, bits - 1);
   const size_t shm = sizeof(double) * (size_t)(2 * half + 256) + sizeof(float) * 256 * (size_t)(half > 0 ? half : 1);
   const int nthr = FB_UP_THREADS;
   if (2 * half <= 128)
     hipLaunchKernelGGL(k_update_perturb<true>, dim3(blocks), dim3(nthr), shm, s, loss, N, half, sigma, zbuf, momentum,
-                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
+                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part, qscale);
   else
     hipLaunchKernelGGL(k_update_perturb<false>, dim3(blocks), dim3(FB_UP_THREADS), shm, s, loss, N, half, sigma, zbuf, momentum,
-                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part);
+                       one_minus_m, epsilon, audio, grad_m, adver, ctl, seed, next_iter, stream, q, dist_part, qscale);
   return blocks;
 }
 

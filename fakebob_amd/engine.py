@@ -13,7 +13,7 @@ from .models import stack_models
 
 def nes_params(task, attack_type, adver_thresh=0., epsilon=0.002, max_iter=1000, max_lr=0.001,
                min_lr=1e-6, samples_per_draw=50, sigma=0.001, momentum=0.9, plateau_length=5,
-               plateau_drop=2., threshold=0., target=None, true=None, seed=42, stream=0):
+               plateau_drop=2., threshold=0., target=None, true=None, seed=42, stream=0, bits_per_sample=16):
     p = N.NesParams()
     p.task = N.TASK[task]
     p.attack_type = N.ATTACK[attack_type]
@@ -24,6 +24,7 @@ def nes_params(task, attack_type, adver_thresh=0., epsilon=0.002, max_iter=1000,
     p.target = 0 if target is None else int(target)
     p.true_label = 0 if true is None else int(true)
     p.seed = int(seed); p.stream = int(stream)
+    p.bits_per_sample = int(bits_per_sample)
     return p
 
 
@@ -214,14 +215,24 @@ class Engine(object):
                                   N.ptr(trace), C.byref(nt), C.byref(flag)))
         return adv, flag.value, adv_f, trace[:nt.value]
 
+    def attack_iter_seconds(self, n):
+        """Seconds per iteration of the last attack / attack_ext (device clock, fb_attack_iter_seconds)."""
+        out = np.zeros(max(int(n), 0), np.float64)
+        if n > 0:
+            N.check(self._L.fb_attack_iter_seconds(self._h, N.ptr(out), C.c_int(int(n))))
+        return out
+
     # ---- NES with a foreign model (the reference's plugin API): scores come from `score_fn`
     @staticmethod
     def _score_cb(score_fn, S, err):
-        """score_fn(audios (N, B) float64) -> (B, S) scores, wrapped as an fb_score_cb.  An exception raised by the
-        model is kept in err[0] and re-raised by the caller (a ctypes callback cannot propagate it)."""
+        """score_fn(audios (N, B) float64) -> (B, S) scores, wrapped as an fb_score_cb.  The model gets its OWN
+        C-contiguous (N, B) array, as the reference hands it one (FAKEBOB.py:237): the callback's buffer is the
+        engine's pinned staging area, recycled on the next iteration, and a model may keep or edit its batch.  An
+        exception raised by the model is kept in err[0] and re-raised by the caller (a ctypes callback cannot
+        propagate it)."""
         def _cb(_ctx, aud, n, b, out):
             try:
-                a = np.ctypeslib.as_array(aud, shape=(b, n)).T          # (N, B) view, columns = utterances
+                a = np.ascontiguousarray(np.ctypeslib.as_array(aud, shape=(b, n)).T)   # (N, B) copy, columns = utterances
                 sc = np.asarray(score_fn(a), np.float64).reshape(b, S)
                 np.ctypeslib.as_array(out, shape=(b, S))[...] = sc
                 return 0

@@ -103,6 +103,8 @@ class _Reader(object):
             line = self.b[self.i:j].decode("ascii").split()
             if line:
                 rows.append([float(x) for x in line])
+            if j >= len(self.b):
+                raise ValueError("kaldi_io: unterminated text matrix (no closing ']')")
             if self.b[j:j + 1] == b"]":
                 self.i = j + 1
                 break

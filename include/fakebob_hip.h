@@ -109,6 +109,9 @@ typedef struct {
   int true_label;    /* attack(true=...) */
   uint64_t seed;     /* Philox4x32-10 key */
   uint32_t stream;   /* Philox counter word 3 (utterance / attack id) */
+  int bits_per_sample; /* attack(bits_per_sample=...): the int16 casts use 2^(bits_per_sample - 1) -- of every NES
+                          sample before scoring (gmm_ubm_OSI.py:85) and of the returned audio (FAKEBOB.py:220).
+                          2 .. 16; 0 means 16 */
 } fb_nes_params;
 
 const char *fb_last_error(void);
@@ -191,6 +194,12 @@ int fb_attack(fb_engine *e, const fb_nes_params *p, const double *audio,
               double *adver_f64, double *trace, int *n_trace,
               int *success_flag);
 
+/* Seconds each iteration of the LAST fb_attack / fb_attack_ext took, iteration 0 from the attack's start: the
+ * `used_time` column of the reference's trace pickle (FAKEBOB.py:205-212 times every loop body with time.time()).
+ * Taken from the device's constant-rate clock where iteration i's loss is evaluated, so it is exact although the
+ * host only looks at the device once per batch of iterations.  n <= the number of trace rows of that attack. */
+int fb_attack_iter_seconds(fb_engine *e, double *seconds, int n);
+
 /* Threshold sweep (FAKEBOB.py:39-137).  model_threshold: the system's own
  * threshold consulted by make_decisions.  Returns FB_E_LIMIT if
  * max_total_iters gradient steps did not reach acceptance. */
@@ -208,7 +217,9 @@ int fb_estimate_threshold(fb_engine *e, const fb_nes_params *p,
  * samples, exactly the columns FAKEBOB.py:234-238 hands to model.score; scores[B*S] out; return 0 -- and
  * everything else of the NES iteration (Philox noise, perturbation, loss, gradient estimate, momentum sign step,
  * clipping, loop control) still runs on the device.  No model has to be loaded into the engine; S = number of
- * enrolled speakers (1 for SV).  Arguments otherwise as fb_get_grad / fb_attack. */
+ * enrolled speakers (1 for SV).  Arguments otherwise as fb_get_grad / fb_attack.
+ * Lifetime: `audios` points into the engine's staging memory and is valid only DURING the call -- it is reused by the
+ * next iteration; a model that keeps its batch must copy it (the Python mirror hands the model a copy). */
 typedef int (*fb_score_cb)(void *ctx, const double *audios, int64_t N, int B, double *scores);
 int fb_get_grad_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, void *cb_ctx,
                     const double *audio, int64_t N, uint32_t iter, const double *noise_pos,

@@ -349,8 +349,8 @@ def test_fakebob_accepts_any_model_with_score_and_rejects_objects_without():
         FakeBob("SV", "targeted", object())
     with pytest.raises(ValueError):
         FakeBob("XYZ", "targeted", Plain())
-    with pytest.raises(ValueError):                      # anything but 16-bit is refused, not silently ignored
-        fb.get_grad(np.zeros(1600), bits_per_sample=8)
+    with pytest.raises(ValueError):                      # the container is int16: 2 .. 16 bits, nothing else
+        fb.get_grad(np.zeros(1600), bits_per_sample=24)
 
 
 def test_bench_roofline_object_and_traffic_file_follow_the_contract():
