@@ -156,7 +156,7 @@ def main(argv=None, model_factory=None, bob_factory=None):
     # one Philox key for the whole job: drawn on rank 0 when --seed is omitted and broadcast, so that a multi-rank
     # run is reproducible and its results do not depend on the sharding
     seed = args.seed if args.seed is not None else (int(np.random.randint(0, 2 ** 31 - 1)) if rank == 0 else 0)
-    seed = int(parallel.broadcast_threshold(float(seed), dist))
+    seed = parallel.broadcast_int(seed, dist)
     hp = dict(adver_thresh=args.adver_thresh, epsilon=args.epsilon, max_iter=args.max_iter, max_lr=args.max_lr,
               min_lr=args.min_lr, samples_per_draw=args.samples_per_draw, sigma=args.sigma,
               momentum=args.momentum, plateau_length=args.plateau_length, plateau_drop=args.plateau_drop)

@@ -6,7 +6,7 @@ is a plain `for` loop sharing only the read-only model and, for OSI/SV, one pre-
 utterances dealt round-robin, NO collective inside an attack.  RCCL (torch.distributed backend
 "nccl" on ROCm; "gloo" in the CPU tests) is used only for
   * one broadcast of the estimated threshold (1 x float64) from rank 0 -- mirrors
-    attackMain.py:356-357 / :393-394, and
+    attackMain.py:356-357 / :393-394 --, one of the job's Philox key (1 x int64) when --seed is omitted, and
   * one all-reduce(sum) of {success_cnt, total_cnt, nes_iters, scored_utts} (4 x int64) at the end
     -- mirrors attackMain.py:312,335-336,411.
 """
@@ -60,6 +60,16 @@ def broadcast_threshold(value, dist=None, src=0):
     t = torch.tensor([float(value) if value is not None else 0.0], dtype=torch.float64, device=_device(dist))
     dist.broadcast(t, src=src)
     return float(t.item())
+
+
+def broadcast_int(value, dist=None, src=0):
+    """An integer (the job's Philox key) from rank `src` to everyone, as int64 -- not through a float."""
+    if dist is None:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_device(dist))
+    dist.broadcast(t, src=src)
+    return int(t.item())
 
 
 def reduce_counters(counters, dist=None):

@@ -41,6 +41,8 @@ WORKER = textwrap.dedent('''
     def attack(item, thr):
         assert abs(thr - 0.2277) < 1e-15            # every rank received rank 0's estimate
         return (1 if item %% 3 else -1), item + 1, 51 * (item + 1)
+    key = P.broadcast_int((1 << 62) + 12345 if rank == 0 else 0, dist)   # beyond float64's 53 bits: an int64 path
+    assert key == (1 << 62) + 12345
     g = P.run_sharded(list(range(11)), attack, estimate, dist)
     assert (len(calls) == 1) == (rank == 0)         # only rank 0 estimates
     with open(sys.argv[1] + "/rank%%d.json" %% rank, "w") as w:     # per-rank file: stdout of two ranks interleaves
