@@ -200,32 +200,42 @@ def timed_region(args, torch, dist, workers, K):
 
 
 def bench_ivector(args, torch):
-    """BASELINE.json configs[2]: i-vector-PLDA SV targeted attack, spd=50, C=2048, D=72, R=400, LDA 200
-    (the T-matrix contraction path).  Not the headline metric: run with --arch iv."""
+    """BASELINE.json configs[2] (default: i-vector-PLDA SV targeted, spd=50) and the single-GPU half of configs[4]
+    (--task OSI --speakers 10 --spd 200 -> 201 utterances per NES batch), C=2048, D=72, R=400, LDA 200.  Not the
+    headline metric: run with --arch iv."""
     from fakebob_amd import parallel
     from fakebob_amd.engine import Engine, nes_params
     from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
     rank, world, dev_index, dist = dist_setup(args, torch)
     t0 = time.perf_counter()
-    sy = synthetic_ivector_system(C=C_GAUSS, D=D_FEAT, R=400, L=200, n_speakers=1)
-    sy = sy.with_enrolled(sy.enrolled, [-40.0], [10.0])
+    task, spd = args.task, args.spd
+    n_spk = args.speakers if args.speakers is not None else (1 if task == "SV" else 10)
+    if task == "SV":
+        n_spk = 1
+    B = 2 * (spd // 2) + 1
+    sy = synthetic_ivector_system(C=C_GAUSS, D=D_FEAT, R=400, L=200, n_speakers=n_spk)
+    sy = sy.with_enrolled(sy.enrolled, [-40.0] * n_spk, [10.0] * n_spk)
     K = max(1, args.streams)
+    fused = (K < 3) if args.chain == "auto" else (args.chain == "fused")
     engs = []
     for k in range(K):
         e = Engine(dev_index)
-        e.load_ivector(sy, "SV")
+        e.load_ivector(sy, task)
+        e.set_fused_chain(fused)
         engs.append(e)
     eng = engs[0]
     t_load = time.perf_counter() - t0
-    kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_iter=1000, threshold=1.0)
+    kw = dict(samples_per_draw=spd, epsilon=0.002, sigma=0.001, max_iter=1000, threshold=1.0)
+    if task != "SV":
+        kw["target"] = 0
     auds = [synthetic_audio(rank * K + k, N_SAMPLES) for k in range(K)]
-    prms = [nes_params("SV", "targeted", seed=42, stream=rank * K + k, **kw) for k in range(K)]
+    prms = [nes_params(task, "targeted", seed=42, stream=rank * K + k, **kw) for k in range(K)]
     res = [None] * K
 
     started = [False] * K
 
     def run(k, n, timed):   # first call: upload + reset; later calls continue the resident attack (see the GMM path)
-        res[k] = engs[k].bench_nes(prms[k], auds[k], 0 if not started[k] else -1, n, time_gmm=timed)
+        res[k] = engs[k].bench_nes(prms[k], auds[k], 0 if not started[k] else -1, n, time_gmm=1 if timed else 0)
         started[k] = True
 
     workers = Workers(K, run)
@@ -239,71 +249,91 @@ def bench_ivector(args, torch):
         assert total_steps == world * args.steps * K
     its = total_steps / dt
     single = None
-    if rank == 0 and K > 1 and not args.no_single:
+    solve_ms = None
+    if rank == 0:
+        # one attack in flight, same step count: the latency view, and the pass that times k_iv_solve_packed
+        # (HIP events around each of its launches on the attack's stream)
+        eng.set_fused_chain(True if args.chain == "auto" else fused)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        eng.bench_nes(prms[0], auds[0], -1, args.steps, time_gmm=False)
+        r1 = eng.bench_nes(prms[0], auds[0], -1, args.steps, time_gmm=2)
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
-        single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
-                  "note": "one attack in flight (a single launch chain), same workload"}
+        solve_ms = r1[1] / args.steps
+        if K > 1 and not args.no_single:
+            single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
+                      "note": "one attack in flight (a single launch chain), same workload"}
     workers.close()
     if rank == 0:
-        tri = 400 * 401 // 2
+        R = 400
+        tri = R * (R + 1) // 2
         n_active = eng.debug_iv_active()
-        n_bgroups = (SPD + 1 + 63) // 64                                   # utterance groups of 64 -> passes over the rows
+        n_bgroups = (B + 63) // 64                                          # utterance groups of 64 -> passes over the rows
         # ALGORITHMIC bytes of the T-matrix contraction: the float64 rows of Sigma^-1 M and U of every component with
         # posterior mass, read once per launch pair -- Kaldi's own loop skips gamma == 0 components
         # (IvectorExtractor::GetIvectorDistMean/Prior); the kernels stream exactly these rows once per
-        # 64-utterance group (one group at spd=50)
-        bytes_alg = 8.0 * n_active * (D_FEAT * 400 + tri)
-        bytes_all = 8.0 * (C_GAUSS * D_FEAT * 400 + C_GAUSS * tri)
+        # 64-utterance group
+        bytes_alg = 8.0 * n_active * (D_FEAT * R + tri)
+        bytes_all = 8.0 * (C_GAUSS * D_FEAT * R + C_GAUSS * tri)
         bytes_exec = bytes_alg * n_bgroups
-        flops_alg = 2.0 * (SPD + 1) * n_active * (D_FEAT * 400 + tri)
-        flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * 400 + tri)   # 64-row MFMA tiles, 51 useful
+        flops_alg = 2.0 * B * n_active * (D_FEAT * R + tri)
+        flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * R + tri)   # 64-row MFMA tiles
         con_ms = ms_con / args.steps
         gbps = bytes_alg / (con_ms * 1e-3) / 1e9
-        out = {"metric": "NES iterations/sec (i-vector-PLDA SV, samples_per_draw=50, 3 s@16 kHz)", "value": its,
+        contraction = {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
+                                 "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
+                       "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                       "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
+                       "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
+                       "all_components_bytes": bytes_all,
+                       "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
+                               "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the two "
+                               "contraction kernels, HIP events on the attack's stream (with several attacks in flight "
+                               "it includes time shared with other attacks' kernels)",
+                       "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
+                                    "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,
+                                    "peak_tflops": PEAK_F64_MFMA_TFLOPS,
+                                    "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+        try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
+                contraction["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
+            contraction["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
+        except Exception:
+            pass
+        # k_iv_solve_packed: B Cholesky factorisations + two triangular solves of R x R (R^3/3 + 2 R^2
+        # flops per utterance) on the float64 matrix cores
+        solve_flops = B * (R ** 3 / 3.0 + 2.0 * R * R)
+        solve_tf = solve_flops / (solve_ms * 1e-3) / 1e12 if solve_ms else 0.0
+        solve = {"kernel": "k_iv_solve_packed (batched blocked Cholesky + substitutions of the R x R posterior "
+                           "precision, v_mfma_f64_16x16x4)", "bound": "mfma", "achieved": solve_tf,
+                 "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": solve_tf / PEAK_F64_MFMA_TFLOPS,
+                 "traffic": None, "avg_launch_ms": solve_ms, "algorithmic_flops_per_launch": solve_flops,
+                 "note": "HIP events around every launch of an extra one-attack pass of the same step count"}
+        dominant = solve if (solve_ms or 0.0) >= con_ms else contraction
+        out = {"metric": "NES iterations/sec (i-vector-PLDA %s, samples_per_draw=%d, 3 s@16 kHz)" % (task, spd), "value": its,
                "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64 (extractor/PLDA), f32 (gselect: two-term f16 split on MFMA)", "data": "synthetic",
-               "vs_readme_nominal": its / 0.083,
+               "vs_readme_nominal": its / 0.083 if (task == "SV" and spd == SPD) else None,
                "single_attack": single,
-               "config": {"workload": "i-vector-PLDA SV targeted, C=2048, D=72, R=400, LDA=200, spd=50, N=48000, "
-                                      "%d attacks in flight per GPU" % K, "attacks_in_flight_per_gpu": K,
-                          "voiced_rows_per_iter": rows, "model_load_s": t_load},
-               "roofline": {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
-                                      "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
-                            "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                            "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
-                            "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
-                            "all_components_bytes": bytes_all,
-                            "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
-                                    "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the two "
-                                    "contraction kernels, HIP events on the attack's stream (with several attacks in flight "
-                                    "it includes time shared with other attacks' kernels)",
-                            "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
-                                         "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,
-                                         "peak_tflops": PEAK_F64_MFMA_TFLOPS,
-                                         "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}}
-        try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
-                out["roofline"]["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
-        except Exception:
-            pass
+               "config": {"workload": "i-vector-PLDA %s targeted, %d enrolled, C=2048, D=72, R=400, LDA=200, spd=%d (%d "
+                                      "utterances per NES batch), N=48000, %d attacks in flight per GPU"
+                                      % (task, n_spk, spd, B, K), "attacks_in_flight_per_gpu": K,
+                          "voiced_rows_per_iter": rows, "model_load_s": t_load,
+                          "launch_chain": "fused" if fused else "unfused"},
+               "roofline": dominant, "roofline_contraction": contraction, "roofline_solve": solve}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             import numpy as np
             ctx = O.IvSystemCtx(O.default_cfg(), sy, nthreads=1)
-            n_s = SPD + 1                                        # one full NES batch (a few seconds of CPU work)
+            n_s = min(B, SPD + 1)                                # a bounded sample: at most 51 utterances (seconds of CPU work)
             wavs = [(synthetic_audio(u, N_SAMPLES) * 32768).astype(np.int16) for u in range(n_s)]
             t0 = time.perf_counter()
             ctx.score_batch(wavs)
             t8 = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": 1.0 / t8, "unit": "NES iterations/s", "cores": 1,
-                                   "kind": "port", "sample": "the %d utterances of one NES batch (3 s each) scored by the CPU "
-                                   "oracle, 1 thread, %.1f s" % (n_s, t8)}
+            out["cpu_baseline"] = {"value": n_s / (t8 * B), "unit": "NES iterations/s", "cores": 1,
+                                   "kind": "port", "sample": "%d of the %d utterances of one NES batch (3 s each) scored by "
+                                   "the CPU oracle, 1 thread, %.1f s" % (n_s, B, t8)}
         emit(out)
     if dist is not None:
         dist.barrier()
@@ -379,6 +409,12 @@ def main():
     ap.add_argument("--precondition", type=int, default=60,
                     help="untimed iterations per attack run once before the declared warm-up (module load, first-touch "
                          "allocations, clock ramp of a cold GPU); reported in config.precondition_steps")
+    ap.add_argument("--chain", default="auto", choices=["auto", "fused", "unfused"],
+                    help="launch chain of the attack loop (fb_set_fused_chain): auto = 5 launches per iteration with fewer "
+                         "than 3 attacks in flight, the 8 separate launches otherwise (they interleave better)")
+    ap.add_argument("--task", default="SV", choices=["SV", "OSI", "CSI"], help="--arch iv: the system (configs[2]: SV; configs[4]: OSI)")
+    ap.add_argument("--speakers", type=int, default=None, help="--arch iv: enrolled speakers (default 1 for SV, 10 otherwise)")
+    ap.add_argument("--spd", type=int, default=SPD, help="--arch iv: samples_per_draw (configs[4]: 200)")
     ap.add_argument("--faithful", action="store_true",
                     help="run the reference pipeline's two file round trips on the device (MFCCs through Kaldi's "
                          "CompressedMatrix, scores through 6-digit text: gmm_ubm_kaldiHelper.py:138-140, 236-248) -- "
@@ -397,6 +433,7 @@ def main():
     from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
 
     K = max(1, args.streams)
+    fused = (K < 3) if args.chain == "auto" else (args.chain == "fused")
     ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
     models = [ubm] + spk
     kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_lr=0.001, min_lr=1e-6, momentum=0.9,
@@ -408,6 +445,7 @@ def main():
             e.set_frontend(compress_feats=1, text_scores=1)
         e.load_gmm(models)
         e.set_system("OSI")
+        e.set_fused_chain(fused)
         engs.append(e)
         utt = rank * K + k                                  # a different utterance per attack
         auds.append(synthetic_audio(utt, N_SAMPLES))
@@ -447,6 +485,7 @@ def main():
     single = None
     if rank == 0 and K > 1 and not args.no_single:
         # the same K steps with ONE attack in flight (a single launch chain): the latency view of the same path
+        engs[0].set_fused_chain(True if args.chain == "auto" else fused)   # what a lone attack runs (auto: fused)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         r1 = engs[0].bench_nes(prms[0], auds[0], -1, args.steps, time_gmm=True)
@@ -477,6 +516,7 @@ def main():
                                    "(compress_feats, text_scores)" if args.faithful else ""),
                        "faithful_pipeline": bool(args.faithful),
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
+                       "launch_chain": "5 launches per iteration (fused)" if fused else "8 launches per iteration",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
             "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, engs[0].gmm_kernel_variant),

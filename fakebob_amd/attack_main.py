@@ -153,6 +153,10 @@ def main(argv=None, model_factory=None, bob_factory=None):
         model_list = spk_id_list
     models = [model_factory(args.architecture, task, model_list, args.pre_model_dir, args.threshold,
                             os.path.join(args.out_dir, ident + ("-%d" % k))) for k in range(K)]
+    if K >= 3:  # several engines share the GPU: the separate launches interleave better (fb_set_fused_chain)
+        for m in models:
+            if hasattr(m, "engine"):
+                m.engine.set_fused_chain(False)
     # one Philox key for the whole job: drawn on rank 0 when --seed is omitted and broadcast, so that a multi-rank
     # run is reproducible and its results do not depend on the sharding
     seed = args.seed if args.seed is not None else (int(np.random.randint(0, 2 ** 31 - 1)) if rank == 0 else 0)

@@ -72,7 +72,8 @@ struct fb_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool time_gmm = false;       // record events around the GMM launch (bench)
+  int time_gmm = 0;            // bench: 1 = events around the GMM launch / the T-matrix contraction, 2 = around k_iv_solve_packed
+  int fuse_opt = -1;           // fb_set_fused_chain: 1 / 0, -1 = the FB_NO_FUSE environment variable decides
   bool gmm_pending = false;
   double gmm_ms_acc = 0.0;
   int64_t gmm_launches = 0;
@@ -749,8 +750,8 @@ static int time_collect(fb_engine *e) {
   e->gmm_pending = false;
   return FB_OK;
 }
-static int time_begin(fb_engine *e) {
-  if (!e->time_gmm) return FB_OK;
+static int time_begin(fb_engine *e, int what = 1) {
+  if (e->time_gmm != what) return FB_OK;
   if (e->evg_n >= 16) {  // ring full: drain (never happens with the batch sizes used)
     FBCHK(sync_stream(e));
     FBCHK(time_collect(e));
@@ -758,15 +759,15 @@ static int time_begin(fb_engine *e) {
   HIPCHK(hipEventRecord(e->evg_ring[2 * e->evg_n], e->stream));
   return FB_OK;
 }
-static int time_end(fb_engine *e) {
-  if (!e->time_gmm) return FB_OK;
+static int time_end(fb_engine *e, int what = 1) {
+  if (e->time_gmm != what) return FB_OK;
   HIPCHK(hipEventRecord(e->evg_ring[2 * e->evg_n + 1], e->stream));
   e->evg_n += 1;
   e->gmm_pending = true;
   return FB_OK;
 }
 
-static bool fb_fuse_on();
+static bool fb_fuse_on(const fb_engine *e);
 // mfcc -> VAD (+ row offsets) -> deltas -> CMVN -> voiced-row compaction
 static int run_post_mfcc(fb_engine *e, int B) {
   const FbFrontendDev &fe = e->fe;
@@ -786,7 +787,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
       HIPCHK(hipMemsetAsync(e->vad_pub.p, 0, e->vad_pub.cap, s));
       e->vad_epoch = 0;
     }
-    if (fb_fuse_on() && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
+    if (fb_fuse_on(e) && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                              e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
                                              e->row_off.as<int>(), e->feats.as<float>())) {
       e->vad_epoch += 1;
@@ -888,8 +889,10 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
                           e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(), e->iv_quad.as<double>());
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
+    FBCHK(time_begin(e, 2));
     fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
                        e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    FBCHK(time_end(e, 2));
     FB_DBG_SYNC(e, "solve");
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
     FB_DBG_SYNC(e, "backend");
@@ -1263,7 +1266,8 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
 }
 
 // One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
-static bool fb_fuse_on() {
+static bool fb_fuse_on(const fb_engine *e) {
+  if (e->fuse_opt >= 0) return e->fuse_opt != 0;  // fb_set_fused_chain
   return getenv("FB_NO_FUSE") == nullptr;  // FB_NO_FUSE=1: the 8-launch chain (A/B, debugging; read per call)
 }
 static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
@@ -1283,7 +1287,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   }
   e->pre_iter = -1;
   // GMM systems inside the device-controlled loop: finalisation and loss share one launch
-  const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_on();
+  const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_on(e);
   e->defer_finalize = fuse_fin;
   const int rc = run_scoring(e, B, e->h_frame_off[B]);
   e->defer_finalize = false;
@@ -1364,7 +1368,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
       FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base));
       FB_DBG_SYNC(e, "loss");
-      if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on()) {
+      if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e)) {
         // momentum sign step of this iteration + the perturbed batch of the next one in a single launch
         e->pre_ndp = fb_launch_update_perturb(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(),
                                               p->momentum, one_minus_m, p->epsilon, e->audio.as<double>(),
@@ -1837,6 +1841,12 @@ extern "C" int fb_gmm_acc_stats(fb_engine *e, const int16_t *wav, int64_t n, dou
 }
 
 
+extern "C" int fb_set_fused_chain(fb_engine *e, int on) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  e->fuse_opt = on < 0 ? -1 : (on ? 1 : 0);
+  return FB_OK;
+}
+
 extern "C" int fb_gmm_kernel_mode(fb_engine *e) {
   if (!e) return fb_fail(FB_E_ARG, "null engine");
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
@@ -1936,7 +1946,7 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
   const int it0 = (int)e->bench_it + warmup;
   FBCHK(sync_stream(e));
   HIPCHK(hipEventRecord(e->ev0, e->stream));
-  e->time_gmm = time_gmm != 0;
+  e->time_gmm = time_gmm;
   e->gmm_ms_acc = 0.0;
   e->gmm_launches = 0;
   FBCHK(run_attack_core(e, p, N, nullptr, it0, iters, false, true, nullptr));
@@ -1946,7 +1956,7 @@ extern "C" int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *
   e->nes_iters += warmup + iters;
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));
-  e->time_gmm = false;
+  e->time_gmm = 0;
   gmm_ms = e->gmm_ms_acc;  // sum over the timed launches
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));

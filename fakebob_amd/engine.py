@@ -345,6 +345,11 @@ class Engine(object):
         N.check(self._L.fb_bench_gmm_kernel(self._h, C.c_int(reps), C.byref(ms), C.byref(rows)))
         return ms.value, rows.value
 
+    def set_fused_chain(self, on):
+        """True: 5 launches per NES iteration (best for one attack per GPU); False: the 8 separate launches (better
+        with >= 3 engines sharing a GPU); None: library default.  Same trajectories (fb_set_fused_chain)."""
+        N.check(self._L.fb_set_fused_chain(self._h, C.c_int(-1 if on is None else (1 if on else 0))))
+
     def bench_nes(self, params, audio, warmup, iters, time_gmm=False):
         """Runs warmup+iters NES iterations (identical work to attack(), early stop disabled).
         Returns (ms over the timed iters [HIP events], summed GMM-kernel ms [HIP events around
@@ -352,6 +357,6 @@ class Engine(object):
         audio = np.ascontiguousarray(audio, np.float64).reshape(-1)
         ms, msg, rows = C.c_double(), C.c_double(), C.c_int64()
         N.check(self._L.fb_bench_nes(self._h, C.byref(params), N.ptr(audio), C.c_int64(audio.size),
-                                     C.c_int(warmup), C.c_int(iters), C.c_int(1 if time_gmm else 0),
+                                     C.c_int(warmup), C.c_int(iters), C.c_int(int(time_gmm)),
                                      C.byref(ms), C.byref(msg), C.byref(rows)))
         return ms.value, msg.value, rows.value
