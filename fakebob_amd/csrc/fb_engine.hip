@@ -117,7 +117,6 @@ struct fb_engine {
   int evg_n = 0;
   int t_max = 0;
   std::vector<int32_t> h_frame_rec;
-  DevBuf feat_mm;
   DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
   std::vector<int> h_frame_off, h_chunk_off;
@@ -227,7 +226,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->feat_mm, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -777,8 +776,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
     HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), s));
   }
   if (e->cfg.compress_feats) {  // make_mfcc.sh's `copy-feats --compress=true`: what VAD / deltas / CMVN read
-    FBCHK(e->feat_mm.ensure(sizeof(float) * 2 * (size_t)B));
-    fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->feat_mm.as<float>());
+    fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);
   }
   {  // every utterance fits the CMVN window (all NES batches): VAD, deltas, CMVN and the row offsets in one launch
     const size_t had = e->vad_pub.cap;

@@ -99,9 +99,8 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
 // counter: one device int, zero before the first launch (the kernel leaves it at zero); row_off[B+1]
 // = exclusive scan of max(tv, 0), written by the workgroup that finishes last
-// Kaldi CompressedMatrix round trip of every utterance's MFCC matrix, in place (mm: 2*B floats of scratch)
-void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B,
-                             float *mm);
+// Kaldi CompressedMatrix round trip of every utterance's MFCC matrix, in place (t_max: longest utterance, frames)
+void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B, int t_max);
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                    int *vrank, int *tv, int *counter, int *row_off);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total

@@ -697,35 +697,47 @@ __device__ __forceinline__ float fb_wave_max_f(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// global header: one workgroup per utterance -> mm[2b] = min, mm[2b+1] = max of its T x nc matrix
-__global__ __launch_bounds__(256) void k_feat_minmax(const float *__restrict__ mfcc, const int *__restrict__ frame_off,
-                                                     int nc, float *__restrict__ mm) {
-  const int b = blockIdx.x;
-  const int base = frame_off[b], T = frame_off[b + 1] - base;
-  const float *m = mfcc + (size_t)base * nc;
-  __shared__ float s_lo[4], s_hi[4];
-  float lo = INFINITY, hi = -INFINITY;
-  for (int i = threadIdx.x; i < T * nc; i += 256) { lo = fminf(lo, m[i]); hi = fmaxf(hi, m[i]); }
-  lo = fb_wave_min_f(lo);
-  hi = fb_wave_max_f(hi);
-  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    mm[2 * b] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
-    mm[2 * b + 1] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-  }
+// workgroup = (utterance, four columns), wave = column.
+//   1. the matrix's global header: minimum and maximum of the whole T x nc matrix, reduced by every workgroup of the
+//      utterance for itself (coalesced, L2-resident; a separate launch for 51 pairs of numbers cost 9 us);
+//   2. the order statistics 0, T/4, 3(T/4), T-1 of the wave's column (what Kaldi's CompressedMatrix takes with
+//      std::nth_element: only their VALUES matter).  The two inner ones by bisection on the order-preserving integer
+//      image of the floats: 32 rounds, each a wave-wide count of the elements below two candidate keys (compare +
+//      ballot + scalar popcount, so the decision is wave-uniform) -- keys in registers for T <= 512, else staged in LDS
+//      (lds_cap per wave), else re-read from global memory every round;
+//   3. every element -> byte -> float, in place.
+// Round 2 ranked every element against every other straight from global memory: T dependent L2 round trips per 64
+// elements, 207 us per NES batch -- the longest kernel of the reference-pipeline mode.
+__device__ __forceinline__ unsigned fb_float_key(float v) {  // a < b  <=>  key(a) < key(b)  (no NaNs; -0 < +0)
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
-// one wave per (utterance, column): order statistics 0, T/4, 3(T/4), T-1 of the column by rank counting (stable
-// ranks are a permutation, so exactly one element has each rank), then every element -> byte -> float, in place
+__device__ __forceinline__ float fb_key_float(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+#define FB_CM_REG 8  // keys per lane held in registers: columns of up to 512 frames
 __global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc, const int *__restrict__ frame_off,
-                                                       int nc, const float *__restrict__ mm) {
-  const int b = blockIdx.x, lane = threadIdx.x & 63;
-  const int c = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (c >= nc) return;
+                                                       int nc, int lds_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_key[];  // [4 waves][lds_cap]
+  __shared__ float s_lo[4], s_hi[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int base = frame_off[b], T = frame_off[b + 1] - base;
   if (T <= 0) return;
+  float minv, maxv;
+  {
+    const float *m = mfcc + (size_t)base * nc;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < T * nc; i += 256) { const float v = m[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    lo = fb_wave_min_f(lo);
+    hi = fb_wave_max_f(hi);
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    __syncthreads();  // also: every wave has read the matrix before any column is rewritten
+    minv = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    maxv = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+  }
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wv);
+  if (c >= nc) return;
   float *col = mfcc + (size_t)base * nc + c;
-  float minv = mm[2 * b], maxv = mm[2 * b + 1];
   if (maxv == minv) maxv = __fadd_rn(minv, __fadd_rn(1.0f, fabsf(minv)));
   const float range = __fsub_rn(maxv, minv);
   if (T <= 8) {  // kTwoByteAuto
@@ -733,43 +745,82 @@ __global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc,
     return;
   }
   const int q = T / 4;
-  float lo = INFINITY, hi = -INFINITY, v25 = 0.0f, v75 = 0.0f;
-  for (int i0 = 0; i0 < T; i0 += 64) {
-    const int i = i0 + lane;
-    const float xi = col[(size_t)min(i, T - 1) * nc];
-    int cnt = 0;
-    for (int j = 0; j < T; ++j) {
-      const float xj = col[(size_t)j * nc];  // wave-uniform address
-      cnt += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+  const bool in_reg = T <= 64 * FB_CM_REG, in_lds = !in_reg && T <= lds_cap;
+  unsigned *sk = s_key + (size_t)wv * lds_cap;
+  unsigned kr[FB_CM_REG];
+  float lo = INFINITY, hi = -INFINITY;
+  if (in_reg) {
+#pragma unroll
+    for (int r = 0; r < FB_CM_REG; ++r) {
+      const int i = 64 * r + lane;
+      const float v = col[(size_t)min(i, T - 1) * nc];
+      kr[r] = i < T ? fb_float_key(v) : 0xffffffffu;  // never below a candidate
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
     }
-    if (i < T) {
-      lo = fminf(lo, xi);
-      hi = fmaxf(hi, xi);
-      if (cnt == q) v25 = xi;
-      if (cnt == 3 * q) v75 = xi;
+  } else {
+    for (int i = lane; i < T; i += 64) {
+      const float v = col[(size_t)i * nc];
+      if (in_lds) sk[i] = fb_float_key(v);
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
     }
-    // the lane that found a rank publishes it to the whole wave
-    const unsigned long long m25 = __ballot(i < T && cnt == q), m75 = __ballot(i < T && cnt == 3 * q);
-    if (m25) v25 = __shfl(v25, __ffsll((long long)m25) - 1, 64);
-    if (m75) v75 = __shfl(v75, __ffsll((long long)m75) - 1, 64);
+    if (in_lds) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
   lo = fb_wave_min_f(lo);
   hi = fb_wave_max_f(hi);
+  // the element of rank r (0-based) is the largest key k with #{x : key(x) < k} <= r
+  unsigned k25 = 0u, k75 = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned c25 = k25 | (1u << bit), c75 = k75 | (1u << bit);
+    int n25 = 0, n75 = 0;
+    if (in_reg) {
+#pragma unroll
+      for (int r = 0; r < FB_CM_REG; ++r) {
+        if (64 * r < T) {  // wave-uniform
+          n25 += __popcll(__ballot(kr[r] < c25));
+          n75 += __popcll(__ballot(kr[r] < c75));
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < T; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned key = in_lds ? sk[min(i, T - 1)] : fb_float_key(col[(size_t)min(i, T - 1) * nc]);
+        n25 += __popcll(__ballot(i < T && key < c25));
+        n75 += __popcll(__ballot(i < T && key < c75));
+      }
+    }
+    if (n25 <= q) k25 = c25;
+    if (n75 <= 3 * q) k75 = c75;
+  }
+  const float v25 = fb_key_float(k25), v75 = fb_key_float(k75);
   const int u0 = min(fb_cm_to_u16(minv, range, lo), 65532);
   const int u25 = min(max(fb_cm_to_u16(minv, range, v25), u0 + 1), 65533);
   const int u75 = min(max(fb_cm_to_u16(minv, range, v75), u25 + 1), 65534);
   const int u100 = max(fb_cm_to_u16(minv, range, hi), u75 + 1);
   const float p0 = fb_cm_from_u16(minv, range, u0), p25 = fb_cm_from_u16(minv, range, u25),
               p75 = fb_cm_from_u16(minv, range, u75), p100 = fb_cm_from_u16(minv, range, u100);
-  for (int i = lane; i < T; i += 64) {
-    float *x = col + (size_t)i * nc;
-    *x = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, *x));
+  if (in_reg) {
+#pragma unroll
+    for (int r = 0; r < FB_CM_REG; ++r) {
+      const int i = 64 * r + lane;
+      if (i < T) col[(size_t)i * nc] = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, fb_key_float(kr[r])));
+    }
+  } else {
+    for (int i = lane; i < T; i += 64) {
+      float *x = col + (size_t)i * nc;
+      *x = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, in_lds ? fb_key_float(sk[i]) : *x));
+    }
   }
 }
-void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B,
-                             float *mm) {
-  hipLaunchKernelGGL(k_feat_minmax, dim3(B), dim3(256), 0, s, mfcc, frame_off, fe.nc, mm);
-  hipLaunchKernelGGL(k_feat_compress, dim3(B, (fe.nc + 3) / 4), dim3(256), 0, s, mfcc, frame_off, fe.nc, mm);
+void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B, int t_max) {
+  const int cap = t_max <= 64 * FB_CM_REG ? 1 : std::min(t_max, 3840);  // keys per wave in LDS (4 x 15 KB: no opt-in needed)
+  hipLaunchKernelGGL(k_feat_compress, dim3(B, (fe.nc + 3) / 4), dim3(256), sizeof(unsigned) * 4 * (size_t)cap, s, mfcc,
+                     frame_off, fe.nc, cap);
 }
 
 // ------------------------------------------------------------------ deltas

@@ -164,7 +164,7 @@ def test_compress_feats_option_is_bit_identical_to_the_oracle_round_trip(oracle)
         ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=72)
         e.load_gmm([ubm] + spk)
         cfg0, cfg1 = oracle.default_cfg(), oracle.default_cfg(compress_feats=1)
-        for utt, n in ((0, 48000), (1, 9000), (2, 1400), (3, 1000), (4, 100000)):   # T = 300, 56, 9, 6 (two-byte), 625
+        for utt, n in ((0, 48000), (1, 9000), (2, 1400), (3, 1000), (4, 100000), (5, 640000)):   # T = 300, 56, 9, 6 (two-byte), 625, 4000 (beyond the LDS-staged column)
             w = _wav(utt, n)
             e.set_frontend(compress_feats=0)
             raw = e.debug_mfcc(w)
