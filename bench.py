@@ -251,7 +251,7 @@ def bench_ivector(args, torch):
     single = None
     solve_ms = None
     if rank == 0:
-        # one attack in flight, same step count: the latency view, and the pass that times k_iv_solve_packed
+        # one attack in flight, same step count: the latency view, and the pass that times k_iv_solve_ll
         # (HIP events around each of its launches on the attack's stream)
         eng.set_fused_chain(True if args.chain == "auto" else fused)
         torch.cuda.synchronize()
@@ -300,11 +300,11 @@ def bench_ivector(args, torch):
             contraction["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
         except Exception:
             pass
-        # k_iv_solve_packed: B Cholesky factorisations + two triangular solves of R x R (R^3/3 + 2 R^2
+        # k_iv_solve_ll: B Cholesky factorisations + two triangular solves of R x R (R^3/3 + 2 R^2
         # flops per utterance) on the float64 matrix cores
         solve_flops = B * (R ** 3 / 3.0 + 2.0 * R * R)
         solve_tf = solve_flops / (solve_ms * 1e-3) / 1e12 if solve_ms else 0.0
-        solve = {"kernel": "k_iv_solve_packed (batched blocked Cholesky + substitutions of the R x R posterior "
+        solve = {"kernel": "k_iv_solve_ll (batched left-looking blocked Cholesky + substitutions of the R x R posterior "
                            "precision, v_mfma_f64_16x16x4)", "bound": "mfma", "achieved": solve_tf,
                  "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": solve_tf / PEAK_F64_MFMA_TFLOPS,
                  "traffic": None, "avg_launch_ms": solve_ms, "algorithmic_flops_per_launch": solve_flops,

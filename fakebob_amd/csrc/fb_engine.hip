@@ -72,7 +72,7 @@ struct fb_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int time_gmm = 0;            // bench: 1 = events around the GMM launch / the T-matrix contraction, 2 = around k_iv_solve_packed
+  int time_gmm = 0;            // bench: 1 = events around the GMM launch / the T-matrix contraction, 2 = around k_iv_solve_ll
   int fuse_opt = -1;           // fb_set_fused_chain: 1 / 0, -1 = the FB_NO_FUSE environment variable decides
   bool gmm_pending = false;
   double gmm_ms_acc = 0.0;
@@ -98,6 +98,7 @@ struct fb_engine {
   int iv_kchunks = 96;
   int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
   int iv_zeroC = -1;  // ... for this component count (position of the zero rows)
+  int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
   // system
   int task = FB_TASK_OSI;
   DevBuf zmean, zstd;
@@ -863,7 +864,15 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     }
     FBCHK(e->iv_linp.ensure(sizeof(double) * (size_t)e->iv_kchunks * B * iv.R));
     FBCHK(e->iv_quad.ensure(sizeof(double) * (size_t)B * iv.triR));
-    FBCHK(e->iv_A.ensure(sizeof(double) * (size_t)B * iv.R));  // the right-hand side row each factorisation carries along
+    {  // the right-hand side row each factorisation carries along, + a row of zeros behind them (k_iv_solve_ll points
+       // the operand rows that do not exist at it)
+      const size_t had = e->iv_A.cap;
+      FBCHK(e->iv_A.ensure(sizeof(double) * ((size_t)B * iv.R + iv.R + 64)));
+      if (e->iv_A.cap != had || e->iv_A_B != B) {
+        HIPCHK(hipMemsetAsync(e->iv_A.p, 0, e->iv_A.cap, s));
+        e->iv_A_B = B;
+      }
+    }
     FBCHK(e->iv_linv.ensure(sizeof(double) * (size_t)B * ((iv.R + 31) / 32) * 1024));
     FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
     FBCHK(e->iv_fail.ensure(sizeof(int)));
@@ -888,8 +897,8 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
     FBCHK(time_begin(e, 2));
-    fb_launch_iv_solve(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
-                       e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    fb_launch_iv_solve_ll(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
+                          e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
     FBCHK(time_end(e, 2));
     FB_DBG_SYNC(e, "solve");
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());

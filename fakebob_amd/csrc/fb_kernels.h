@@ -221,6 +221,8 @@ void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, co
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
                            double *quad);
-void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                        int B, double *Aall, double *LinvAll, double *ivec, int *fail);
+// ivector_solve.hip (k_iv_solve_ll): quad is consumed (factored in place); Aall = B x R right-hand sides + a row of
+// R + 64 zeros behind them
+void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
+                           int B, double *Aall, double *LinvAll, double *ivec, int *fail);
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr);

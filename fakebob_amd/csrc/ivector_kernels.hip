@@ -17,7 +17,7 @@
 //   k_iv_active           list of the components with posterior mass
 //   k_iv_contract_gemm    the T-matrix contraction: lin = sum_k (S_k^-1 M_k)^T F_k, quad = sum_k N_k U_k
 //                         as an LDS-tiled float64-MFMA GEMM over the active rows (of 0.47 GB + 1.3 GB)
-//   k_iv_solve_packed     blocked Cholesky (f64 MFMA, look-ahead) + triangular solves of the B (R x R) systems
+//   k_iv_solve_ll         (ivector_solve.hip) blocked left-looking Cholesky + triangular solves of the B (R x R) systems
 //   k_iv_backend          mean subtraction, LDA, length norm, PLDA transform, LLR vs enrolled
 #include <float.h>
 #include <stdlib.h>
@@ -915,333 +915,7 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
                      iv, gammaT, Bpad, active, n_active, B, 1, quad);
 }
 
-// --------------------------------------------------------- solve (K10c)
-// One workgroup per utterance: A = I + unpack(quad), rhs = sum of lin partials (+ prior offset).
-// Right-looking blocked Cholesky (panel 32) in global scratch (L2 resident).  Everything serial is kept
-// out of LDS-latency chains: the 32x32 diagonal block is factored AND inverted by one wave in registers
-// (fb_chol32_fused: rows in the lower half of the wave, columns of the inverse in the upper half, one instruction
-// stream), and both the panel below (X = A21 L11^-T) and the triangular solves then use that inverse as plain
-// mat-vec / mat-mat products.  ivec = solution with the prior offset removed from component 0.
-#define FB_IV_NB 32
-__device__ __forceinline__ double fb_readlane_f64(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src);
-  hi = __builtin_amdgcn_readlane(hi, src);
-  return __hiloint2double(hi, lo);
-}
-// Cholesky factor AND inverse of a 32 x 32 block by one wave, fused: lanes 0..31 hold the rows of A (lane = row: the
-// factor's right-looking column loop), lanes 32..63 the columns of the identity (lane - 32 = column: the forward
-// substitution L X = I).  Both halves run the SAME instructions: column c is scaled by 1/L[c][c] (= the new column of
-// L below, = row c of L^-1 above), broadcast from the lower half, and subtracted from the later columns -- in the
-// upper half that is exactly the substitution step, so the inverse costs no instruction of its own and 64 registers
-// hold everything (round 1: separate passes, the inverse reading L back from LDS; 49 % of the solve's cycles).
-// The broadcast goes through LDS (one ds_write of the column, then reads of one address by all lanes; bc = 2 x 64
-// doubles, alternating): two v_readlane + wait states per element made every update a 20-cycle affair, and hipcc
-// turned the loop left-looking to save the scalar registers -- c dependent fmas in front of every pivot.  Scheduling
-// regions keep it right-looking: the 31 - c updates of a column are independent, a pivot waits for ONE of them.
-// X: in = A[rr][c] (lower triangle, zeros above; identity rows beyond a short block) / delta(r, rr);
-// out = L[rr][c] / Linv[r][rr].  Returns true on a non-positive pivot.
-// column C of fb_chol32_fused (compile-time recursion: the register array X must never be indexed at run time).
-// l = column C, scaled, already in the broadcast buffer C & 1.  The broadcast values of column C are read into
-// registers; first the next pivot's column is updated, then that pivot's chain -- v_readlane, v_rsq_f64, two Newton steps,
-// the scaling: ten dependent operations, issued in order -- runs with the other 30 - C updates of column C dealt into
-// its nine gaps (one scheduling region each): they are independent of the chain and fill its latency.  (In one piece
-// the chain ran back to back and the updates behind it: ~900 cycles per column, 12 us per block, the longest path of
-// the whole solve.)
-template <int C, int S>
-__device__ __forceinline__ void fb_chol32_gap(double (&X)[FB_IV_NB], const double (&col)[FB_IV_NB], double l) {
-  constexpr int P = FB_IV_NB - 2 - C, Q = (P + 8) / 9;
-#pragma unroll
-  for (int u = 0; u < Q; ++u) {
-    constexpr int base = C + 2 + S * Q;
-    if (base + u < FB_IV_NB) X[base + u] = fma(-l, col[base + u], X[base + u]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <int C>
-__device__ __forceinline__ void fb_chol32_col(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane, double l, bool &bad) {
-  if constexpr (C + 1 < FB_IV_NB) {
-    double col[FB_IV_NB];  // the broadcast values of column C, all requested before the chain starts
-#pragma unroll
-    for (int cc = C + 1; cc < FB_IV_NB; ++cc) col[cc] = bc[(C & 1) * 64 + cc];
-    X[C + 1] = fma(-l, col[C + 1], X[C + 1]);
-    __builtin_amdgcn_sched_barrier(0);
-    const double d = fb_readlane_f64(X[C + 1], C + 1);
-    fb_chol32_gap<C, 0>(X, col, l);
-    bad |= !(d > 0.0);  // off the chain: a non-positive pivot yields NaNs below and is reported
-    double ri = __builtin_amdgcn_rsq(d);  // 1/sqrt(d): v_rsq_f64 + two Newton steps (full double precision)
-    fb_chol32_gap<C, 1>(X, col, l);
-    const double hd = -0.5 * d;           // (independent of the rsq result)
-    double t = hd * ri;
-    fb_chol32_gap<C, 2>(X, col, l);
-    double u1 = fma(t, ri, 1.5);
-    fb_chol32_gap<C, 3>(X, col, l);
-    ri = ri * u1;
-    fb_chol32_gap<C, 4>(X, col, l);
-    t = hd * ri;
-    fb_chol32_gap<C, 5>(X, col, l);
-    u1 = fma(t, ri, 1.5);
-    fb_chol32_gap<C, 6>(X, col, l);
-    ri = ri * u1;
-    fb_chol32_gap<C, 7>(X, col, l);
-    const double l_next = X[C + 1] * ri;  // lower half: L[rr][C+1]; upper half: Linv[C+1][rr]
-    X[C + 1] = l_next;
-    fb_chol32_gap<C, 8>(X, col, l);       // (reads buffer C & 1; the write below goes to the other one)
-    if constexpr (C + 2 < FB_IV_NB) {
-      bc[((C + 1) & 1) * 64 + lane] = l_next;  // all 64 lanes write (the upper half into the buffer's unused half): no branch
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    fb_chol32_col<C + 1>(X, bc, lane, l_next, bad);
-  }
-}
-__device__ __forceinline__ bool fb_chol32_fused(double (&X)[FB_IV_NB], double *__restrict__ bc, int lane) {
-  bool bad = false;
-  const double d = fb_readlane_f64(X[0], 0);
-  bad |= !(d > 0.0);
-  const double dd = d > 0.0 ? d : 1.0;
-  double ri = __builtin_amdgcn_rsq(dd);
-  ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-  ri = ri * fma(-0.5 * dd * ri, ri, 1.5);
-  const double l = X[0] * ri;
-  X[0] = l;
-  bc[lane] = l;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  fb_chol32_col<0>(X, bc, lane, l, bad);
-  return bad;
-}
-// The factorisation runs IN PLACE on the packed lower triangle the contraction produced (a dense copy cost 126 us of
-// unpacking per batch), with the right-hand side carried along as row R of the matrix so that the forward
-// substitution falls out of the panel solves and the trailing updates (another 50 us).  quad is consumed.
-__global__ __launch_bounds__(512) void k_iv_solve_packed(FbIvDev iv, double *__restrict__ quad,
-                                                   const double *__restrict__ linp, int n_kchunks, int B,
-                                                   double *__restrict__ AugAll, double *__restrict__ LinvAll,
-                                                   double *__restrict__ ivec, int *__restrict__ fail) {
-  extern __shared__ __attribute__((aligned(16))) double smd[];
-  constexpr int LD = FB_IV_NB + 1;
-  const int R = iv.R, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-  const int npanel = (R + FB_IV_NB - 1) / FB_IV_NB;
-  double *Q = quad + (size_t)b * iv.triR;
-  double *aug = AugAll + (size_t)b * R;
-  auto rowp = [&](int r) -> double * { return r < R ? Q + ((r * (r + 1)) >> 1) : aug; };  // R <= 2^15: 32-bit offsets
-  double *Lg = LinvAll + (size_t)b * npanel * FB_IV_NB * FB_IV_NB;
-  double *rhs = smd;                  // [R]
-  double *Dg = rhs + ((R + 1) & ~1);  // [NB][LD]  L11
-  double *Di = Dg + FB_IV_NB * LD;    // [NB][LD]  L11^-1
-  constexpr int LDP = FB_IV_NB + 2;   // panel row stride: conflict-free for the MFMA fragment reads
-  double *Lp = Di + FB_IV_NB * LD;    // [R+16][LDP] panel below the diagonal block
-  for (int r = tid; r < R; r += nt) Q[((r * (r + 1)) >> 1) + r] += 1.0;  // A = I + quad
-  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order (thread = component:
-  // coalesced, 8 independent loads in flight)
-  for (int r = tid; r < R; r += nt) {
-    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const double *lp = linp + (size_t)b * R + r;
-    int ch = 0;
-    for (; ch + 8 <= n_kchunks; ch += 8) {
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
-    }
-    for (int sl = 0; ch + sl < n_kchunks; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
-    double acc = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) acc += a8[sl];
-    aug[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
-  }
-  __syncthreads();
-  // Diagonal block (j0, nb) of the current A: Cholesky factor and its inverse, by ONE wave entirely in
-  // registers (fb_chol32_fused).  Leaves L11 in A, L11^-1 in Di and Lg.  Identity beyond nb keeps the
-  // fixed-size code valid for a short last block.
-  auto factor_block = [&](int j0, int nb, int pi) {
-    double X[FB_IV_NB];
-    const int rr = lane & 31;
-    if (lane < FB_IV_NB) {
-      const int rl = min(rr, nb - 1);
-      const double *ar = rowp(j0 + rl) + j0;
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) {
-        const double v = ar[min(c, rl)];  // never past the end of the packed row
-        X[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c) X[c] = (rr == c) ? 1.0 : 0.0;
-    }
-    const bool bad = fb_chol32_fused(X, Dg, lane);
-    if (bad && lane == 0) atomicMax(fail, b + 1);
-    if (lane < FB_IV_NB) {
-#pragma unroll
-      for (int c = 0; c < FB_IV_NB; ++c)
-        if (rr < nb && c <= rr) rowp(j0 + rr)[j0 + c] = X[c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < FB_IV_NB; ++r) {
-        Di[r * LD + rr] = X[r];
-        Lg[((size_t)pi * FB_IV_NB + r) * FB_IV_NB + rr] = X[r];
-      }
-    }
-  };
-  // Right-looking blocked Cholesky with look-ahead: while the other waves apply panel j to the trailing
-  // matrix, wave 0 first updates the three 16x16 tiles of the NEXT diagonal block, then factors and
-  // inverts it -- the serial part runs in the shadow of the update.
-  if (wv == 0) factor_block(0, min(FB_IV_NB, R), 0);
-  __syncthreads();
-  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_IV_NB, ++pi) {
-    const int nb = min(FB_IV_NB, R - j0);
-    // (b) panel below: X = A21 * L11^-T on the float64 matrix cores.  Wave = 16 rows: A fragment straight
-    //     from global A (lane l: row l % 16, column 4 q + l / 16), B fragment = L11^-1 from LDS (explicit
-    //     zeros above its diagonal), 2 column tiles x 8 steps.  Rows past the end contribute zeros, so the
-    //     panel copy in LDS is padded to a multiple of 16 rows for the update below.
-    const int m = R - j0 - nb;      // real rows / columns behind the panel
-    const int ma = m + 1;           // ... plus the right-hand-side row
-    const int mt16 = (ma + 15) / 16;
-    for (int tI = wv; tI < mt16; tI += nw) {
-      const int i0 = 16 * tI;
-      const int ri = i0 + (lane & 15);
-      const bool rok = ri < ma;
-      const double *arow = rowp(j0 + nb + (rok ? ri : 0)) + j0 + (lane >> 4);
-      fb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
-      double av[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {  // (unconditional load on a clamped address, then masked)
-        const int kk = 4 * q + (lane >> 4);
-        const double v = arow[kk < nb ? 4 * q : 0];
-        av[q] = (rok && kk < nb) ? v : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int kk = 4 * q + (lane >> 4);
-        const double b0v = Di[(lane & 15) * LD + kk], b1v = Di[(16 + (lane & 15)) * LD + kk];
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b0v, x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b1v, x1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr2 = i0 + (lane >> 4) + 4 * i, cc = lane & 15;
-        Lp[rr2 * LDP + cc] = x0[i];
-        Lp[rr2 * LDP + 16 + cc] = x1[i];
-        if (rr2 < ma) {
-          double *ao = rowp(j0 + nb + rr2) + j0;
-          if (cc < nb) ao[cc] = x0[i];
-          if (16 + cc < nb) ao[16 + cc] = x1[i];
-        }
-      }
-    }
-    __syncthreads();
-    // (c) trailing update A22 -= L21 L21^T (lower triangle) in 16x16 tiles, 8 MFMAs each, both operands
-    //     from the LDS panel; the 4 results of a lane are 4 rows of one column, so 16 lanes write 128
-    //     contiguous bytes.  (Diagonal tiles also touch the strict upper triangle of A, which nothing reads.)
-    // NT tiles of one tile row at a time: their old values (global A, L2 latency) and column fragments
-    // are all requested before the first MFMA, the row fragment is loaded once.
-    auto update_tiles = [&](int tr, int tc0, int ntc) {  // tiles (tr, tc0 .. tc0 + ntc - 1), ntc <= 4
-      constexpr int NT = 4;
-      const double *lr = Lp + (size_t)(16 * tr + (lane & 15)) * LDP + (lane >> 4);
-      double af[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) af[q] = lr[4 * q];
-      double *cp[NT][4];
-      double cv[NT][4];
-      bool ok[NT][4];
-      double bf[NT][8];
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const int tc = tc0 + min(u, ntc - 1);
-        const int cc2 = 16 * tc + (lane & 15);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int rr2 = 16 * tr + (lane >> 4) + 4 * x;
-          ok[u][x] = u < ntc && rr2 < ma && cc2 < m && cc2 <= rr2;  // packed storage: the lower triangle only
-          cp[u][x] = rowp(j0 + nb + (ok[u][x] ? rr2 : 0)) + j0 + nb + (ok[u][x] ? cc2 : 0);
-          cv[u][x] = *cp[u][x];
-        }
-        const double *lc = Lp + (size_t)(16 * tc + (lane & 15)) * LDP + (lane >> 4);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bf[u][q] = lc[4 * q];
-      }
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        fb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[u][q], acc, 0, 0, 0);
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-          if (ok[u][x]) *cp[u][x] = cv[u][x] - acc[x];
-      }
-    };
-    if (wv == 0) {
-      if (m > 0) {  // tiles (0,0), (1,0), (1,1) = the next diagonal block, then its factorisation
-        update_tiles(0, 0, 1);
-        if (mt16 > 1) update_tiles(1, 0, 2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the factor reads what other lanes just stored
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        factor_block(j0 + nb, min(FB_IV_NB, m), pi + 1);
-      }
-    } else {
-      // work items = (tile row tr >= 2, group of 4 column tiles); rows are dealt out longest first
-      int item = 0;
-      for (int tr = mt16 - 1; tr >= 2; --tr)
-        for (int tc0 = 0; tc0 <= tr; tc0 += 4, ++item)
-          if (item % (nw - 1) == wv - 1) update_tiles(tr, tc0, min(4, tr + 1 - tc0));
-    }
-    __syncthreads();
-  }
-  // ---- the augmented row now holds y = L^-1 rhs; L^T x = y panel by panel with the stored panel inverses
-  for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
-  __syncthreads();
-  for (int pi = npanel - 1; pi >= 0; --pi) {
-    const int j0 = pi * FB_IV_NB, nb = min(FB_IV_NB, R - j0);
-    // the panel inverse through LDS (one coalesced pass) instead of 32 dependent global loads per lane
-    for (int idx = tid; idx < FB_IV_NB * FB_IV_NB; idx += nt)
-      Di[(idx >> 5) * LD + (idx & 31)] = Lg[(size_t)pi * FB_IV_NB * FB_IV_NB + idx];
-    __syncthreads();
-    if (tid < FB_IV_NB) {  // x = L11^-T y
-      double x = 0.0;
-#pragma unroll
-      for (int q = 0; q < FB_IV_NB; ++q) {
-        const double t = Di[q * LD + tid] * rhs[j0 + min(q, nb - 1)];
-        x += (q >= tid && q < nb) ? t : 0.0;
-      }
-      Dg[tid] = x;
-    }
-    __syncthreads();
-    if (tid < nb) rhs[j0 + tid] = Dg[tid];
-    // rows above: rhs[i] -= sum_q L[j0+q][i] x[q]  (x from Dg; all 32 loads of a thread are in flight together)
-    for (int i = tid; i < j0; i += nt) {
-      const double *lrow = rowp(j0) + i;
-      double lv[FB_IV_NB];
-#pragma unroll
-      for (int q = 0; q < FB_IV_NB; ++q) {
-        lv[q] = q < nb ? *lrow : 0.0;
-        if (q < nb) lrow += j0 + q + 1;  // next packed row
-      }
-      double v = rhs[i];
-#pragma unroll
-      for (int q = 0; q < FB_IV_NB; ++q) v = fma(-lv[q], Dg[q], v);
-      rhs[i] = v;
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
-}
-
-void fb_launch_iv_solve(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                        int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
-  const int R = iv.R;
-  const size_t panel = (size_t)(R + 17) * (FB_IV_NB + 2);  // Lp (incl. the right-hand-side row) / rhs partials
-  size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_IV_NB * (FB_IV_NB + 1) + std::max(panel, (size_t)8 * R));
-  static std::atomic<unsigned long long> optin{0};
-  unsigned long long bit = 0;
-  if (fb_device_needs_optin(optin, &bit)) {  // > 64 KiB of dynamic LDS needs the opt-in, once per device
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_packed), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    if (ok) optin.fetch_or(bit, std::memory_order_release);  // a failed opt-in surfaces as a launch error (hipGetLastError in run_scoring)
-  }
-  hipLaunchKernelGGL(k_iv_solve_packed, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
-                     LinvAll, ivec, fail);
-}
+// (K10c, the posterior systems: ivector_solve.hip)
 
 // ------------------------------------------------------ back-end (K11/K12)
 __device__ __forceinline__ double fb_block_sum(double v, double *red) {

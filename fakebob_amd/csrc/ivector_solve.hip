@@ -1,0 +1,424 @@
+// ivector_solve.hip -- K10c: the B posterior systems (I + sum_k N_k U_k) w = lin of the i-vector extractor
+// (`quadratic.Invert()` + mat-vec of IvectorExtractor::GetIvectorDistribution, [EXT] SURVEY.md A.9; the reference
+// reaches it through `ivector-extract`, ivector_PLDA_kaldiHelper.py:202-204).
+//
+// k_iv_solve_ll: one workgroup (8 waves) per utterance, blocked LEFT-looking Cholesky in place on the packed lower
+// triangle the contraction wrote, the right-hand side carried along as row R (the forward substitution falls out of
+// the panel solves), then a blocked back substitution.
+//
+// Why left-looking (round 3).  The round-2 kernel was right-looking: every panel read, modified and wrote the whole
+// trailing matrix through L2 (10.7 MB of scattered read-modify-write per utterance; 31 us per panel of which the
+// matrix cores worked 6) and its 400 x 400 doubles fit neither LDS nor the register file.  Here a panel (32 columns,
+// all rows below) is touched ONCE: its tiles are accumulators in registers, S = sum over ALL finished panels q of
+// L[rows, q] L[pivot rows, q]^T streamed from the rows written earlier (each lane reads 64 contiguous bytes per row and
+// panel: the K index of the MFMA is permuted so that a lane's eight k values are adjacent), then A - S, the diagonal
+// block's factorisation, the panel solve against its inverse, one store.  Reads 2.7 MB per utterance, writes 0.64 MB.
+//
+// The diagonal block (32 x 32) is factored AND inverted by one wave in registers as before (lanes 0..31 = rows of A,
+// lanes 32..63 = columns of the identity, same instructions), but the critical path no longer goes through LDS:
+// the ONE column the next pivot needs is updated with the multiplier taken by v_readlane from the column just
+// scaled; all other columns get that update one pivot later from the LDS broadcast, dealt into the gaps of the next
+// pivot's rsq / Newton chain.  13 serial blocks of 32 pivots are the kernel's critical path, so the pivot step is
+// what the kernel's time is made of.
+#include <float.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "fb_device.h"
+#include "fb_kernels.h"
+
+typedef double fb_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64
+typedef double fb_d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load from an 8-byte aligned packed row
+
+#define FB_SV_NB 32   // panel width
+// NTR (template parameter of the kernel): 16-row tiles of a panel per wave; waves 1 .. 7 hold them (wave 0 factors):
+// 7 x 16 NTR rows >= R + 1, i.e. NTR = 4 up to R = 447 (the recipe's 400), 5 up to R = 512
+#define FB_SV_LD 33   // LDS row stride of the 32 x 32 blocks
+#define FB_SV_LDC 34  // ... of the per-wave 16 x 32 layout-conversion tile
+
+__device__ __forceinline__ double fb_sv_readlane(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+// One slice of the deferred updates of column C's iteration: X[cc] -= lprev * col[cc] for a share of cc = C+1 .. 31
+// (lprev = the PREVIOUS pivot's scaled column, col = its LDS broadcast), one scheduling region.
+template <int C, int S>
+__device__ __forceinline__ void fb_sv_gap(double (&X)[FB_SV_NB], const double (&col)[FB_SV_NB], double lprev) {
+  if constexpr (C >= 1) {
+    constexpr int P = FB_SV_NB - 1 - C, Q = (P + 8) / 9;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      constexpr int base = C + 1 + S * Q;
+      if (base + u < FB_SV_NB) X[base + u] = fma(-lprev, col[base + u], X[base + u]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// Pivot C.  On entry X[C] carries every earlier pivot; the columns behind it lack pivot C-1's update, whose scaled
+// column lprev every lane finds in the broadcast buffer bc[(C-1) & 1].
+template <int C>
+__device__ __forceinline__ void fb_sv_col(double (&X)[FB_SV_NB], double *__restrict__ bc, int lane, double lprev, bool &bad) {
+  double col[FB_SV_NB];
+  if constexpr (C >= 1) {
+#pragma unroll
+    for (int cc = C + 1; cc < FB_SV_NB; ++cc) col[cc] = bc[((C - 1) & 1) * 64 + cc];
+  }
+  const double d = fb_sv_readlane(X[C], C);
+  fb_sv_gap<C, 0>(X, col, lprev);   // (the first slice holds column C + 1, which the readlane step below continues)
+  bad |= !(d > 0.0);                // off the chain: a non-positive pivot yields NaNs below and is reported
+  double ri = __builtin_amdgcn_rsq(d);  // 1/sqrt(d): v_rsq_f64 + two Newton steps (full double precision)
+  fb_sv_gap<C, 1>(X, col, lprev);
+  const double hd = -0.5 * d;
+  double t = hd * ri;
+  fb_sv_gap<C, 2>(X, col, lprev);
+  double u1 = fma(t, ri, 1.5);
+  fb_sv_gap<C, 3>(X, col, lprev);
+  ri = ri * u1;
+  fb_sv_gap<C, 4>(X, col, lprev);
+  t = hd * ri;
+  fb_sv_gap<C, 5>(X, col, lprev);
+  u1 = fma(t, ri, 1.5);
+  fb_sv_gap<C, 6>(X, col, lprev);
+  ri = ri * u1;
+  fb_sv_gap<C, 7>(X, col, lprev);
+  const double l = X[C] * ri;       // lower half: L[rr][C]; upper half: Linv[C][rr]
+  X[C] = l;
+  fb_sv_gap<C, 8>(X, col, lprev);
+  if constexpr (C + 1 < FB_SV_NB) {
+    if constexpr (C + 2 < FB_SV_NB) {
+      bc[(C & 1) * 64 + lane] = l;  // for the columns behind C + 1, one pivot later; a wave's LDS accesses stay in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const double lc1 = fb_sv_readlane(l, C + 1);  // L[C+1][C]: the only multiplier the next pivot waits for
+    X[C + 1] = fma(-l, lc1, X[C + 1]);
+    fb_sv_col<C + 1>(X, bc, lane, l, bad);
+  }
+}
+// X: in = A[rr][c] (lower triangle, zeros above; identity rows beyond a short block) in lanes 0..31, delta(r, rr) in
+// lanes 32..63; out = L[rr][c] / Linv[r][rr].  bc: 128 doubles of LDS.  Returns true on a non-positive pivot.
+__device__ __forceinline__ bool fb_sv_chol32(double (&X)[FB_SV_NB], double *__restrict__ bc, int lane) {
+  bool bad = false;
+  fb_sv_col<0>(X, bc, lane, 0.0, bad);
+  return bad;
+}
+
+// S[t] += L[rows of tile t, panel q] L[pivot rows, panel q]^T for q = 0 .. np-1: tiles t < NT of a wave.  pa / pb point at
+// this lane's eight k values of panel 0 in its operand rows -- or into a row of zeros where the lane's row does not
+// exist, so that nothing is masked after a load and the loop body has no branches.  The k values of a lane are adjacent
+// (8 l4 .. 8 l4 + 7 within the panel: any assignment of k to the MFMA's K slots is a valid sum as long as both operands
+// use the same one): 64 contiguous bytes per lane, row and panel.
+// PIPE: the operands of panel q + 1 are requested before panel q is multiplied (two static register sets, two panels per
+// trip, the last request repeated rather than branched around) -- for the late panels, whose few tiles per wave make
+// one L2 round trip per panel longer than the panel's MFMAs.
+template <int NTR, int NT, bool PIPE>
+__device__ __forceinline__ void fb_sv_accumulate(fb_d4 (&S)[NTR][2], const double *const (&pa)[NTR],
+                                                 const double *pb0, const double *pb1, int np) {
+  auto load8 = [](const double *p, double (&f)[8]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const fb_d2u v = *reinterpret_cast<const fb_d2u *>(p + 2 * h);
+      f[2 * h] = v[0];
+      f[2 * h + 1] = v[1];
+    }
+  };
+  auto mma = [&](int t, const double (&af)[8], const double (&b0)[8], const double (&b1)[8]) {
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      S[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s8], b0[s8], S[t][0], 0, 0, 0);
+      S[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s8], b1[s8], S[t][1], 0, 0, 0);
+    }
+  };
+  if constexpr (PIPE) {
+    double a0[NT][8], a1[NT][8], b00[8], b01[8], b10[8], b11[8];
+    load8(pb0, b00);
+    load8(pb1, b01);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load8(pa[t], a0[t]);
+    for (int q = 0; q < np; q += 2) {
+      const int k1 = FB_SV_NB * min(q + 1, np - 1), k2 = FB_SV_NB * min(q + 2, np - 1);
+      load8(pb0 + k1, b10);
+      load8(pb1 + k1, b11);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load8(pa[t] + k1, a1[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) mma(t, a0[t], b00, b01);
+      if (q + 1 < np) {
+        load8(pb0 + k2, b00);
+        load8(pb1 + k2, b01);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load8(pa[t] + k2, a0[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mma(t, a1[t], b10, b11);
+      }
+    }
+  } else {
+    for (int q = 0; q < np; ++q) {
+      const int k0 = FB_SV_NB * q;
+      double b0[8], b1[8], af[NT][8];
+      load8(pb0 + k0, b0);
+      load8(pb1 + k0, b1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load8(pa[t] + k0, af[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) mma(t, af[t], b0, b1);
+    }
+  }
+}
+
+template <int NTR>
+__global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restrict__ quad, const double *__restrict__ linp,
+                                                     int n_kchunks, int B, double *__restrict__ AugAll,
+                                                     double *__restrict__ LinvAll, double *__restrict__ ivec,
+                                                     int *__restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  const int R = iv.R, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // tile row tr of a panel belongs to wave 1 + tr % 7 (its tile number tr / 7); wave 0 keeps its registers for the
+  // factorisation
+  const int tw = wv - 1;
+  auto tile_row = [&](int t) { return wv == 0 ? 0x7fff : tw + 7 * t; };
+  const int npanel = (R + FB_SV_NB - 1) / FB_SV_NB;
+  double *Q = quad + (size_t)b * iv.triR;
+  double *aug = AugAll + (size_t)b * R;
+  // Rows of the matrix (packed), the right-hand side as row R, and a row of zeros (R + 64 of them behind the
+  // right-hand sides, kept by the engine) for the lanes whose row or element does not exist: all as element offsets
+  // from Q, chosen with integer selects -- nothing is masked after a load and the loops have no divergent branches.
+  const long long aug_off = (long long)(aug - Q), zero_off = (long long)((AugAll + (size_t)B * R) - Q);
+  auto roff = [&](int r) -> long long { return r < R ? (long long)((r * (r + 1)) >> 1) : aug_off; };  // R <= 2^15
+  auto rowp = [&](int r) -> double * { return Q + roff(r); };
+  double *Lg = LinvAll + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
+  double *rhs = smd;                          // [R]
+  double *Dg = rhs + ((R + 1) & ~1);          // [32][33] the diagonal block on its way to wave 0; later scratch
+  double *Di = Dg + FB_SV_NB * FB_SV_LD;      // [32][33] its inverse
+  double *bc = Di + FB_SV_NB * FB_SV_LD;      // [128] column broadcast of the factorisation
+  double *cvt = bc + 128;                     // [8 waves][16][34] accumulator layout -> A-operand layout
+  double *red = cvt + 8 * 16 * FB_SV_LDC;     // [16][33] partial sums of the back substitution
+  for (int r = tid; r < R; r += nt) Q[((r * (r + 1)) >> 1) + r] += 1.0;  // A = I + quad
+  // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order (thread = component:
+  // coalesced, 8 independent loads in flight)
+  for (int r = tid; r < R; r += nt) {
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double *lp = linp + (size_t)b * R + r;
+    int ch = 0;
+    for (; ch + 8 <= n_kchunks; ch += 8) {
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
+    }
+    for (int sl = 0; ch + sl < n_kchunks; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
+    double acc = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) acc += a8[sl];
+    aug[r] = acc + (r == 0 ? iv.prior_offset : 0.0);
+  }
+  __syncthreads();
+
+  for (int j0 = 0, pi = 0; j0 < R; j0 += FB_SV_NB, ++pi) {
+    const int nb = min(FB_SV_NB, R - j0);
+    const int ntr = (R + 1 - j0 + 15) >> 4;  // 16-row tiles of the panel: the diagonal block, the rows below, the rhs row
+    // ---- phase 1: S = sum over the finished panels q of L[rows, q] L[pivot rows, q]^T - A, tiles in registers.  The
+    //      accumulators START from -A (element i of a lane = row 4 i + l4, column l15 of the tile): those loads are in
+    //      flight together with the first operands instead of costing their own L2 round trip afterwards.
+    fb_d4 S[NTR][2];
+    int nt_w = 0;  // valid tiles of this wave (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      const int tr = tile_row(t);
+      if (tr < ntr) nt_w = t + 1;
+      double av[2][4];
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = j0 + 16 * tr + l4 + 4 * i, cc = j0 + 16 * tc + l15;
+          const bool ok = tr < ntr && rr <= R && cc < j0 + nb && cc <= rr;
+          av[tc][i] = Q[ok ? roff(rr) + cc : zero_off];
+        }
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S[t][tc][i] = -av[tc][i];
+    }
+    nt_w = __builtin_amdgcn_readfirstlane(nt_w);
+    if (pi > 0 && nt_w > 0) {
+      // pivot rows of this lane's B fragments (column tiles 0 / 1): rows j0 + l15, j0 + 16 + l15 of the matrix proper
+      const double *pb0 = Q + (l15 < nb ? roff(j0 + l15) : zero_off) + 8 * l4,
+                   *pb1 = Q + (16 + l15 < nb ? roff(j0 + 16 + l15) : zero_off) + 8 * l4;
+      const double *pa[NTR];
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        const int ra = j0 + 16 * tile_row(t) + l15;
+        pa[t] = Q + ((tile_row(t) < ntr && ra <= R) ? roff(ra) : zero_off) + 8 * l4;
+      }
+      switch (nt_w) {
+        case 1: fb_sv_accumulate<NTR, 1, true>(S, pa, pb0, pb1, pi); break;
+        case 2: fb_sv_accumulate<NTR, 2, true>(S, pa, pb0, pb1, pi); break;
+        case 3: fb_sv_accumulate<NTR, 3, false>(S, pa, pb0, pb1, pi); break;
+        case 4: fb_sv_accumulate<NTR, 4, false>(S, pa, pb0, pb1, pi); break;
+        default: fb_sv_accumulate<NTR, NTR, false>(S, pa, pb0, pb1, pi); break;
+      }
+    }
+    // ---- A - S: the sign; a diagonal tile's upper part saw real operands and is zeroed here
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      const int tr = tile_row(t);
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = j0 + 16 * tr + l4 + 4 * i, cc = j0 + 16 * tc + l15;
+          const bool ok = tr < ntr && rr <= R && cc < j0 + nb && cc <= rr;
+          S[t][tc][i] = ok ? -S[t][tc][i] : 0.0;
+        }
+    }
+    if (wv == 1 || wv == 2) {  // tile rows 0 and 1 are the diagonal block (tile 0 of waves 1 and 2): to LDS for the factorisation
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Dg[(16 * tw + l4 + 4 * i) * FB_SV_LD + 16 * tc + l15] = S[0][tc][i];
+    }
+    __syncthreads();
+    // ---- phase 2: wave 0 factors the block and inverts the factor (registers only); L11 -> A, L11^-1 -> Di, Lg
+    if (wv == 0) {
+      double X[FB_SV_NB];
+      const int rr = lane & 31;
+      if (lane < FB_SV_NB) {
+#pragma unroll
+        for (int c = 0; c < FB_SV_NB; ++c) {
+          const double v = Dg[rr * FB_SV_LD + c];
+          X[c] = (rr < nb && c < nb) ? (c <= rr ? v : 0.0) : (rr == c ? 1.0 : 0.0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < FB_SV_NB; ++c) X[c] = (rr == c) ? 1.0 : 0.0;
+      }
+      const bool bad = fb_sv_chol32(X, bc, lane);
+      if (bad && lane == 0) atomicMax(fail, b + 1);
+      if (lane < FB_SV_NB) {
+#pragma unroll
+        for (int c = 0; c < FB_SV_NB; ++c)
+          if (rr < nb && c <= rr) Q[roff(j0 + rr) + j0 + c] = X[c];
+      } else {
+#pragma unroll
+        for (int r = 0; r < FB_SV_NB; ++r) {
+          Di[r * FB_SV_LD + rr] = X[r];
+          Lg[((size_t)pi * FB_SV_NB + r) * FB_SV_NB + rr] = X[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: the rows below, X = (A - S) L11^-T on the matrix cores; the tile changes from the accumulator layout
+    //      to the A-operand layout through a per-wave LDS tile; one store per element of the panel
+    {
+      double *cw = cvt + (size_t)wv * 16 * FB_SV_LDC;
+      double b0[8], b1[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {  // B fragments: Linv[column][k], k = 4 s + l4 (zeros above the diagonal are stored)
+        b0[s8] = Di[l15 * FB_SV_LD + 4 * s8 + l4];
+        b1[s8] = Di[(16 + l15) * FB_SV_LD + 4 * s8 + l4];
+      }
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        const int tr = tile_row(t);
+        // rows behind the diagonal block: tiles 2 .. when the block is full; a short last block (nb < 32) has only the
+        // rhs row behind it, in tile nb / 16, next to block rows that are masked at the store
+        if (tr >= (nb >> 4) && tr < ntr) {  // wave-uniform
+#pragma unroll
+          for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cw[(l4 + 4 * i) * FB_SV_LDC + 16 * tc + l15] = S[t][tc][i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          fb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            const double av = cw[l15 * FB_SV_LDC + 4 * s8 + l4];
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0[s8], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1[s8], x1, 0, 0, 0);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // the tile is read before the next one overwrites it
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = j0 + 16 * tr + l4 + 4 * i;
+            if (rr <= R && rr >= j0 + nb) {
+              double *ao = Q + roff(rr) + j0;
+              if (l15 < nb) ao[l15] = x0[i];
+              if (16 + l15 < nb) ao[16 + l15] = x1[i];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the panel is in memory before the next one streams it
+  }
+  // ---- the augmented row now holds y = L^-1 rhs; L^T x = y block by block from the end: for block p
+  //      x_p = L_pp^-T (y_p - sum over the rows k below of L[k][p columns] x_k), every row of L read once, 256
+  //      contiguous bytes at a time (thread = (row group of 16, column))
+  for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
+  __syncthreads();
+  for (int pi = npanel - 1; pi >= 0; --pi) {
+    const int j0 = pi * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
+    const int g = tid >> 5, c = tid & 31;
+    double acc = 0.0;
+    if (c < nb) {  // eight rows of this thread's group in flight at a time
+      for (int k = j0 + nb + g; k < R; k += 128) {
+        double lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lv[u] = rowp(min(k + 16 * u, R - 1))[j0 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(k + 16 * u < R ? lv[u] : 0.0, rhs[min(k + 16 * u, R - 1)], acc);
+      }
+    }
+    red[g * FB_SV_LD + c] = acc;
+    for (int idx = tid; idx < FB_SV_NB * FB_SV_NB; idx += nt)
+      Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = Lg[(size_t)pi * FB_SV_NB * FB_SV_NB + idx];
+    __syncthreads();
+    if (tid < FB_SV_NB) {
+      double s = 0.0;
+#pragma unroll
+      for (int gg = 0; gg < 16; ++gg) s += red[gg * FB_SV_LD + tid];
+      Dg[tid] = tid < nb ? rhs[j0 + tid] - s : 0.0;
+    }
+    __syncthreads();
+    if (tid < FB_SV_NB) {  // x = L11^-T t
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < FB_SV_NB; ++q) {
+        const double t = Di[q * FB_SV_LD + tid] * Dg[q];
+        x += (q >= tid && q < nb) ? t : 0.0;
+      }
+      if (tid < nb) rhs[j0 + tid] = x;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
+}
+
+template <int NTR>
+static void launch_solve_ll(hipStream_t s, size_t shm, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
+                            int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (shm > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_ll<NTR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+      optin.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(k_iv_solve_ll<NTR>, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
+                     LinvAll, ivec, fail);
+}
+void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
+                           int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
+  const int R = iv.R;
+  const size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_SV_NB * FB_SV_LD + 128 + 8 * 16 * FB_SV_LDC + 16 * FB_SV_LD);
+  if (R + 1 <= 7 * 16 * 4) launch_solve_ll<4>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
+  else launch_solve_ll<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
+}

@@ -47,7 +47,7 @@ int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64_t *rows);
 /* run `iters` NES iterations (get_grad + update, early stop disabled) on the
  * device without host round trips; returns elapsed ms (HIP events) and the
  * accumulated time of the GMM kernel alone (events around each launch when
- * time_gmm = 1; time_gmm = 2 with an i-vector system: around k_iv_solve_packed instead of the T-matrix contraction).  warmup < 0: continue the attack the previous call left on the
+ * time_gmm = 1; time_gmm = 2 with an i-vector system: around k_iv_solve_ll instead of the T-matrix contraction).  warmup < 0: continue the attack the previous call left on the
  * device -- nothing is uploaded or reset, `audio` is ignored (the timed region of
  * bench.py starts with its inputs resident in HBM). */
 int fb_bench_nes(fb_engine *e, const fb_nes_params *p, const double *audio,
