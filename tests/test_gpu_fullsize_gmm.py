@@ -36,7 +36,7 @@ def test_config1_get_grad_and_attack_at_full_size(oracle, full_system, monkeypat
     (FAKEBOB.py:202): of 48 000 entries a dozen lie within that 1e-3 of zero, so ANY two float32 evaluations of the
     GMM (this kernel with 2 or 3 products, Kaldi's sgemv order, the oracle's float64 sums) step those samples in
     opposite directions, and the iteration amplifies it -- 12 samples after one update, ~500 after two, a quarter
-    after five, measured identically for delta_p = 2 and for the round-2 arithmetic (delta_p = 3).  Asserted here:
+    after five, measured identically for delta_p = 1, 2 and for the round-2 arithmetic (delta_p = 3).  Asserted here:
     the first iteration to score tolerance, sign flips only where the gradient is indistinguishable from zero, the
     same success flag and row count, later rows at the 1e-2 level, the perturbation inside the same epsilon ball.
     (Bit-identical trajectories are asserted where they are attainable: the 1 s / spd = 10 cases of
@@ -47,7 +47,7 @@ def test_config1_get_grad_and_attack_at_full_size(oracle, full_system, monkeypat
         monkeypatch.delenv("FB_GMM_DELTA_P", raising=False)
     e, ctx = _pair(oracle, full_system, {})
     try:
-        assert e.gmm_kernel_variant == "fx2w/%s" % (delta_p or "2")      # "fx2w/2": the kernel bench.py times
+        assert e.gmm_kernel_variant == "fx2w/%s" % (delta_p or "1")      # "fx2w/1": the kernel bench.py times
         audio = synthetic_audio(0, 48000)
         pg = nes_params("OSI", "targeted", seed=42, stream=0, max_iter=1000, **KW)
         po = oracle.nes_params("OSI", "targeted", ctx.S, max_iter=1000, **KW)

@@ -38,7 +38,7 @@ def test_engines_on_two_devices_in_one_process(full_system):
         e = Engine(dev)
         try:
             e.load_gmm([ubm] + spk)
-            assert e.gmm_kernel_variant == "fx2w/2"      # > 64 KB of dynamic LDS: needs the opt-in on each device
+            assert e.gmm_kernel_variant == "fx2w/1"      # > 64 KB of dynamic LDS: needs the opt-in on each device
             raws.append(e.score_raw(wavs)[0])
         finally:
             e.close()

@@ -71,7 +71,7 @@ def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
     two-term f16 split (k_gmm_fx2, FB_GMM_NARROW=1), the 6 partial products of an EXACT three-term bf16 split
     (k_gmm_bx3, FB_GMM_MODE=bx3), or -- the default, k_gmm_fx2w -- the base model with the 3 partial products and the
     speaker models as DELTAS from it with P = 1 .. 3 partial products (fb_load_gmm picks P from how far the models
-    were adapted: 2 for the synthetic speakers of SURVEY.md 8(d); FB_GMM_DELTA_P forces it).  Against the
+    were adapted: 1 for the synthetic speakers of SURVEY.md 8(d); FB_GMM_DELTA_P forces it).  Against the
     float64-accumulating oracle all of them must stay within float32 rounding of the ~-150 results (ulp 1.5e-5), and
     the default must be as close as the exact split -- i.e. no precision is given up."""
     from fakebob_amd.engine import Engine
@@ -81,7 +81,7 @@ def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
     gc, miv, iv = stack_models([ubm] + spk)
     raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
     errs, raws, sys_errs = {}, {}, {}
-    variants = (("fx2w", {}, "fx2w/2"), ("fx2w/1", {"FB_GMM_DELTA_P": "1"}, "fx2w/1"),
+    variants = (("fx2w", {}, "fx2w/1"), ("fx2w/2", {"FB_GMM_DELTA_P": "2"}, "fx2w/2"),
                 ("fx2w/3", {"FB_GMM_DELTA_P": "3"}, "fx2w/3"), ("fx2", {"FB_GMM_NARROW": "1"}, "fx2"),
                 ("bx3", {"FB_GMM_MODE": "bx3"}, "bx3"))
     for name, env, variant in variants:
@@ -102,7 +102,7 @@ def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
         sys_errs[name] = float(np.abs((raws[name][:, 1:] - raws[name][:, :1]) - (raw_o[:, 1:] - raw_o[:, :1])).max())
     print("max |err| vs float64 oracle: raw", errs, "speaker - UBM", sys_errs)
     assert max(errs.values()) <= 2e-5, errs
-    for name in ("fx2w", "fx2w/3", "fx2"):
+    for name in ("fx2w", "fx2w/2", "fx2w/3", "fx2"):
         assert errs[name] <= 2.0 * errs["bx3"] + 2e-6, errs
         assert sys_errs[name] <= 2.0 * sys_errs["bx3"] + 2e-6, sys_errs
     assert len({raws[n].tobytes() for n in raws}) == len(raws)  # five different kernels really ran
@@ -134,7 +134,7 @@ def test_far_adapted_models_keep_three_products(oracle, monkeypatch):
             e.load_gmm([ubm] + spk)
             if name == "auto":
                 assert e.gmm_kernel_variant == "fx2w/3", (e.gmm_kernel_variant, e.gmm_shift_rms)
-                assert e.gmm_shift_rms > 6e-5
+                assert e.gmm_shift_rms > 8.6e-5
             raw, _ = e.score_raw(wavs)
         finally:
             e.close()
