@@ -481,9 +481,9 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
   }
 }
 // k_gmm_fx2w is instantiated for the shapes the reference's systems have with the recipe's 72-dimensional features
-// (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models (SV: UBM + 1; OSI: UBM +
-// speakers; CSI: the speakers).  Everything else runs on k_gmm_fx2.
-#define FB_FXW_MAX_M 6
+// (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models (SV: UBM + 1; OSI: UBM + up
+// to 9 speakers; CSI: up to 10 speakers).  Everything else runs on k_gmm_fx2.
+#define FB_FXW_MAX_M 10  // (1 + M) 10 KB items + the state of 2 M x 256 frames: 156 KB of LDS at M = 10
 bool fb_gmm_use_wide(const FbGmmDev &g) {
   const bool off = getenv("FB_GMM_NARROW") != nullptr;  // read per call: the tests switch it inside one process
   return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
@@ -497,6 +497,10 @@ void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, co
     case 4: launch_gmm_fxw_t<5, 4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     case 5: launch_gmm_fxw_t<5, 5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     case 6: launch_gmm_fxw_t<5, 6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 7: launch_gmm_fxw_t<5, 7>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 8: launch_gmm_fxw_t<5, 8>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 9: launch_gmm_fxw_t<5, 9>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 10: launch_gmm_fxw_t<5, 10>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     default: break;  // fb_gmm_use_wide() admits only the cases above
   }
 }

@@ -297,9 +297,9 @@ def test_wide_scoring_kernel_single_tile_chunks(oracle, monkeypatch, n_speakers,
 
 
 @pytest.mark.parametrize("delta_p", [1, 2, 3])
-@pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers, delta_p):
-    """k_gmm_fx2w is instantiated per model count M = 2 .. 6 (SV: UBM + 1; OSI: UBM + speakers) and per number of
+    """k_gmm_fx2w is instantiated per model count M = 2 .. 10 (SV: UBM + 1; OSI: UBM + up to 9 speakers) and per number of
     partial products of the delta items: each instantiation has its own LDS slot split, LDS-DMA piece schedule,
     accumulator rotation and update-slice schedule.  Several component chunks per strip (C = 1024 -> tiles streamed
     through both slots many times), a ragged last strip, against the oracle and against the general kernel on the
@@ -347,6 +347,25 @@ def test_wide_scoring_kernel_csi_base_is_the_first_speaker(oracle, monkeypatch):
         e.load_gmm(spk)
         e.set_system("CSI", np.zeros(5), np.ones(5))
         assert e.gmm_kernel_variant in ("fx2w/1", "fx2w/2", "fx2w/3"), (e.gmm_kernel_variant, e.gmm_shift_rms)
+        raw_g, _ = e.score_raw(wavs)
+    finally:
+        e.close()
+    assert np.abs(raw_g - raw_o).max() <= 2e-5
+
+
+def test_more_than_ten_models_run_on_the_general_kernel(oracle, monkeypatch):
+    """Beyond 10 models the LDS of one CU no longer holds a tile of every model plus the logsumexp state: the general
+    kernel takes over (documented cliff: DESIGN.md section 5), with the same results."""
+    for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
+        monkeypatch.delenv(k, raising=False)
+    ubm, spk = synthetic_gmm_system(n_speakers=10, C=256, D=72)
+    wavs = [_wav(u, 16000) for u in range(3)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, _ = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=8)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        assert e.gmm_kernel_variant == "fx2"
         raw_g, _ = e.score_raw(wavs)
     finally:
         e.close()
