@@ -343,8 +343,8 @@ def bench_ivector(args, torch):
 
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
-GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
-TRAFFIC_FILE = "r02_traffic.json"
+GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6, 1>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
+TRAFFIC_FILE = "r03_traffic.json"
 # bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip): the clock drops to ~1.6 GHz
 # under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
 MFMA16_POWER_LIMITED_TFLOPS = 1660.0
