@@ -52,8 +52,8 @@
 // With one wave per SIMD nothing hides instruction fetch after a branch (a loop over items with the item kind,
 // pending update and padding decided by branches ran at ~1500 cycles per item with an EMPTY body), hence the
 // specialisation: M and P are template parameters, accumulator sets have static roles (delta item m writes set m & 1
-// while the previous item's values are updated in the gaps between its MFMAs, fb_fxw_step; the quadratic item carries
-// the update of the previous tile's last model), and a tile is one basic block.  Models with C % 32 != 0, several
+// while the previous item's values are updated in the gaps between its MFMAs, fb_fxw_step; the quadratic and the base
+// item carry the updates of the previous tile's last two models, the last delta item none), and a tile is one basic block.  Models with C % 32 != 0, several
 // variance groups or other M run on k_gmm_fx2.
 // Parameter items arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS
 // slots, a group of items each, requested a whole group of steps ahead of the barrier that publishes them
@@ -164,7 +164,10 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
   constexpr int KP = 2 * NP, NG = KP * NK;  // MFMAs per chunk / per step
   static_assert(NP >= 1 && NP <= 3 && NG >= 10, "slice layout");
   f32x16 x0 = init0, x1 = init1;
-  u32x4 s1[2], s2[2];  // fragment sets of the chunks 1 .. NK-1: chunk c uses set c & 1
+  // fragment sets of the chunks 1 .. NK-1, read from LDS PD chunks ahead of their MFMAs: one chunk (6 or 4 MFMAs) covers
+  // the LDS latency, but with one product per chunk (2 MFMAs) it takes two; chunk c uses set c % (PD + 1)
+  constexpr int PD = NP == 1 ? 2 : 1;
+  u32x4 s1[PD + 1], s2[PD + 1];
   float v0[16], v1[16];
   float t0 = FB_GMM_NEG, t1 = FB_GMM_NEG, mo0 = 0.f, mo1 = 0.f, so0 = 0.f, so1 = 0.f, mn0 = 0.f, mn1 = 0.f;
   float nr0 = 0.f, nr1 = 0.f, d0 = 0.f, d1 = 0.f;
@@ -175,12 +178,13 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
     const int c = g / KP, kk = g % KP;
     const int k = NP == 3 ? kk : (NP == 2 ? (kk < 2 ? kk : kk + 2) : kk + 4);  // which of the six products of a chunk
     if (kk == 0) {
-      if (c + 1 < NK) {
-        s1[(c + 1) & 1] = cur4[(0 * NK + c + 1) * 64 + lane];
-        if (NP >= 2) s2[(c + 1) & 1] = cur4[(1 * NK + c + 1) * 64 + lane];
+#pragma unroll
+      for (int cn = (c == 0 ? 1 : c + PD); cn <= c + PD && cn < NK; ++cn) {  // (the step's first gap requests 1 .. PD)
+        s1[cn % (PD + 1)] = cur4[(0 * NK + cn) * 64 + lane];
+        if (NP >= 2) s2[cn % (PD + 1)] = cur4[(1 * NK + cn) * 64 + lane];
       }
     }
-    const u32x4 &a1 = c == 0 ? z1 : s1[c & 1], &a2 = c == 0 ? z2 : s2[c & 1];
+    const u32x4 &a1 = c == 0 ? z1 : s1[c % (PD + 1)], &a2 = c == 0 ? z2 : s2[c % (PD + 1)];
     if (k == 0) FB_FX_MFMA(a2, b1[0][c], x0);
     else if (k == 1) FB_FX_MFMA(a2, b1[1][c], x1);
     else if (k == 2) FB_FX_MFMA(a1, b2[0][c], x0);
@@ -365,13 +369,13 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
   }
   {
-    // The quadratic step of the FIRST tile has no finished model to carry, and a branch for it costs more than a bogus
-    // update (nothing hides an instruction fetch at one wave per SIMD): it "updates" the last model with 16 sentinel
-    // values -2^60 / unscale, whose scaled form is exactly -2^60 fl(log2 e) -- the state becomes (that maximum, 16),
-    // and the first real update rescales those 16 by 2^(-1.6e18) = 0.
+    // The base steps of the FIRST tile have no finished models to carry, and a branch for them costs more than a bogus
+    // update (nothing hides an instruction fetch at one wave per SIMD): they "update" the last two models with 16
+    // sentinel values -2^60 / unscale, whose scaled form is exactly -2^60 fl(log2 e) -- the state becomes (that
+    // maximum, 16), and the first real update rescales those 16 by 2^(-1.6e18) = 0.
     const float sentinel = -fb_pow2f(60 - sh + g.kacc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[(M - 1) & 1][0][r] = sentinel; acc[(M - 1) & 1][1][r] = sentinel; }
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = sentinel; acc[0][1][r] = sentinel; acc[1][0][r] = sentinel; acc[1][1][r] = sentinel; }
   }
   fb_fxw_fetch<GA, NPIECE>(gimg + lane, ring_lds, wv);  // group A of the first tile
   publish();
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     const u32x4 *srcB = gimg + (size_t)min(it0 + GA, total_items - GB) * IMG4 + (size_t)wv * (PW_B * 64) + lane;
     const u32x4 *srcA = gimg + (size_t)min(it0 + NI, total_items - GA) * IMG4 + (size_t)wv * (PW_A * 64) + lane;
     const unsigned dstB = ring_lds + SLOTB4 * 16 + (unsigned)wv * (PW_B * 1024), dstA = ring_lds + (unsigned)wv * (PW_A * 1024);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int jj = 0; jj < NI; ++jj) {   // compile-time item index within the tile: 0 = Q, 1 + m = model m
       const bool first_of_group = (jj == 0 || jj == GA);
       const u32x4 *cur4 = slot0 + item4(jj);
@@ -411,15 +415,28 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       //               m - 1 -- for m = 1 that is the base model, read from hq itself
       const bool pf0 = (jj + 1 < NI && jj + 1 != GA);
       const u32x4 *nxt4 = slot0 + item4(jj + 1 < NI ? jj + 1 : 0);
+      // Which step carries which update (DEFER: three or more models).  The base items have the vector issue port to
+      // spare (30 MFMAs each), the delta items do not (10 - 30 MFMAs for the 126 instructions of an update), so the
+      // updates of the LAST TWO models wait for the next tile's Q and base steps -- their accumulator sets are not written
+      // again before delta items 1 / 2 of that tile -- and the last delta item carries none.
+      constexpr bool DEFER = M >= 3;
       if (jj == 0) {
-        float *pm = st_m + (2 * (M - 1)) * 256 + tid, *ps = st_s + (2 * (M - 1)) * 256 + tid;
-        fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+        if constexpr (DEFER) {
+          float *pm = st_m + (2 * (M - 2)) * 256 + tid, *ps = st_s + (2 * (M - 2)) * 256 + tid;
+          fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+        } else {
+          fb_fxw_step<NK, 3, false>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
+        }
       } else if (jj == 1) {
-        fb_fxw_step<NK, 3, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
+        float *pm = st_m + (2 * (M - 1)) * 256 + tid, *ps = st_s + (2 * (M - 1)) * 256 + tid;
+        fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
       } else if (jj == 2) {
         float *pm = st_m + tid, *ps = st_s + tid;
         fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], pm, ps, ls,
                                  dsrc, ddst, dq0, dn);
+      } else if (DEFER && jj == NI - 1) {
+        fb_fxw_step<NK, P, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                                  zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
       } else {
         float *pm = st_m + (2 * (jj - 2)) * 256 + tid, *ps = st_s + (2 * (jj - 2)) * 256 + tid;
         fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
@@ -429,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (M >= 3) update(acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], M - 2);
   update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);
 
 #pragma unroll
