@@ -5,6 +5,7 @@
 // launches on that stream with a single 8-byte-aligned result block copied back
 // through pinned memory; nothing else crosses PCIe inside the attack loop.
 #include <float.h>
+#include <algorithm>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -86,7 +87,7 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_items, gmm_images_bx, gmm_images_fx, gmm_images_fd;
+  DevBuf gmm_items, gmm_images_bx, gmm_images_fx, gmm_images_fd, gmm_anchor;
   double gmm_delta_rms = 0.0;  // fb_load_gmm's shift statistic behind gmm.delta_p
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
@@ -226,7 +227,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
@@ -431,7 +432,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0;
   // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
   // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
-  const bool want_delta = G == 1 && M >= 2 && (C & 31) == 0 && NKF == 5;
+  const bool want_delta = G == 1 && M >= 2 && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -509,39 +510,16 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
       //   ll_m,k(x) = ll_0,k(x) + (gconst_m,k - gconst_0,k) + (means_invvars_m,k - means_invvars_0,k) . x
       // and the second line is small: the kernel continues the base model's finished accumulator with the delta
       // item.  The deltas are float32 differences (exact by Sterbenz's lemma for the close values adaptation
-      // produces, correctly rounded otherwise), split into two f16 terms like every other parameter.
-      std::vector<uint16_t> fd((size_t)n_tiles * n_items * per_item, 0);
-      for (int t = 0; t < n_tiles; ++t)
-        for (int it = 0; it < n_items; ++it) {
-          uint16_t *im = &fd[((size_t)t * n_items + it) * per_item];
-          if (it < 2) {  // Q and the base model: as in the full images (the item list is {Q, 0, 1, ..})
-            memcpy(im, &fx[((size_t)t * n_items + it) * per_item], sizeof(uint16_t) * per_item);
-            continue;
-          }
-          const int m = it - 1;
-          for (int cc = 0; cc < 32; ++cc) {
-            const int c = t * 32 + cc;
-            for (int k = 0; k < 16 * NKF; ++k) {
-              uint16_t sp[2] = {0, 0};
-              if (k < D) split2(lscale * (miv[((size_t)m * C + c) * D + k] - miv[(size_t)c * D + k]), sp);
-              else if (k == D) split2(lscale * (gconsts[(size_t)m * C + c] - gconsts[c]), sp);
-              const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
-              for (int s2 = 0; s2 < 2; ++s2) im[(((size_t)s2 * NKF + ch) * 64 + lane) * 8 + i] = sp[s2];
-            }
-          }
-        }
-      FBCHK(e->gmm_images_fd.ensure(sizeof(uint16_t) * fd.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
-      HIPCHK(hipMemcpy(e->gmm_images_fd.p, fd.data(), sizeof(uint16_t) * fd.size(), hipMemcpyHostToDevice));
+      // produces, correctly rounded otherwise).
+      //
       // Products per K chunk of the delta items.  P = 2 drops the frames' second f16 term -- an error of 2^-12 |delta . x|
       // per (frame, component), random in sign from frame to frame --, P = 1 also the deltas' second term.
       // b_k = 2^-12 |delta_k * (|mu_k| + 3 sigma_k)|_2 bounds the former where component k matters (x within 3 sigma of
       // its mean); on the utterance averages the error measured in a float64 numpy model of the split is ~0.07 rms(b)
       // for P = 2 and ~0.14 rms(b) for P = 1.  The thresholds keep that prediction below 6e-6,
       // less than half a float32 ulp of the ~-150 results and inside the ~3.3e-6 float32 accumulation error every
-      // variant carries (measured on the GPU against the float64 oracle, UBM + 5 synthetic speakers of SURVEY.md 8(d):
-      // P = 1 3.97e-6, P = 2 3.39e-6, P = 3 3.23e-6, k_gmm_fx2 3.35e-6, the exact bf16 split 3.70e-6;
-      // tests/test_gpu_parity.py).  Models adapted further (enrolment on many frames, a small tau, unrelated means)
-      // get more products, up to the full three -- the arithmetic of the non-delta kernels.
+      // variant carries (tests/test_gpu_parity.py).  Models adapted further (enrolment on many frames, a small tau,
+      // unrelated means) get more products, up to the full three -- the arithmetic of the non-delta kernels.
       double sumsq = 0.0;
       for (int m = 1; m < M; ++m)
         for (int c = 0; c < C; ++c)
@@ -552,14 +530,136 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
             sumsq += dl * dl * reach * reach;
           }
       const double rms_b = ldexp(sqrt(sumsq / ((double)(M - 1) * C)), -12);
-      delta_p = rms_b <= 4.3e-5 ? 1 : (rms_b <= 8.6e-5 ? 2 : 3);
+      int want_p = rms_b <= 4.3e-5 ? 1 : (rms_b <= 8.6e-5 ? 2 : 3);
       const char *pe = getenv("FB_GMM_DELTA_P");  // tests: force the number of products
       if (pe && *pe) {
         const int v = atoi(pe);
         if (v < 1 || v > 3) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_P must be 1, 2 or 3 (got '%s')", pe);
-        delta_p = v;
+        want_p = v;
       }
       e->gmm_delta_rms = rms_b;
+
+      // The images are in LOG2 units: every parameter is multiplied by log2 e in float64 and then split into its f16
+      // terms -- the accumulators of k_gmm_fx2w then hold the exponent of 2 directly and its logsumexp update needs
+      // no multiplication (gmm_wide_kernel.hip).  There is no common power-of-two factor to undo either; instead every
+      // DIMENSION d is balanced by an exact power of two of its own: the frames' x_d is multiplied by 2^kd[d], the
+      // linear parameters by 2^-kd[d] (x_d^2 by 2^kq[d], the quadratic ones by 2^-kq[d]), chosen from the spread
+      // sd[d] of the dimension under the base model so that |x_d| 2^kd ~ 1 and x_d^2 2^kq ~ 1: the parameters -- whose
+      // rounding is the same for every frame -- then sit around 1 .. 10 where both f16 terms are normal numbers (22
+      // significant bits), the frames keep theirs down to |x_d| = sd/8 and an absolute 2^-25 below.
+      // The constants (gconst of the base model, its difference for the others) stand in the K padding against 1.0 in
+      // the frame operand, as THREE f16 terms at K = D, D + 1, D + 2 of the FIRST parameter term: they come out with 33
+      // bits whatever P.  With P = 1 a delta item's linear parameters are their leading f16 term only; what that
+      // leaves out at the component's own mean, sum_d (delta' - f16(delta'))_kd mu'_kd -- a constant per (model,
+      // component), the same for every frame the component explains --, goes into that constant.
+      const double L2E = 1.4426950408889634;
+      auto f16r = [](double v) { return (double)(_Float16)v; };  // round to nearest even
+      auto put16 = [](double v, uint16_t *out) { const _Float16 a = (_Float16)v; memcpy(out, &a, 2); };
+      std::vector<int> kd(16 * NKF, 0), kq(16 * NKF, 0);
+      bool fits = true;
+      for (int k = 0; k < D; ++k) {
+        double m1 = 0.0, m2 = 0.0, vs = 0.0;  // spread of dimension k: mean component variance + variance of the means
+        for (int c = 0; c < C; ++c) {
+          const double var = 1.0 / (double)iv[(size_t)c * D + k], mu = (double)miv[(size_t)c * D + k] * var;
+          m1 += mu; m2 += mu * mu; vs += var;
+        }
+        const double sd2 = vs / C + std::max(0.0, m2 / C - (m1 / C) * (m1 / C));
+        const int e2 = sd2 > 0.0 && std::isfinite(sd2) ? (int)lrint(-0.5 * log2(sd2)) : 0;
+        kd[k] = std::min(24, std::max(-24, e2));
+        kq[k] = 2 * kd[k];
+        double pl = 0.0, pq = 0.0;  // the largest scaled parameters must stay inside f16's range
+        for (int m = 0; m < M; ++m)
+          for (int c = 0; c < C; ++c) pl = std::max(pl, fabs((double)miv[((size_t)m * C + c) * D + k]));
+        for (int c = 0; c < C; ++c) pq = std::max(pq, 0.5 * (double)iv[(size_t)c * D + k]);
+        fits = fits && ldexp(L2E * pl, -kd[k]) < 60000.0 && ldexp(L2E * pq, -kq[k]) < 60000.0;
+      }
+      for (int c = 0; c < M * C; ++c) fits = fits && L2E * fabs((double)gconsts[c]) < 60000.0;
+      if (fits) {  // (k_gmm_fx2 scores a model that does not)
+        std::vector<uint16_t> fd((size_t)n_tiles * n_items * per_item, 0);
+        for (int t = 0; t < n_tiles; ++t)
+          for (int it = 0; it < n_items; ++it) {
+            uint16_t *im = &fd[((size_t)t * n_items + it) * per_item];
+            const int m = it - 1;  // -1: the quadratic item
+            auto at = [&](int term, int k, int cc) -> uint16_t * {
+              const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
+              return &im[(((size_t)term * NKF + ch) * 64 + lane) * 8 + i];
+            };
+            for (int cc = 0; cc < 32; ++cc) {
+              const int c = t * 32 + cc;
+              double cst = m == 0 ? L2E * (double)gconsts[c]
+                                  : (m > 0 ? L2E * (double)(gconsts[(size_t)m * C + c] - gconsts[c]) : 0.0);
+              for (int k = 0; k < D; ++k) {
+                double v;
+                if (m < 0) v = ldexp(L2E * (double)(-0.5f * iv[(size_t)c * D + k]), -kq[k]);
+                else if (m == 0) v = ldexp(L2E * (double)miv[(size_t)c * D + k], -kd[k]);
+                else v = ldexp(L2E * (double)(miv[((size_t)m * C + c) * D + k] - miv[(size_t)c * D + k]), -kd[k]);
+                const double a = f16r(v);
+                put16(a, at(0, k, cc));
+                put16(v - a, at(1, k, cc));
+                if (m > 0 && want_p == 1)  // the dropped second term at the component's mean (mu' = mu 2^kd)
+                  cst += (v - a) * ldexp((double)miv[(size_t)c * D + k] / (double)iv[(size_t)c * D + k], kd[k]);
+              }
+              if (m < 0) {  // the frames' reference stands in their x^2 operand as -(R mod 2048), -(R div 2048) (gmm_wide_kernel.hip)
+                put16(1.0, at(0, D + 3, cc));
+                put16(2048.0, at(0, D + 4, cc));
+              }
+              if (m >= 0) {
+                const double c1 = f16r(cst), c2 = f16r(cst - c1);
+                put16(c1, at(0, D, cc));
+                put16(c2, at(0, D + 1, cc));
+                put16(cst - c1 - c2, at(0, D + 2, cc));
+              }
+            }
+          }
+        FBCHK(e->gmm_images_fd.ensure(sizeof(uint16_t) * fd.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
+        HIPCHK(hipMemcpy(e->gmm_images_fd.p, fd.data(), sizeof(uint16_t) * fd.size(), hipMemcpyHostToDevice));
+        // The anchors of k_gmm_fx2w's reference: the base model's FB_FXW_ANCHORS widest components.  The log2-likelihood
+        // of a frame under one of them is a lower bound of the base model's log2 sum; every other model's sum is at least
+        // that minus |dgconst| + |dlinear|_2 |x|_2 (Cauchy-Schwarz on the delta line above, in the frames' balanced units),
+        // whose two maxima over the models go along.  Table: [0, 80) the frames' balancing factors 2^kd, [80, 160) those of
+        // their squares 2^kq, then per anchor {80 linear terms with gconst at D, 80 quadratic terms -- in balanced units:
+        // the kernel evaluates them on the leading f16 term of its frame operand, hence the + 2 --, max |dgconst| + 2,
+        // max |dlinear|_2, 0, 0}.
+        std::vector<int> order(C);
+        std::vector<double> vol(C);
+        for (int c = 0; c < C; ++c) {
+          order[c] = c;
+          double lv = 0.0;
+          for (int k = 0; k < D; ++k) lv -= log((double)iv[(size_t)c * D + k]);
+          vol[c] = lv;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vol[a] > vol[b]; });
+        const int W = 16 * NKF;
+        std::vector<float> an(2 * W + FB_FXW_ANCHORS * (2 * W + 4), 0.0f);
+        for (int k = 0; k < W; ++k) {
+          an[k] = ldexpf(1.0f, kd[k]);
+          an[W + k] = ldexpf(1.0f, kq[k]);
+        }
+        for (int a = 0; a < FB_FXW_ANCHORS; ++a) {
+          const int ks = order[std::min(a, C - 1)];
+          float *at = &an[2 * W + (size_t)a * (2 * W + 4)];
+          for (int k = 0; k < D; ++k) {
+            at[k] = (float)ldexp(L2E * (double)miv[(size_t)ks * D + k], -kd[k]);
+            at[W + k] = (float)ldexp(L2E * (double)(-0.5f * iv[(size_t)ks * D + k]), -kq[k]);
+          }
+          at[D] = (float)(L2E * (double)gconsts[ks]);
+          double mg = 0.0, ml = 0.0;
+          for (int m = 1; m < M; ++m) {
+            double l2 = 0.0;
+            for (int k = 0; k < D; ++k) {
+              const double dl = ldexp((double)miv[((size_t)m * C + ks) * D + k] - (double)miv[(size_t)ks * D + k], -kd[k]);
+              l2 += dl * dl;
+            }
+            ml = std::max(ml, L2E * sqrt(l2));
+            mg = std::max(mg, L2E * fabs((double)gconsts[(size_t)m * C + ks] - (double)gconsts[ks]));
+          }
+          at[2 * W] = (float)(mg * 1.000001 + 2.0);
+          at[2 * W + 1] = (float)(ml * 1.000001);
+        }
+        FBCHK(e->gmm_anchor.ensure(sizeof(float) * an.size()));
+        HIPCHK(hipMemcpy(e->gmm_anchor.p, an.data(), sizeof(float) * an.size(), hipMemcpyHostToDevice));
+        delta_p = want_p;
+      }
     }
   }
   if (mode == FB_GMM_MODE_BX3) {
@@ -618,6 +718,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.delta_p = mode == FB_GMM_MODE_FX2 ? delta_p : 0;
   g.images_fd = g.delta_p ? reinterpret_cast<decltype(g.images_fd)>(e->gmm_images_fd.p) : nullptr;
+  g.anchor = g.delta_p ? e->gmm_anchor.as<float>() : nullptr;
   g.item_model = e->gmm_items.as<int>();
   g.item_model_host_q_first = (G == 1) ? 1 : 0;  // one group: the list built above is {Q, 0, 1, ..., M-1}
   e->n_groups = G;
@@ -1902,6 +2003,43 @@ extern "C" int fb_stats(fb_engine *e, int64_t *scored_utts, int64_t *scored_fram
   if (scored_frames) *scored_frames = e->scored_frames;
   if (voiced_frames) *voiced_frames = e->voiced_frames;
   if (nes_iters) *nes_iters = e->nes_iters;
+  return FB_OK;
+}
+
+// Test hook: the GMM kernel the engine runs for scoring, on T rows of features handed in as they are (no front-end),
+// per-frame log-likelihoods out[m * T + t] -- the chunk partials merged here in float64.
+extern "C" int fb_debug_gmm_frames(fb_engine *e, const float *feats, int T, double *out) {
+  if (!e || !feats || !out || T <= 0) return fb_fail(FB_E_ARG, "bad argument");
+  if (!e->have_gmm || e->kind != 0) return fb_fail(FB_E_STATE, "no GMM system loaded");
+  HIPCHK(hipSetDevice(e->device));
+  const FbGmmDev &g = e->gmm;
+  FBCHK(sync_stream(e));
+  const int n_chunks = choose_chunks(g, T, true);
+  FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * g.D));
+  FBCHK(e->row_off.ensure(sizeof(int) * 2));
+  FBCHK(e->part_m.ensure(sizeof(float) * (size_t)n_chunks * g.M * T));
+  FBCHK(e->part_s.ensure(sizeof(float) * (size_t)n_chunks * g.M * T));
+  const int rows_host[2] = {0, T};
+  HIPCHK(hipMemcpy(e->feats.p, feats, sizeof(float) * (size_t)T * g.D, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->row_off.p, rows_host, sizeof(rows_host), hipMemcpyHostToDevice));
+  fb_launch_gmm(e->stream, g, e->feats.as<float>(), e->row_off.as<int>() + 1, T, n_chunks, e->part_m.as<float>(),
+                e->part_s.as<float>());
+  HIPCHK(hipGetLastError());
+  FBCHK(sync_stream(e));
+  std::vector<float> pm((size_t)n_chunks * g.M * T), ps(pm.size());
+  HIPCHK(hipMemcpy(pm.data(), e->part_m.p, sizeof(float) * pm.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ps.data(), e->part_s.p, sizeof(float) * ps.size(), hipMemcpyDeviceToHost));
+  for (int m = 0; m < g.M; ++m)
+    for (int t = 0; t < T; ++t) {
+      double mx = -INFINITY, sum = 0.0;
+      for (int c = 0; c < n_chunks; ++c) mx = std::max(mx, (double)pm[((size_t)c * g.M + m) * T + t]);
+      for (int c = 0; c < n_chunks; ++c) {
+        const size_t o = ((size_t)c * g.M + m) * T + t;
+        sum += (double)ps[o] * exp((double)pm[o] - mx);
+      }
+      out[(size_t)m * T + t] = mx + log(sum);
+    }
+  e->last_total_frames = 0;  // the feature buffer no longer belongs to a scored batch
   return FB_OK;
 }
 

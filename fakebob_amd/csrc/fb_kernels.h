@@ -134,13 +134,17 @@ struct FbGmmDev {
   int kx, kx2, kacc;
   const unsigned int __attribute__((ext_vector_type(4))) * images_fx;
   // k_gmm_fx2w (one variance group): images [n_tiles][1 + M][2][NKF][64] x 16 B of {Q, base model 0, delta_1 ..
-  // delta_{M-1}}, delta_m = (means_invvars, gconst) of model m MINUS the base model's, in the same scaling; delta_p =
-  // partial products per K chunk the delta items are evaluated with (1 .. 3; 0: no delta images)
+  // delta_{M-1}}, delta_m = (means_invvars, gconst) of model m MINUS the base model's, all times log2 e and without
+  // power-of-two scaling (the frames are used unscaled); delta_p = partial products per K chunk the delta items are
+  // evaluated with (1 .. 3; 0: no delta images); anchor = the frames' balancing factors and the components whose
+  // log2-likelihoods start the kernel's per-frame reference (layout: fb_load_gmm)
   const unsigned int __attribute__((ext_vector_type(4))) * images_fd;
   int delta_p;
+  const float *anchor;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
+#define FB_FXW_ANCHORS 2  // anchor components of k_gmm_fx2w's per-frame reference (FbGmmDev::anchor)
 #define FB_GMM_MODE_BX3 1
 #define FB_GMM_MODE_FX2 2
 #ifndef FB_FX_OCC

@@ -26,6 +26,12 @@
 // UBM + 5 speakers.  The speaker-minus-UBM differences the OSI / SV scores are made of also come out closer to the
 // float64 oracle than from independent chains (the base model's rounding is common to both).
 //
+// Log2-domain accumulators (round 3, second step).  The images are the parameters times log2 e, balanced per dimension
+// against the frames by exact powers of two instead of scaled as a whole (fb_load_gmm), and the frame operand carries
+// -R, an integer reference per frame, in two K places of the padding: an accumulator is t = ll log2 e - R, ready for
+// v_exp_f32.  The logsumexp update is one exponential and one addition per value (above fb_fxw_step), with a cold
+// rescue path for the frames whose reference turns out too low and for frames outside f16's range.
+//
 // What the design rests on (tools/probes/coissue_probe.hip, valu_cost_probe.hip, mfma_operand_probe.hip; one wave per
 // SIMD):
 //   * MFMAs on ONE accumulator issue only as fast as they execute (the wave sits at the next dependent MFMA), so in
@@ -46,15 +52,16 @@
 // 226 v_accvgpr_read copies of the round-2 kernel and the hazard s_nops in front of them are gone); of the 160
 // registers of frame operands only the leading term of x (40: every item but Q uses it) stays beside them, x's second
 // term and both terms of x^2 (120: used by the two base items only) are parked in accumulation registers by an empty
-// asm and read from there by the MFMAs; + 24 of parameter fragments: 201 vector + 120 accumulation registers.
+// asm and read from there by the MFMAs; + 24 of parameter fragments: 204 vector + 120 accumulation registers.
 // 4 waves (256 frames) per workgroup, one workgroup per CU, component chunks chosen so that a launch is one round of
 // <= 256 workgroups.
 // With one wave per SIMD nothing hides instruction fetch after a branch (a loop over items with the item kind,
 // pending update and padding decided by branches ran at ~1500 cycles per item with an EMPTY body), hence the
 // specialisation: M and P are template parameters, accumulator sets have static roles (delta item m writes set m & 1
 // while the previous item's values are updated in the gaps between its MFMAs, fb_fxw_step; the quadratic and the base
-// item carry the updates of the previous tile's last two models, the last delta item none), and a tile is one basic block.  Models with C % 32 != 0, several
-// variance groups or other M run on k_gmm_fx2.
+// item carry the updates of the previous tile's last two models, the last delta item none), and a tile is a straight
+// line of basic blocks whose only branches are the never-taken ones to the rescue code behind the loop.  Models with
+// C % 32 != 0, D % 4 != 0, several variance groups or other M run on k_gmm_fx2.
 // Parameter items arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS
 // slots, a group of items each, requested a whole group of steps ahead of the barrier that publishes them
 // (fb_fxw_fetch and the loop below).
@@ -131,48 +138,123 @@ __device__ __forceinline__ float fb_v_max3(float a, float b, float c) {
   return d;
 }
 
+// The logsumexp state of k_gmm_fx2w (round 3, second form).  The parameter images carry log2 e (fb_load_gmm) and the
+// quadratic item's accumulation includes -R, R an integer reference per frame that stands in two K places of the x^2
+// operand's padding (set_ref in the kernel): a finished accumulator holds t = ll * log2 e - R, and a value costs ONE
+// v_exp_f32 and ONE v_add_f32 -- no running maximum, no subtraction (204 v_fma_f32 and 108 v_max3_f32 of the 850
+// vector instructions per tile gone; the steps of the delta items are bound by the vector issue port).
+//   state per (frame half, model) in LDS: (mref, s), sum_k 2^(ll_k log2 e) = s * 2^mref; mref an integer-valued float
+//   fast update:  s += (sum_i 2^t_i) * 2^(R_tile - mref)            [the factor is 1 unless a rescue moved one of them]
+//   guard:        s <= 2^100 (false for inf and NaN too), else the RESCUE below redoes the update from the accumulator
+//                 registers -- still there -- the classical way (maximum, re-reference) and proposes a new R for the
+//                 next tile.  Cold code behind the loop (~2.4 us per visit, mostly instruction fetch), taken by the
+//                 whole wave when one lane needs it.
+// R starts from a guaranteed LOWER bound of every model's log2 sum: the best of the log-likelihoods of
+// FB_FXW_ANCHORS wide components of the base model (the "anchors", fb_load_gmm), evaluated in the prologue on the
+// frame operand's leading term, minus a Cauchy-Schwarz bound of what the other models' deltas can take away, +
+// FB_FXW_ROFF: never more than 2^64 above a sum (nothing that matters underflows: what is flushed lies 2^-62 below
+// the ANCHOR's term; Kaldi's own LogSumExp drops what is 2^-23 below the maximum), and a sum may lie 2^164 = 113 nats
+// above the bound before a rescue is needed.  On the SURVEY.md 8(d) workload: 56 rescues in 87 552 updates with two
+// anchors (3 563 with one -- 9 us of the launch).
+// A wave with a frame that needed the dynamic range shift (|x| >= 181 spreads) takes the rescue path for every update.
+#ifdef FB_FXW_COUNT  // instrumented build (tools/profile/fxw_instrumented.sh): how often the cold paths run
+__device__ unsigned long long g_fxw_counts[4];
+extern "C" int fb_debug_fxw_counts(unsigned long long *out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fxw_counts), sizeof(g_fxw_counts)) != hipSuccess) return -1;
+  unsigned long long z[4] = {0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fxw_counts), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#define FXW_COUNT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fxw_counts[i], 1ull); } while (0)
+#else
+#define FXW_COUNT(i) do { } while (0)
+#endif
+#ifdef FB_FXW_STAMP  // instrumented build (tools/profile/fxw_instrumented.sh): where a workgroup's time goes
+__device__ unsigned long long g_fxw_stamps[16];
+extern "C" int fb_debug_fxw_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fxw_stamps), sizeof(g_fxw_stamps)) == hipSuccess ? 0 : -1;
+}
+#define FXW_STAMP(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) g_fxw_stamps[i] = wall_clock64(); } while (0)
+#else
+#define FXW_STAMP(i) do { } while (0)
+#endif
+#define FB_FXW_ROFF 64.0f
+#define FB_FXW_SMAX 1.2676506002282294e30f  // 2^100
+struct FbFxwUpd { float mo0, mo1, so0, so1, sn0, sn1; };  // state before / sums after a fast update (halves 0, 1)
+
+// the rescue: fold the 16 values p (t * 2^-sh, relative to rt) into (mo, so) with a maximum; lanes with `need` store
+__device__ __forceinline__ void fb_fxw_slow_update(const f32x16 &p, float up, float rt, float mo, float so,
+                                                   float *__restrict__ pm, float *__restrict__ ps, float &rn, bool need) {
+  float tm = -3.0e38f;  // (finite also for the sentinel values of the first tile)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, __fmul_rn(p[r], up));
+  const float mo_e = so > 0.0f ? mo : -INFINITY;              // an empty state has no reference yet
+  const float mn = fmaxf(mo_e, __fadd_rn(rt, rintf(tm)));     // integer-valued like mo and rt
+  const float off = __fsub_rn(mn, rt);
+  float a0 = __fmul_rn(so, __builtin_amdgcn_exp2f(__fsub_rn(mo_e, mn))), a1 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    a0 = __fadd_rn(a0, __builtin_amdgcn_exp2f(__fmaf_rn(p[r], up, -off)));
+    a1 = __fadd_rn(a1, __builtin_amdgcn_exp2f(__fmaf_rn(p[r + 1], up, -off)));
+  }
+  if (need) {
+    *pm = mn;
+    *ps = __fadd_rn(a0, a1);
+    rn = fmaxf(rn, mn);
+  }
+}
+
+__device__ __forceinline__ float fb_v_sub(float a, float b) {
+  float d;
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // One item step with the logsumexp update of ANOTHER accumulator set threaded between the MFMAs, by construction.
 // One wave per SIMD issues in order; about five plain vector instructions behind an MFMA are free, what exceeds them
-// adds to the step.  Left alone hipcc lumps the ~160 vector instructions of an update behind the MFMAs (kernel time =
+// adds to the step.  Left alone hipcc lumps the vector instructions of an update behind the MFMAs (kernel time =
 // MFMA time + update time, measured), so the step is cut into one scheduling region per MFMA
-// (__builtin_amdgcn_sched_barrier(0)) and each region gets its share of the 30 slices of the update of the pending set
-// (p0, p1 = the two halves' 16 values each, pm / ps their LDS state [2 halves][256]):
-//   slice  0       the state is requested from LDS (the pending values are still in the matrix pipe)
-//   slices 2..9    four values are copied from the accumulation registers into vector registers, where they stay for
-//                  the second pass (two reads per value would make the update the longer pipe); running maximum
-//   slices 10, 11  new reference r = fl(m L), the old sums rescaled
-//   slices 12..27  one value of each half: fma, exponential, and the ADD of the previous slice's exponentials (so that
-//                  no exponential is consumed right behind itself); even and odd values are summed apart and joined at
-//                  the end, which is fb_lse_update16's order
-//   slices 28, 29  last adds, state written back
-// NP = partial products per K chunk: 3 (a2 b1 + a1 b2 + a1 b1: the full two-term product, 30 MFMAs per step, one slice
-// per gap), 2 (a2 b1 + a1 b1: both parameter terms against the leading frame term, 20 MFMAs) or 1 (a1 b1, 10 MFMAs) --
-// the delta items of k_gmm_fx2w; with fewer gaps than slices the slices 2 .. 29 are dealt evenly over the gaps 2 ..
+// (__builtin_amdgcn_sched_barrier(0)) and each region gets its share of the 19 slices of the update of the pending set
+// (p0, p1 = the two halves' 16 values each, pm / ps their LDS state [2 halves][256], rt0 / rt1 the reference the set
+// was computed against):
+//   slice  0       the state is requested from LDS
+//   slices 1..16   one value of each half: its exponential, and the ADD of the previous slice's exponentials (no
+//                  exponential is consumed right behind itself); even and odd values are summed apart
+//   slice  17      last add, 2^(rt - mref)
+//   slice  18      s + sum * 2^(rt - mref) written back; the caller checks it (guard above)
+// NP = partial products per K chunk: 3 (a2 b1 + a1 b2 + a1 b1: the full two-term product, 30 MFMAs per step), 2
+// (a2 b1 + a1 b1: both parameter terms against the leading frame term, 20 MFMAs) or 1 (a1 b1, 10 MFMAs) -- the delta
+// items of k_gmm_fx2w.
 // The parameter fragments are streamed with the K chunks -- chunk c + 1 is read from LDS while the MFMAs of chunk
 // c run (two alternating register sets for the chunks 1 .. NK-1; chunk 0 has its own, z1 / z2, refilled with the NEXT
-// item's chunk 0 when pf0) -- 24 registers instead of two whole items' 80: that is what leaves room for the 32
-// pending values.
+// item's chunk 0 when pf0) -- 24 registers instead of two whole items' 80.
 // The LDS-DMA pieces [dq0, dq0 + dn) of this wave's share of the next parameter group go out one per chunk.
-// UPD = false: no pending set (the base model's item: its own values are not there yet).
-template <int NK, int NP, bool UPD>
+// UPD = false: no pending set.
+template <int NK, int NP, bool UPD, bool ZI = false>
 __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, const u32x4 *__restrict__ nxt4, const bool pf0,
                                             int lane, u32x4 &z1, u32x4 &z2, const u32x4 (&b1)[2][NK],
                                             const u32x4 (&b2)[2][NK], const f32x16 &init0, const f32x16 &init1,
                                             f32x16 &out0, f32x16 &out1, const f32x16 &p0, const f32x16 &p1,
-                                            float *__restrict__ pm, float *__restrict__ ps, float ls,
+                                            float *__restrict__ pm, float *__restrict__ ps, const float rt0, const float rt1,
+                                            FbFxwUpd &u,
                                             const u32x4 *__restrict__ dsrc, unsigned ddst, const int dq0, const int dn) {
   constexpr int KP = 2 * NP, NG = KP * NK;  // MFMAs per chunk / per step
+  constexpr int NS = 19;                    // slices of an update
   static_assert(NP >= 1 && NP <= 3 && NG >= 10, "slice layout");
-  f32x16 x0 = init0, x1 = init1;
+  f32x16 x0, x1;  // ZI: from zero -- a literal C operand of the first MFMAs, no registers to clear
+  if constexpr (ZI) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x0[r] = 0.0f; x1[r] = 0.0f; }
+  } else {
+    x0 = init0;
+    x1 = init1;
+  }
   // fragment sets of the chunks 1 .. NK-1, read from LDS PD chunks ahead of their MFMAs: one chunk (6 or 4 MFMAs) covers
   // the LDS latency, but with one product per chunk (2 MFMAs) it takes two; chunk c uses set c % (PD + 1)
   constexpr int PD = NP == 1 ? 2 : 1;
   u32x4 s1[PD + 1], s2[PD + 1];
-  float v0[16], v1[16];
-  float t0 = FB_GMM_NEG, t1 = FB_GMM_NEG, mo0 = 0.f, mo1 = 0.f, so0 = 0.f, so1 = 0.f, mn0 = 0.f, mn1 = 0.f;
-  float nr0 = 0.f, nr1 = 0.f, d0 = 0.f, d1 = 0.f;
   float se0 = 0.f, se1 = 0.f, sd0 = 0.f, sd1 = 0.f;  // sums of the even / odd values, halves 0 / 1
   float e0 = 0.f, e1 = 0.f;                          // the previous slice's exponentials
+  float w0 = 0.f, w1 = 0.f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int c = g / KP, kk = g % KP;
@@ -197,41 +279,26 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
     }
     if (kk == (KP > 3 ? 3 : KP - 1) && c < dn) fb_glds16(dsrc + (dq0 + c) * 64, ddst + (unsigned)(dq0 + c) * 1024u);
     if constexpr (UPD) {
-      // slices of this gap: 0 and 1 in the gaps 0 and 1, the 28 others dealt over the NG - 2 gaps that follow
-      const int sl0 = g < 2 ? g : 2 + ((g - 2) * 28) / (NG - 2), sl1 = g < 2 ? g + 1 : 2 + ((g - 1) * 28) / (NG - 2);
+      const int sl0 = (g * NS) / NG, sl1 = ((g + 1) * NS) / NG;  // the 19 slices dealt evenly over the gaps
 #pragma unroll
       for (int sl = sl0; sl < sl1; ++sl) {
-        if (sl == 0) { mo0 = pm[0]; mo1 = pm[256]; so0 = ps[0]; so1 = ps[256]; }
-        if (sl >= 2 && sl < 10) {
-          const int r = 2 * (sl - 2);
-          v0[r] = p0[r]; v0[r + 1] = p0[r + 1]; v1[r] = p1[r]; v1[r + 1] = p1[r + 1];
-          // the copies are the compiler's (it knows the matrix pipe's hazards); the empty asm keeps them HERE and in
-          // vector registers
-          asm volatile("" : "+v"(v0[r]), "+v"(v0[r + 1]), "+v"(v1[r]), "+v"(v1[r + 1]));
-          t0 = fb_v_max3(t0, v0[r], v0[r + 1]);
-          t1 = fb_v_max3(t1, v1[r], v1[r + 1]);
-        } else if (sl == 10) {
-          mn0 = fb_v_max3(mo0, t0, t0); mn1 = fb_v_max3(mo1, t1, t1);
-          const float rn0 = fb_v_mul(mn0, ls), rn1 = fb_v_mul(mn1, ls);
-          nr0 = -rn0; nr1 = -rn1;
-          d0 = fb_v_fma(mo0, ls, nr0); d1 = fb_v_fma(mo1, ls, nr1);  // r_old - r_new; r_old = -inf at the start
-        } else if (sl == 11) {
-          e0 = fb_v_exp(d0); e1 = fb_v_exp(d1);
-        } else if (sl >= 12 && sl < 28) {
-          const int r = sl - 12;
-          const float u0 = fb_v_fma(v0[r], ls, nr0), u1 = fb_v_fma(v1[r], ls, nr1);
-          const float f0 = fb_v_exp(u0), f1 = fb_v_exp(u1);
-          if (r == 0) { se0 = fb_v_mul(so0, e0); se1 = fb_v_mul(so1, e1); }      // s_old * 2^(r_old - r_new)
-          else if (r == 1) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // + value 0
-          else if (r == 2) { sd0 = e0; sd1 = e1; }                                 // value 1 starts the odd sums
-          else if (r & 1) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // value r - 1 is even
-          else { sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1); }
+        if (sl == 0) {
+          u.mo0 = pm[0]; u.mo1 = pm[256]; u.so0 = ps[0]; u.so1 = ps[256];
+        } else if (sl <= 16) {
+          const int r = sl - 1;
+          const float f0 = fb_v_exp(p0[r]), f1 = fb_v_exp(p1[r]);
+          if (r == 1) { se0 = e0; se1 = e1; }                                        // value 0 starts the even sums
+          else if (r == 2) { sd0 = e0; sd1 = e1; }                                   // value 1 the odd ones
+          else if (r >= 3 && (r & 1)) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // value r - 1 is even
+          else if (r >= 3) { sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1); }
           e0 = f0; e1 = f1;
-        } else if (sl == 28) {
-          sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1);                       // value 15
-        } else if (sl == 29) {
-          pm[0] = mn0; pm[256] = mn1;
-          ps[0] = fb_v_add(se0, sd0); ps[256] = fb_v_add(se1, sd1);
+        } else if (sl == 17) {
+          sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1);                          // value 15
+          w0 = fb_v_exp(fb_v_sub(rt0, u.mo0)); w1 = fb_v_exp(fb_v_sub(rt1, u.mo1));
+        } else {
+          u.sn0 = fb_v_fma(fb_v_add(se0, sd0), w0, u.so0);
+          u.sn1 = fb_v_fma(fb_v_add(se1, sd1), w1, u.so1);
+          ps[0] = u.sn0; ps[256] = u.sn1;
         }
       }
     }
@@ -252,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
   constexpr int NI = M + 1;          // items per tile: Q, base model, delta_1 .. delta_{M-1}
   constexpr int GA = (NI + 1) / 2, GB = NI - GA;  // a tile's items live in two LDS slots: A = items 0 .. GA-1, B = the rest
+  FXW_STAMP(0);
   const int n_rows = *n_rows_ptr;
   int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
   if (xcd_map) {
@@ -273,74 +341,167 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   float *st_m = lds + (NI * IMG4 + 2 * PAD4) * 4;  // [M][2 halves][256]
   float *st_s = st_m + M * 512;                // [M][2 halves][256]
 
-  // ---- frame fragments of the two 32-frame halves (layout and range guard as in k_gmm_fx2; the power-of-two shift
-  //      is uniform over the wave's 64 frames)
+  // ---- frame fragments of the two 32-frame halves.  All of a lane's feature loads go out first; while they are under
+  //      way the per-dimension tables (balancing factors, anchor components: fb_load_gmm) are staged in LDS -- in slot B,
+  //      which no LDS-DMA touches before the first publish() below, a barrier every wave passes after its last read here.
   u32x4 bx1[2][NK], bx2[2][NK], bq1[2][NK], bq2[2][NK];
-  int sh = 0;
   int rows[2];
-  {
-    const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);
-    float vv[2][NK][8], qq[2][NK][8];
-    float amax = xs;
+  float4 ft[NK][2][2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      rows[hf] = strip0 + w * 64 + hf * 32 + j;
-      const bool ok = rows[hf] < n_rows;
-      const float *fr = feats + (size_t)(ok ? rows[hf] : 0) * g.D;
+  for (int hf = 0; hf < 2; ++hf) {
+    rows[hf] = strip0 + w * 64 + hf * 32 + j;
+    const float *fr = feats + (size_t)(rows[hf] < n_rows ? rows[hf] : 0) * g.D;
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
-        const int d0 = 16 * c + 8 * h;
-        float *v = vv[hf][c], *q = qq[hf][c];
-        if ((g.D & 3) == 0) {
+    for (int c = 0; c < NK; ++c)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int d = d0 + 4 * u;
-            const float4 t = *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
-            const bool in = ok && d < g.D;
-            v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
-            v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
-          }
+      for (int u = 0; u < 2; ++u) ft[c][hf][u] = *reinterpret_cast<const float4 *>(fr + min(16 * c + 8 * h + 4 * u, g.D - 4));
+  }
+  // tables: [0, 16 NK) 2^kd, [16 NK, 32 NK) 2^kq, then per anchor component {16 NK linear terms (gconst at D), 16 NK
+  // quadratic ones -- both in the frames' balanced units --, max |dgconst|, max |dlinear|_2, 0, 0}
+  constexpr int TAB = 32 * NK + FB_FXW_ANCHORS * (32 * NK + 4);
+  float *tab = lds + SLOTB4 * 4;
+  for (int i = tid; i < TAB; i += 256) tab[i] = g.anchor[i];
+  __syncthreads();
+  FXW_STAMP(1);
+  float amax[2] = {1.0f, 1.0f};  // per frame: largest balanced |x|, x^2 (this lane's half of the dimensions)
+  // one group of eight dimensions of the two frames at a time, straight into the f16 fragments.  down != 1: the range
+  // shift's second pass (rare: reads the features again)
+  auto load_frames = [&](const float (&down)[2], const bool first) {
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      const int d0 = 16 * c + 8 * h;
+      const float4 *sx = reinterpret_cast<const float4 *>(tab + d0), *sq = reinterpret_cast<const float4 *>(tab + 16 * NK + d0);
+      const float4 x0 = sx[0], x1 = sx[1], y0 = sq[0], y1 = sq[1];
+      const float xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, yw[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bool ok = rows[hf] < n_rows;
+        float v[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d = d0 + 4 * u;
+          float4 t = ft[c][hf][u];
+          if (!first) t = *reinterpret_cast<const float4 *>(feats + (size_t)(ok ? rows[hf] : 0) * g.D + min(d, g.D - 4));
+          const bool in = ok && d < g.D;
+          v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
+          v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(v[i], v[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (d0 + i >= g.D && d0 + i < g.D + 3) ? 1.0f : v[i];  // against the constants' three terms
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = __fmul_rn(v[i], xw[i]); q[i] = __fmul_rn(q[i], yw[i]); }  // exact
+        if (first) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) amax[hf] = fmaxf(amax[hf], fmaxf(fabsf(v[i]), q[i]));
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
+          for (int i = 0; i < 8; ++i) { v[i] = __fmul_rn(v[i], down[hf]); q[i] = __fmul_rn(q[i], down[hf]); }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fmaxf(fabsf(v[i]), q[i]));
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (amax >= 32768.0f) {
-      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
-      sh = min(ex - 14, 100);
-    }
-    const float down = fb_pow2f(-sh);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int c = 0; c < NK; ++c) {
-        if (sh) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { vv[hf][c][i] = __fmul_rn(vv[hf][c][i], down); qq[hf][c][i] = __fmul_rn(qq[hf][c][i], down); }
-        }
-        fb_split2_frag(vv[hf][c], bx1[hf][c], bx2[hf][c]);
-        fb_split2_frag(qq[hf][c], bq1[hf][c], bq2[hf][c]);
+        fb_split2_frag(v, bx1[hf][c], bx2[hf][c]);
+        fb_split2_frag(q, bq1[hf][c], bq2[hf][c]);
         // only the base items use these: parked in accumulation registers, read from there by their MFMAs
         asm volatile("" : "+a"(bx2[hf][c]), "+a"(bq1[hf][c]), "+a"(bq2[hf][c]));
       }
+      __builtin_amdgcn_sched_barrier(0);  // one group at a time
+    }
+  };
+  const float one2[2] = {1.0f, 1.0f};
+  load_frames(one2, true);
+  FXW_STAMP(2);
+  // Range shift, per FRAME: a frame whose balanced values leave f16's range (|x| >= 181 spreads) is scaled down by a
+  // power of two of its own, its accumulators hold t 2^-sh, and the whole wave takes the rescue path for every update
+  // (`slow`), which multiplies each lane's values back -- by exactly 1 for the wave's other frames.
+  float up[2] = {1.0f, 1.0f};
+  bool any_shift = false;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) amax[hf] = fmaxf(amax[hf], __shfl_xor(amax[hf], 32, 64));
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(amax[0] >= 32768.0f || amax[1] >= 32768.0f) != 0ull, 0)) {
+    float down[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int ex = (int)((__float_as_uint(amax[hf]) >> 23) & 0xffu) - 127;
+      const int sh = amax[hf] >= 32768.0f ? min(ex - 14, 100) : 0;
+      down[hf] = fb_pow2f(-sh);
+      up[hf] = fb_pow2f(sh);
+    }
+    load_frames(down, false);
+    any_shift = true;
+  }
+  // The anchors' log2-likelihoods of the two frames, from the LEADING f16 term of the balanced frame operand (a lower
+  // bound with 64 to spare does not need more than its 11 bits; in the fragment pass the extra live values made hipcc
+  // spill ~85 registers -- 23 us of scratch traffic per workgroup, measured).  Each lane sums its 8 of every 16
+  // dimensions; |x|^2 in the same units for the Cauchy-Schwarz slack.
+  float lbest[2] = {-3.0e38f, -3.0e38f};
+  {
+    float xx[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < FB_FXW_ANCHORS; ++a) {
+      const float *at = tab + 32 * NK + a * (32 * NK + 4);
+      float lb[2] = {0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        const int d0 = 16 * c + 8 * h;
+        const float4 *tl = reinterpret_cast<const float4 *>(at + d0), *tq = reinterpret_cast<const float4 *>(at + 16 * NK + d0);
+        const float4 l0 = tl[0], l1 = tl[1], q0 = tq[0], q1 = tq[1];
+        const float lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f16x8 xh = __builtin_bit_cast(f16x8, bx1[hf][c]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = (float)xh[i], q = __fmul_rn(x, x);
+            lb[hf] = __fmaf_rn(lw[i], x, __fmaf_rn(qw[i], (d0 + i >= g.D) ? 0.0f : q, lb[hf]));
+            if (a == 0) xx[hf] = __fadd_rn(xx[hf], (d0 + i >= g.D) ? 0.0f : q);
+          }
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float full = lb[hf] + __shfl_xor(lb[hf], 32, 64), x2 = xx[hf] + __shfl_xor(xx[hf], 32, 64);
+        lbest[hf] = fmaxf(lbest[hf], full - at[32 * NK] - at[32 * NK + 1] * sqrtf(x2));
+      }
+    }
+  }
+  // the frames' reference R (see above fb_fxw_step): both lanes of a frame add the same two numbers.  A wave with the
+  // range shift keeps R = 0 and takes the rescue path for every update (`slow`, uniform over the wave)
+  const bool slow = any_shift;  // (the same in every lane: a scalar for the branches below)
+  float rc[2], rp[2], rn[2];  // reference of the current tile's accumulators, of the previous tile's, proposed for the next
+  // -R enters the quadratic item's accumulation through the K padding: the x^2 operand of frame j carries -(R mod 2048)
+  // at K = D + 3 and -(R div 2048) at K = D + 4 (integers below 2049: exact in f16), the quadratic item's image 1 and
+  // 2048 there (fb_load_gmm) -- no registers, no instructions.  The lanes that hold those K places patch their fragment.
+  auto set_ref = [&](const int hf, const float R) {
+    const float hi = truncf(__fmul_rn(R, 1.0f / 2048.0f)), lo = __fmaf_rn(hi, -2048.0f, R);
+    u32x4 f = bq1[hf][NK - 1];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int k = g.D + 3 + sidx - 16 * (NK - 1), el = k & 7;
+      const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(sidx == 0 ? -lo : -hi));
+      if ((k >> 3) == h) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u == (el >> 1)) f[u] = (el & 1) ? ((f[u] & 0x0000ffffu) | (bits << 16)) : ((f[u] & 0xffff0000u) | bits);
+      }
+    }
+    bq1[hf][NK - 1] = f;
+    asm volatile("" : "+a"(bq1[hf][NK - 1]));
+  };
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const float r0 = floorf(lbest[hf]) + FB_FXW_ROFF;
+    rc[hf] = slow ? 0.0f : fminf(fmaxf(r0, -4.0e6f), 4.0e6f);  // (the two K places hold |R| < 2^22)
+    rp[hf] = rc[hf];
+    rn[hf] = rc[hf];
+    set_ref(hf, rc[hf]);
   }
 #pragma unroll
-  for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
+  for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = rc[m & 1]; st_s[m * 256 + tid] = 0.0f; }
 
   const int tile0 = chunk_i * tiles_per_chunk;
   const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
   const int n_t = tile1 - tile0, total_items = n_t * NI;
   const u32x4 *gimg = g.images_fd + (size_t)tile0 * NI * IMG4;
-  const float unscale = fb_pow2f(sh - g.kacc), ls = __fmul_rn(FB_LOG2E_F, unscale);  // exact: a power of two
 
   // ---- parameter stream.  A workgroup barrier per item costs ~400 cycles at one wave per SIMD (the probe's mode 12
   // against 11), so the barrier is taken twice per TILE: slot A holds items 0 .. GA-1, slot B items GA .. NI-1.
@@ -353,36 +514,57 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   const int wv = __builtin_amdgcn_readfirstlane(w);
   const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
   auto item4 = [&](int jj) { return jj < GA ? jj * IMG4 : SLOTB4 + (jj - GA) * IMG4; };
-  auto update = [&](const f32x16 &v0, const f32x16 &v1, int model) {
-    fb_lse_update16(v0, st_m + (2 * model) * 256 + tid, st_s + (2 * model) * 256 + tid, ls);
-    fb_lse_update16(v1, st_m + (2 * model + 1) * 256 + tid, st_s + (2 * model + 1) * 256 + tid, ls);
+  // after a step that carried a fast update: the guard, and the rescue of the lanes that fail it (cold)
+  auto settle = [&](const f32x16 &p0, const f32x16 &p1, float *pm, float *ps, const float (&rt)[2], const FbFxwUpd &u) {
+    const bool b0 = !(u.sn0 <= FB_FXW_SMAX), b1 = !(u.sn1 <= FB_FXW_SMAX);
+    const bool any = __builtin_amdgcn_ballot_w64(b0 || b1) != 0ull;
+    FXW_COUNT(0);
+    if (__builtin_expect(slow || any, 0)) {
+      FXW_COUNT(1);
+      fb_fxw_slow_update(p0, up[0], rt[0], u.mo0, u.so0, pm, ps, rn[0], slow || b0);
+      fb_fxw_slow_update(p1, up[1], rt[1], u.mo1, u.so1, pm + 256, ps + 256, rn[1], slow || b1);
+    }
+  };
+  auto update = [&](const f32x16 &v0, const f32x16 &v1, int model) {  // the kernel's tail: every lane the classical way
+    float *pm = st_m + (2 * model) * 256 + tid, *ps = st_s + (2 * model) * 256 + tid;
+    fb_fxw_slow_update(v0, up[0], rc[0], pm[0], ps[0], pm, ps, rn[0], true);
+    fb_fxw_slow_update(v1, up[1], rc[1], pm[256], ps[256], pm + 256, ps + 256, rn[1], true);
   };
   auto publish = [&]() {  // everything this wave asked for has landed; the barrier publishes all four waves' pieces
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
+  // The base steps of the FIRST tile have no finished models to carry, and a branch for them costs more than a bogus
+  // update (nothing hides an instruction fetch at one wave per SIMD): they "update" the last two models with 16 values
+  // -1e30, whose exponentials are zero.
   f32x16 hq[2], acc[2][2], zero;  // acc[set][half]
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     hq[0][r] = 0.f; hq[1][r] = 0.f; zero[r] = 0.f;
-    acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+    acc[0][0][r] = -1.0e30f; acc[0][1][r] = -1.0e30f; acc[1][0][r] = -1.0e30f; acc[1][1][r] = -1.0e30f;
   }
-  {
-    // The base steps of the FIRST tile have no finished models to carry, and a branch for them costs more than a bogus
-    // update (nothing hides an instruction fetch at one wave per SIMD): they "update" the last two models with 16
-    // sentinel values -2^60 / unscale, whose scaled form is exactly -2^60 fl(log2 e) -- the state becomes (that
-    // maximum, 16), and the first real update rescales those 16 by 2^(-1.6e18) = 0.
-    const float sentinel = -fb_pow2f(60 - sh + g.kacc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][0][r] = sentinel; acc[0][1][r] = sentinel; acc[1][0][r] = sentinel; acc[1][1][r] = sentinel; }
-  }
+  FbFxwUpd uu;
+  FXW_STAMP(3);
   fb_fxw_fetch<GA, NPIECE>(gimg + lane, ring_lds, wv);  // group A of the first tile
   publish();
+  FXW_STAMP(4);
   u32x4 z1, z2;  // chunk 0 of the item in front (fb_fxw_step)
   constexpr int PW_A = (GA * NPIECE + 3) / 4, PW_B = (GB * NPIECE + 3) / 4;  // LDS-DMA pieces per wave for a group
   for (int t = 0; t < n_t; ++t) {
     const int it0 = t * NI;
+    // a rescue of the last tile proposed a new reference for some frame: from this tile on (the two deferred updates
+    // below still belong to the old one, rp)
+    rp[0] = rc[0]; rp[1] = rc[1];
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rn[0] > rc[0] || rn[1] > rc[1]) != 0ull, 0)) {
+      FXW_COUNT(2);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {  // the two lanes of a frame (its rows 0 .. 15 / 16 .. 31 of the tile) agree on the larger proposal
+        rn[hf] = fminf(fmaxf(rn[hf], __shfl_xor(rn[hf], 32, 64)), 4.0e6f);
+        rc[hf] = slow ? 0.0f : rn[hf];
+        set_ref(hf, rc[hf]);
+      }
+    }
     // this wave's share of the groups requested during this tile: group B of this tile (while A runs), group A of the
     // next one (while B runs); past the chunk's end the last group is read again and never used
     const u32x4 *srcB = gimg + (size_t)min(it0 + GA, total_items - GB) * IMG4 + (size_t)wv * (PW_B * 64) + lane;
@@ -423,38 +605,50 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       if (jj == 0) {
         if constexpr (DEFER) {
           float *pm = st_m + (2 * (M - 2)) * 256 + tid, *ps = st_s + (2 * (M - 2)) * 256 + tid;
-          fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+          fb_fxw_step<NK, 3, true, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, rp[0], rp[1], uu, dsrc, ddst, dq0, dn);
+          settle(acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, rp, uu);
         } else {
-          fb_fxw_step<NK, 3, false>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
+          fb_fxw_step<NK, 3, false, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], zero, zero, st_m, st_s, 0.f, 0.f, uu, dsrc, ddst, dq0, dn);
         }
       } else if (jj == 1) {
         float *pm = st_m + (2 * (M - 1)) * 256 + tid, *ps = st_s + (2 * (M - 1)) * 256 + tid;
-        fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+        fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, rp[0], rp[1], uu, dsrc, ddst, dq0, dn);
+        settle(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, rp, uu);
       } else if (jj == 2) {
         float *pm = st_m + tid, *ps = st_s + tid;
-        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], pm, ps, ls,
+        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], pm, ps, rc[0], rc[1], uu,
                                  dsrc, ddst, dq0, dn);
+        settle(hq[0], hq[1], pm, ps, rc, uu);
       } else if (DEFER && jj == NI - 1) {
         fb_fxw_step<NK, P, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                  zero, zero, st_m, st_s, ls, dsrc, ddst, dq0, dn);
+                                  zero, zero, st_m, st_s, 0.f, 0.f, uu, dsrc, ddst, dq0, dn);
       } else {
         float *pm = st_m + (2 * (jj - 2)) * 256 + tid, *ps = st_s + (2 * (jj - 2)) * 256 + tid;
         fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, ls, dsrc, ddst, dq0, dn);
+                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, rc[0], rc[1], uu, dsrc, ddst, dq0, dn);
+        settle(acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, rc, uu);
       }
       if (jj == GA - 1 || jj == NI - 1) publish();
     }
   }
+  FXW_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (M >= 3) update(acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], M - 2);
   update(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], M - 1);
+  FXW_STAMP(6);
 
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const float ms = st_m[(2 * m + hf) * 256 + tid];  // maximum of ll * 2^(kacc - sh)
-      const float mm = ms * unscale, ss = fb_lse_to_natural(ms, st_s[(2 * m + hf) * 256 + tid], ls);
+      // (mref, s) in log2 units -> the (m, sum exp(ll - m)) convention of the chunk merge / k_gmm_finalize:
+      // m = fl(mref ln 2); what the rounding leaves, d = mref ln 2 - m (|d| < 1e-4: the product's exact residual from
+      // an fma + mref times the constant's own error), is folded into s: s e^d = s (1 + d + d^2 / 2)
+      const float ms = st_m[(2 * m + hf) * 256 + tid], s0 = st_s[(2 * m + hf) * 256 + tid];
+      const float ln2f = 0.693147182464599609375f;                 // fl(ln 2); ln 2 - fl(ln 2) = -1.9046543e-9
+      const float mm = __fmul_rn(ms, ln2f);
+      const float dd = __fmaf_rn(ms, -1.9046542999e-9f, __fmaf_rn(ms, ln2f, -mm));
+      const float ss = __fmaf_rn(s0, __fmaf_rn(__fmul_rn(0.5f, dd), dd, dd), s0);
       const float m2 = __shfl_xor(mm, 32, 64), s2 = __shfl_xor(ss, 32, 64);
       const float mx = fmaxf(mm, m2);
       const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
@@ -464,6 +658,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
         part_s[o] = sx;
       }
     }
+  FXW_STAMP(7);
 }
 
 template <int NK, int M, int P>
@@ -504,8 +699,8 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
 #define FB_FXW_MAX_M 10  // (1 + M) 10 KB items + the state of 2 M x 256 frames: 156 KB of LDS at M = 10
 bool fb_gmm_use_wide(const FbGmmDev &g) {
   const bool off = getenv("FB_GMM_NARROW") != nullptr;  // read per call: the tests switch it inside one process
-  return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
-         g.M <= FB_FXW_MAX_M && g.item_model_host_q_first && g.delta_p >= 1 && g.images_fd != nullptr;
+  return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && (g.D & 3) == 0 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
+         g.M <= FB_FXW_MAX_M && g.item_model_host_q_first && g.delta_p >= 1 && g.images_fd != nullptr && g.anchor != nullptr;
 }
 void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
                         int n_chunks, int tpc, float *part_m, float *part_s) {

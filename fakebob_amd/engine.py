@@ -335,6 +335,14 @@ class Engine(object):
                                        C.byref(To)))
         return out[:tv.value].copy(), To.value
 
+    def debug_gmm_frames(self, feats):
+        """Per-frame log-likelihoods [M, T] of `feats` [T, D] from the GMM kernel the engine scores with (test hook)."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        T = feats.shape[0]
+        out = np.empty((self.n_models, T), np.float64)
+        N.check(self._L.fb_debug_gmm_frames(self._h, N.ptr(feats), C.c_int(T), N.ptr(out)))
+        return out
+
     def stats(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         N.check(self._L.fb_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

@@ -37,6 +37,11 @@ int fb_gmm_kernel_mode(fb_engine *e);
  * FB_GMM_DELTA_P forces it; FB_GMM_NARROW=1 selects k_gmm_fx2 instead).  Negative FB_E_* without a model. */
 int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms);
 
+/* the GMM kernel the engine scores with, on T rows of D features handed in as they are (no front-end): per-frame
+ * log-likelihoods out[m * T + t] of every model (gmm-global-get-frame-likes without --average).  Lets the tests reach
+ * inputs the front-end never produces: outliers, huge magnitudes, frames far from every component. */
+int fb_debug_gmm_frames(fb_engine *e, const float *feats, int T, double *out);
+
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
 int fb_debug_iv_active(fb_engine *e, int *n_active);

@@ -370,3 +370,89 @@ def test_more_than_ten_models_run_on_the_general_kernel(oracle, monkeypatch):
     finally:
         e.close()
     assert np.abs(raw_g - raw_o).max() <= 2e-5
+
+
+def _frame_lls(models, x):
+    """float64 reference of gmm-global-get-frame-likes: [M, T] from [T, D] features."""
+    x = np.asarray(x, np.float64)
+    out = []
+    for m in models:
+        ll = (m.gconsts.astype(np.float64)[None, :] + x @ m.means_invvars.astype(np.float64).T
+              - 0.5 * (x * x) @ m.inv_vars.astype(np.float64).T)
+        mx = ll.max(axis=1)
+        out.append(mx + np.log(np.exp(ll - mx[:, None]).sum(axis=1)))
+    return np.stack(out)
+
+
+def test_wide_kernel_reference_rescue_and_range_paths(monkeypatch):
+    """k_gmm_fx2w keeps its logsumexp relative to a per-frame reference R that starts from a lower bound (two anchor
+    components) and is repaired by a cold path when a tile's values run more than 2^100 above it; frames whose balanced
+    values leave f16's range take a shifted slow path.  The front-end never produces such frames, fb_debug_gmm_frames
+    does: rows drawn from the model, rows tens of sigmas away from every component (the rescue), rows of magnitude
+    1e3 .. 1e4 (the range shift), all-zero rows -- each against the float64 formula, for every delta variant P."""
+    D, C = 72, 512
+    ubm, spk = synthetic_gmm_system(n_speakers=5, C=C, D=D)
+    models = [ubm] + spk
+    rng = np.random.default_rng(7)
+    var = 1.0 / ubm.inv_vars.astype(np.float64)
+    mu = ubm.means_invvars.astype(np.float64) * var
+    ks = rng.integers(0, C, 700)
+    near = mu[ks] + np.sqrt(var[ks]) * rng.standard_normal((700, D))
+    sd = np.sqrt(var.mean(axis=0) + mu.var(axis=0))
+    far = mu[ks[:300]] + 25.0 * sd * rng.standard_normal((300, D))          # hundreds of nats below any anchor bound
+    onefar = near[:200].copy()
+    onefar[:, 3] += 60.0 * sd[3] * np.sign(rng.standard_normal(200))        # one dimension out: a narrow component may still win
+    huge = rng.standard_normal((130, D)) * np.logspace(3, 4, 130)[:, None]  # |x| sd^-1 > 181: the range shift
+    rows = np.concatenate([near, far, np.zeros((7, D)), onefar, huge, near[:50]]).astype(np.float32)
+    want = _frame_lls(models, rows)
+    for P in ("1", "2", "3"):
+        monkeypatch.setenv("FB_GMM_DELTA_P", P)
+        e = Engine(0)
+        try:
+            e.load_gmm(models)
+            assert e.gmm_kernel_variant == "fx2w/" + P
+            got = e.debug_gmm_frames(rows)
+        finally:
+            e.close()
+        assert np.isfinite(got).all()
+        rel = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+        print("P =", P, "max relative error %.2e (|ll| up to %.1e)" % (rel.max(), np.abs(want).max()))
+        # float32 accumulation at these magnitudes; with P < 3 a FRAME's speaker values carry the dropped products'
+        # ~1e-4 (random from frame to frame: the scores average hundreds of frames)
+        assert rel[0].max() <= 2e-6 and rel.max() <= (2e-6 if P == "3" else 1e-5)
+        sysd = np.abs((got[1:] - got[:1]) - (want[1:] - want[:1]))[:, :700]
+        assert sysd.max() <= 2e-3                      # per FRAME (the scores average hundreds of them)
+
+
+def test_wide_kernel_with_far_models_keeps_every_models_sum(monkeypatch):
+    """The reference's lower bound covers every model through a Cauchy-Schwarz slack on the deltas: models far from the
+    base one (unrelated means) must neither overflow nor lose their whole sum to underflow."""
+    D, C = 72, 256
+    ubm, _ = synthetic_gmm_system(n_speakers=1, C=C, D=D)
+    other, _ = synthetic_gmm_system(n_speakers=1, C=C, D=D, seed_ubm=99)
+    from fakebob_amd.models import DiagGmm
+    var = 1.0 / ubm.inv_vars.astype(np.float64)
+    w = np.full(C, 1.0 / C)
+    mu_far = (other.means_invvars.astype(np.float64) / other.inv_vars.astype(np.float64)) * 3.0 + 5.0
+    far = DiagGmm.from_internal(w, (mu_far / var).astype(np.float32), ubm.inv_vars)
+    base = DiagGmm.from_internal(w, ubm.means_invvars, ubm.inv_vars)
+    models = [base, far]
+    rng = np.random.default_rng(3)
+    mu = ubm.means_invvars.astype(np.float64) * var
+    ks = rng.integers(0, C, 400)
+    rows = np.concatenate([mu[ks[:200]] + np.sqrt(var[ks[:200]]) * rng.standard_normal((200, D)),
+                           mu_far[ks[200:]] + np.sqrt(var[ks[200:]]) * rng.standard_normal((200, D))]).astype(np.float32)
+    want = _frame_lls(models, rows)
+    e = Engine(0)
+    try:
+        e.load_gmm(models)
+        assert e.gmm_kernel_variant.startswith("fx2w/")
+        got = e.debug_gmm_frames(rows)
+    finally:
+        e.close()
+    assert np.isfinite(got).all()
+    # the far model's value is the base model's plus a delta of the same size: float32 accumulation rounds at the
+    # larger of the two magnitudes (a frame near the far model is thousands of nats from the base one)
+    rel = np.abs(got - want) / np.maximum(1.0, np.abs(want).max(axis=0, keepdims=True))
+    print("far models: max error %.2e of the larger |ll| (up to %.1e)" % (rel.max(), np.abs(want).max()))
+    assert rel.max() <= 5e-6
