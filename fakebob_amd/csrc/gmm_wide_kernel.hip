@@ -143,8 +143,10 @@ __device__ __forceinline__ float fb_v_max3(float a, float b, float c) {
 // operand's padding (set_ref in the kernel): a finished accumulator holds t = ll * log2 e - R, and a value costs ONE
 // v_exp_f32 and ONE v_add_f32 -- no running maximum, no subtraction (204 v_fma_f32 and 108 v_max3_f32 of the 850
 // vector instructions per tile gone; the steps of the delta items are bound by the vector issue port).
-//   state per (frame half, model) in LDS: (mref, s), sum_k 2^(ll_k log2 e) = s * 2^mref; mref an integer-valued float
-//   fast update:  s += (sum_i 2^t_i) * 2^(R_tile - mref)            [the factor is 1 unless a rescue moved one of them]
+//   state per (frame half, model) in LDS: (mref, s), sum_k 2^(ll_k log2 e) = s * 2^mref; mref an integer-valued float,
+//                 equal to the frame's R wherever a fast update meets it (the tile boundary that moves R moves every
+//                 model's state along; the fast path never reads mref)
+//   fast update:  s += sum_i 2^t_i        [times 2^(R_old - R_new) for the two updates deferred across a moved reference]
 //   guard:        s <= 2^100 (false for inf and NaN too), else the RESCUE below redoes the update from the accumulator
 //                 registers -- still there -- the classical way (maximum, re-reference) and proposes a new R for the
 //                 next tile.  Cold code behind the loop (~2.4 us per visit, mostly instruction fetch), taken by the
@@ -179,7 +181,7 @@ extern "C" int fb_debug_fxw_stamps(unsigned long long *out) {
 #endif
 #define FB_FXW_ROFF 64.0f
 #define FB_FXW_SMAX 1.2676506002282294e30f  // 2^100
-struct FbFxwUpd { float mo0, mo1, so0, so1, sn0, sn1; };  // state before / sums after a fast update (halves 0, 1)
+struct FbFxwUpd { float so0, so1, sn0, sn1; };  // sums before / after a fast update (halves 0, 1)
 
 // the rescue: fold the 16 values p (t * 2^-sh, relative to rt) into (mo, so) with a maximum; lanes with `need` store
 __device__ __forceinline__ void fb_fxw_slow_update(const f32x16 &p, float up, float rt, float mo, float so,
@@ -213,14 +215,15 @@ __device__ __forceinline__ float fb_v_sub(float a, float b) {
 // One wave per SIMD issues in order; about five plain vector instructions behind an MFMA are free, what exceeds them
 // adds to the step.  Left alone hipcc lumps the vector instructions of an update behind the MFMAs (kernel time =
 // MFMA time + update time, measured), so the step is cut into one scheduling region per MFMA
-// (__builtin_amdgcn_sched_barrier(0)) and each region gets its share of the 19 slices of the update of the pending set
-// (p0, p1 = the two halves' 16 values each, pm / ps their LDS state [2 halves][256], rt0 / rt1 the reference the set
-// was computed against):
-//   slice  0       the state is requested from LDS
-//   slices 1..16   one value of each half: its exponential, and the ADD of the previous slice's exponentials (no
-//                  exponential is consumed right behind itself); even and odd values are summed apart
-//   slice  17      last add, 2^(rt - mref)
-//   slice  18      s + sum * 2^(rt - mref) written back; the caller checks it (guard above)
+// (__builtin_amdgcn_sched_barrier(0)) and each region gets its share of the 20 slices of the update of the pending set
+// (p0, p1 = the two halves' 16 values each, ps their sums in LDS [2 halves][256]; DEFERRED: the set belongs to the
+// previous tile, wd0 / wd1 = 2^(that tile's reference - this one's), 1 unless a rescue came between):
+//   slice  0       the sums are requested from LDS
+//   slices 1..16   one value of each half: its exponential
+//   slices 3..18   the ADD of the exponentials issued two slices earlier -- in another gap, so that no addition reads
+//                  a transcendental result with nothing but transcendentals in between (an s_nop each); even and odd
+//                  values are summed apart
+//   slice  19      sums written back; the caller checks them (guard above)
 // NP = partial products per K chunk: 3 (a2 b1 + a1 b2 + a1 b1: the full two-term product, 30 MFMAs per step), 2
 // (a2 b1 + a1 b1: both parameter terms against the leading frame term, 20 MFMAs) or 1 (a1 b1, 10 MFMAs) -- the delta
 // items of k_gmm_fx2w.
@@ -229,16 +232,15 @@ __device__ __forceinline__ float fb_v_sub(float a, float b) {
 // item's chunk 0 when pf0) -- 24 registers instead of two whole items' 80.
 // The LDS-DMA pieces [dq0, dq0 + dn) of this wave's share of the next parameter group go out one per chunk.
 // UPD = false: no pending set.
-template <int NK, int NP, bool UPD, bool ZI = false>
+template <int NK, int NP, bool UPD, bool ZI = false, bool DEFERRED = false>
 __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, const u32x4 *__restrict__ nxt4, const bool pf0,
                                             int lane, u32x4 &z1, u32x4 &z2, const u32x4 (&b1)[2][NK],
                                             const u32x4 (&b2)[2][NK], const f32x16 &init0, const f32x16 &init1,
                                             f32x16 &out0, f32x16 &out1, const f32x16 &p0, const f32x16 &p1,
-                                            float *__restrict__ pm, float *__restrict__ ps, const float rt0, const float rt1,
-                                            FbFxwUpd &u,
+                                            float *__restrict__ ps, const float wd0, const float wd1, FbFxwUpd &u,
                                             const u32x4 *__restrict__ dsrc, unsigned ddst, const int dq0, const int dn) {
   constexpr int KP = 2 * NP, NG = KP * NK;  // MFMAs per chunk / per step
-  constexpr int NS = 19;                    // slices of an update
+  constexpr int NS = 20;                    // slices of an update
   static_assert(NP >= 1 && NP <= 3 && NG >= 10, "slice layout");
   f32x16 x0, x1;  // ZI: from zero -- a literal C operand of the first MFMAs, no registers to clear
   if constexpr (ZI) {
@@ -253,8 +255,7 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
   constexpr int PD = NP == 1 ? 2 : 1;
   u32x4 s1[PD + 1], s2[PD + 1];
   float se0 = 0.f, se1 = 0.f, sd0 = 0.f, sd1 = 0.f;  // sums of the even / odd values, halves 0 / 1
-  float e0 = 0.f, e1 = 0.f;                          // the previous slice's exponentials
-  float w0 = 0.f, w1 = 0.f;
+  float ea0 = 0.f, ea1 = 0.f, eb0 = 0.f, eb1 = 0.f;  // the exponentials of the last two slices (a: older)
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int c = g / KP, kk = g % KP;
@@ -279,25 +280,25 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
     }
     if (kk == (KP > 3 ? 3 : KP - 1) && c < dn) fb_glds16(dsrc + (dq0 + c) * 64, ddst + (unsigned)(dq0 + c) * 1024u);
     if constexpr (UPD) {
-      const int sl0 = (g * NS) / NG, sl1 = ((g + 1) * NS) / NG;  // the 19 slices dealt evenly over the gaps
+      const int sl0 = (g * NS) / NG, sl1 = ((g + 1) * NS) / NG;  // the 20 slices dealt evenly over the gaps
 #pragma unroll
       for (int sl = sl0; sl < sl1; ++sl) {
-        if (sl == 0) {
-          u.mo0 = pm[0]; u.mo1 = pm[256]; u.so0 = ps[0]; u.so1 = ps[256];
-        } else if (sl <= 16) {
-          const int r = sl - 1;
-          const float f0 = fb_v_exp(p0[r]), f1 = fb_v_exp(p1[r]);
-          if (r == 1) { se0 = e0; se1 = e1; }                                        // value 0 starts the even sums
-          else if (r == 2) { sd0 = e0; sd1 = e1; }                                   // value 1 the odd ones
-          else if (r >= 3 && (r & 1)) { se0 = fb_v_add(se0, e0); se1 = fb_v_add(se1, e1); }  // value r - 1 is even
-          else if (r >= 3) { sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1); }
-          e0 = f0; e1 = f1;
-        } else if (sl == 17) {
-          sd0 = fb_v_add(sd0, e0); sd1 = fb_v_add(sd1, e1);                          // value 15
-          w0 = fb_v_exp(fb_v_sub(rt0, u.mo0)); w1 = fb_v_exp(fb_v_sub(rt1, u.mo1));
-        } else {
-          u.sn0 = fb_v_fma(fb_v_add(se0, sd0), w0, u.so0);
-          u.sn1 = fb_v_fma(fb_v_add(se1, sd1), w1, u.so1);
+        // value r's exponential is added TWO slices after it was issued: with two slices in a gap an addition would
+        // otherwise read a transcendental result with only transcendentals in between -- an s_nop each, 70 per tile
+        const int r = sl - 1;          // the value whose exponential this slice issues (0 .. 15)
+        const int ra = sl - 3;         // the value this slice adds (its exponential is ea)
+        if (sl == 0) { u.so0 = ps[0]; u.so1 = ps[256]; }
+        if (ra == 0) { se0 = ea0; se1 = ea1; }                                        // value 0 starts the even sums
+        else if (ra == 1) { sd0 = ea0; sd1 = ea1; }                                   // value 1 the odd ones
+        else if (ra >= 2 && ra <= 15 && !(ra & 1)) { se0 = fb_v_add(se0, ea0); se1 = fb_v_add(se1, ea1); }
+        else if (ra >= 2 && ra <= 15) { sd0 = fb_v_add(sd0, ea0); sd1 = fb_v_add(sd1, ea1); }
+        ea0 = eb0; ea1 = eb1;
+        if (r >= 0 && r <= 15) { eb0 = fb_v_exp(p0[r]); eb1 = fb_v_exp(p1[r]); }
+        if (sl == NS - 1) {  // (value 15 was added in this slice: ra = 16 - ... see the static_assert below)
+          // the state is relative to the set's reference unless a rescue moved the frame's reference between the tile
+          // the set belongs to and this one: wd is 2^(old - new) then, 1 otherwise (kernel, tile boundary)
+          u.sn0 = DEFERRED ? fb_v_fma(fb_v_add(se0, sd0), wd0, u.so0) : fb_v_add(fb_v_add(se0, sd0), u.so0);
+          u.sn1 = DEFERRED ? fb_v_fma(fb_v_add(se1, sd1), wd1, u.so1) : fb_v_add(fb_v_add(se1, sd1), u.so1);
           ps[0] = u.sn0; ps[256] = u.sn1;
         }
       }
@@ -514,15 +515,17 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   const int wv = __builtin_amdgcn_readfirstlane(w);
   const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
   auto item4 = [&](int jj) { return jj < GA ? jj * IMG4 : SLOTB4 + (jj - GA) * IMG4; };
-  // after a step that carried a fast update: the guard, and the rescue of the lanes that fail it (cold)
+  // after a step that carried a fast update: the guard -- the new sums' bit patterns, as unsigned integers, against
+  // 2^100's (+ 1: inf, NaN and anything negative lie above it; 0 for a wave on the rescue path: always) -- and the
+  // rescue of the lanes that fail it (cold)
+  const unsigned guard = slow ? 0u : __float_as_uint(FB_FXW_SMAX) + 1u;
   auto settle = [&](const f32x16 &p0, const f32x16 &p1, float *pm, float *ps, const float (&rt)[2], const FbFxwUpd &u) {
-    const bool b0 = !(u.sn0 <= FB_FXW_SMAX), b1 = !(u.sn1 <= FB_FXW_SMAX);
-    const bool any = __builtin_amdgcn_ballot_w64(b0 || b1) != 0ull;
+    const unsigned worst = max(__float_as_uint(u.sn0), __float_as_uint(u.sn1));
     FXW_COUNT(0);
-    if (__builtin_expect(slow || any, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst >= guard) != 0ull, 0)) {
       FXW_COUNT(1);
-      fb_fxw_slow_update(p0, up[0], rt[0], u.mo0, u.so0, pm, ps, rn[0], slow || b0);
-      fb_fxw_slow_update(p1, up[1], rt[1], u.mo1, u.so1, pm + 256, ps + 256, rn[1], slow || b1);
+      fb_fxw_slow_update(p0, up[0], rt[0], pm[0], u.so0, pm, ps, rn[0], __float_as_uint(u.sn0) >= guard);
+      fb_fxw_slow_update(p1, up[1], rt[1], pm[256], u.so1, pm + 256, ps + 256, rn[1], __float_as_uint(u.sn1) >= guard);
     }
   };
   auto update = [&](const f32x16 &v0, const f32x16 &v1, int model) {  // the kernel's tail: every lane the classical way
@@ -545,6 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     acc[0][0][r] = -1.0e30f; acc[0][1][r] = -1.0e30f; acc[1][0][r] = -1.0e30f; acc[1][1][r] = -1.0e30f;
   }
   FbFxwUpd uu;
+  float wd[2] = {1.0f, 1.0f};  // 2^(rp - rc): the factor of the two deferred updates behind a moved reference
   FXW_STAMP(3);
   fb_fxw_fetch<GA, NPIECE>(gimg + lane, ring_lds, wv);  // group A of the first tile
   publish();
@@ -556,13 +560,25 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     // a rescue of the last tile proposed a new reference for some frame: from this tile on (the two deferred updates
     // below still belong to the old one, rp)
     rp[0] = rc[0]; rp[1] = rc[1];
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rn[0] > rc[0] || rn[1] > rc[1]) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rn[0] > rc[0] || rn[1] > rc[1] || wd[0] != 1.0f || wd[1] != 1.0f) != 0ull, 0)) {
       FXW_COUNT(2);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {  // the two lanes of a frame (its rows 0 .. 15 / 16 .. 31 of the tile) agree on the larger proposal
         rn[hf] = fminf(fmaxf(rn[hf], __shfl_xor(rn[hf], 32, 64)), 4.0e6f);
         rc[hf] = slow ? 0.0f : rn[hf];
         set_ref(hf, rc[hf]);
+        // the fast updates add to sums that are relative to rc: every model's state moves to the new reference (a model
+        // the rescue re-referenced on its own comes back too), and the two deferred updates below, whose values are
+        // relative to rp, take the factor 2^(rp - rc) -- 1 again from the next boundary on
+        wd[hf] = __builtin_amdgcn_exp2f(rp[hf] - rc[hf]);
+        if (!slow) {
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            float *pm = st_m + (2 * m + hf) * 256 + tid, *ps = st_s + (2 * m + hf) * 256 + tid;
+            *ps = *ps * __builtin_amdgcn_exp2f(*pm - rc[hf]);
+            *pm = rc[hf];
+          }
+        }
       }
     }
     // this wave's share of the groups requested during this tile: group B of this tile (while A runs), group A of the
@@ -605,27 +621,27 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       if (jj == 0) {
         if constexpr (DEFER) {
           float *pm = st_m + (2 * (M - 2)) * 256 + tid, *ps = st_s + (2 * (M - 2)) * 256 + tid;
-          fb_fxw_step<NK, 3, true, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, rp[0], rp[1], uu, dsrc, ddst, dq0, dn);
+          fb_fxw_step<NK, 3, true, true, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], ps, wd[0], wd[1], uu, dsrc, ddst, dq0, dn);
           settle(acc[(M - 2) & 1][0], acc[(M - 2) & 1][1], pm, ps, rp, uu);
         } else {
-          fb_fxw_step<NK, 3, false, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], zero, zero, st_m, st_s, 0.f, 0.f, uu, dsrc, ddst, dq0, dn);
+          fb_fxw_step<NK, 3, false, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[0], hq[1], zero, zero, st_s, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
         }
       } else if (jj == 1) {
         float *pm = st_m + (2 * (M - 1)) * 256 + tid, *ps = st_s + (2 * (M - 1)) * 256 + tid;
-        fb_fxw_step<NK, 3, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, rp[0], rp[1], uu, dsrc, ddst, dq0, dn);
+        fb_fxw_step<NK, 3, true, false, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], hq[0], hq[1], acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], ps, wd[0], wd[1], uu, dsrc, ddst, dq0, dn);
         settle(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, rp, uu);
       } else if (jj == 2) {
         float *pm = st_m + tid, *ps = st_s + tid;
-        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], pm, ps, rc[0], rc[1], uu,
+        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], ps, 1.f, 1.f, uu,
                                  dsrc, ddst, dq0, dn);
         settle(hq[0], hq[1], pm, ps, rc, uu);
       } else if (DEFER && jj == NI - 1) {
         fb_fxw_step<NK, P, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                  zero, zero, st_m, st_s, 0.f, 0.f, uu, dsrc, ddst, dq0, dn);
+                                  zero, zero, st_s, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
       } else {
         float *pm = st_m + (2 * (jj - 2)) * 256 + tid, *ps = st_s + (2 * (jj - 2)) * 256 + tid;
         fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, rc[0], rc[1], uu, dsrc, ddst, dq0, dn);
+                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], ps, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
         settle(acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, rc, uu);
       }
       if (jj == GA - 1 || jj == NI - 1) publish();
