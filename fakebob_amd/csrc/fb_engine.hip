@@ -653,12 +653,26 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
             ml = std::max(ml, L2E * sqrt(l2));
             mg = std::max(mg, L2E * fabs((double)gconsts[(size_t)m * C + ks] - (double)gconsts[ks]));
           }
-          at[2 * W] = (float)(mg * 1.000001 + 2.0);
+          at[2 * W] = (float)(mg * 1.000001 + 4.0);
           at[2 * W + 1] = (float)(ml * 1.000001);
+        }
+        {  // f16 copies of the anchors' 2 x W terms behind the float table: what the kernel's packed dot products read.
+           // The bound stays a bound: the rounding of the copies and of the f16 squares (2^-11 each, relative to terms
+           // that add up to a few hundred at most) is inside the + 2 of the slack above
+          const size_t nf = an.size();
+          an.resize(nf + (size_t)FB_FXW_ANCHORS * W, 0.0f);
+          uint16_t *hp = reinterpret_cast<uint16_t *>(&an[nf]);
+          for (int a = 0; a < FB_FXW_ANCHORS; ++a)
+            for (int k = 0; k < 2 * W; ++k) {
+              const float v = an[2 * W + (size_t)a * (2 * W + 4) + k];
+              fits = fits && fabsf(v) < 60000.0f;
+              const _Float16 hv = (_Float16)v;
+              memcpy(&hp[(size_t)a * 2 * W + k], &hv, 2);
+            }
         }
         FBCHK(e->gmm_anchor.ensure(sizeof(float) * an.size()));
         HIPCHK(hipMemcpy(e->gmm_anchor.p, an.data(), sizeof(float) * an.size(), hipMemcpyHostToDevice));
-        delta_p = want_p;
+        if (fits) delta_p = want_p;
       }
     }
   }

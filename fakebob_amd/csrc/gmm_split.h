@@ -11,20 +11,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fb_pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
+// v[8] -> two packed f16x8 fragments, v = f1 + f2 to 22 bits: f1 = f16(v) (round to nearest even), f2 = f16(v - f1) --
+// the residual is exact in f32 (possibly a subnormal f16, which the matrix pipe keeps).  Four instructions per pair of
+// values: v_cvt_pk_f16_f32, two v_fma_mix_f32 (x - f1 straight from the packed halves: no conversion back), v_cvt_pk_f16_f32.
 __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u32x4 &f2) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f16x2 a, b;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float x = v[2 * i + u];
-      const _Float16 x1 = (_Float16)x;                                   // round to nearest even
-      const float r = __fsub_rn(x, (float)x1);  // exact; possibly a subnormal f16, which the matrix pipe keeps
-      a[u] = x1;
-      b[u] = (_Float16)r;
-    }
-    f1[i] = __builtin_bit_cast(unsigned, a);
-    f2[i] = __builtin_bit_cast(unsigned, b);
+    unsigned a, b;
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(v[2 * i]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(v[2 * i + 1]));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(b) : "v"(r0), "v"(r1));
+    f1[i] = a;
+    f2[i] = b;
   }
 }
 

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   // quadratic ones -- both in the frames' balanced units --, max |dgconst|, max |dlinear|_2, 0, 0}
   constexpr int TAB = 32 * NK + FB_FXW_ANCHORS * (32 * NK + 4);
   float *tab = lds + SLOTB4 * 4;
-  for (int i = tid; i < TAB; i += 256) tab[i] = g.anchor[i];
+  constexpr int TABH = FB_FXW_ANCHORS * 16 * NK;  // + the anchors' f16 copies, two per float
+  for (int i = tid; i < TAB + TABH; i += 256) tab[i] = g.anchor[i];
   __syncthreads();
   FXW_STAMP(1);
   float amax[2] = {1.0f, 1.0f};  // per frame: largest balanced |x|, x^2 (this lane's half of the dimensions)
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
           const int d = d0 + 4 * u;
           float4 t = ft[c][hf][u];
           if (!first) t = *reinterpret_cast<const float4 *>(feats + (size_t)(ok ? rows[hf] : 0) * g.D + min(d, g.D - 4));
-          const bool in = ok && d < g.D;
+          // (a row past the end of the batch repeats row 0, its results are not stored; NK chunks: 16 (NK - 1) <= D)
+          const bool in = c < NK - 1 || d < g.D;
           v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
           v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
         }
@@ -436,31 +438,54 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   // dimensions; |x|^2 in the same units for the Cauchy-Schwarz slack.
   float lbest[2] = {-3.0e38f, -3.0e38f};
   {
+    // (packed f16: x'^2 by v_pk_mul_f16 -- below 32768 in a wave without range shift --, the sums by v_dot2_f32_f16 with
+    //  f32 accumulation; the tables' f16 copies stand behind their f32 ones: tab + TAB, fb_load_gmm's layout in halves)
+    const _Float16 *tabh = reinterpret_cast<const _Float16 *>(tab + TAB);
+    f16x2 xs[2][NK][4];  // x'^2, zero past D
     float xx[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int c = 0; c < NK; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned xw_ = bx1[hf][c][u];  // (a copy first: __builtin_bit_cast of a vector ELEMENT reads element 0, hipcc 7.2)
+          const f16x2 x = __builtin_bit_cast(f16x2, xw_);
+          f16x2 q = x * x;
+          const int d = 16 * c + 8 * h + 2 * u;
+          if (c == NK - 1) { if (d >= g.D) q[0] = (_Float16)0.0f; if (d + 1 >= g.D) q[1] = (_Float16)0.0f; }
+          xs[hf][c][u] = q;
+          xx[hf] = __builtin_amdgcn_fdot2(x, x, xx[hf], false);
+        }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {  // (the three constants' places hold 1.0: not part of |x|^2)
+      const int lo = 16 * (NK - 1) + 8 * h;
+      float ones = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ones += (lo + i >= g.D && lo + i < g.D + 3) ? 1.0f : 0.0f;
+      xx[hf] -= ones;
+    }
 #pragma unroll
     for (int a = 0; a < FB_FXW_ANCHORS; ++a) {
       const float *at = tab + 32 * NK + a * (32 * NK + 4);
+      const _Float16 *ah = tabh + a * (32 * NK);
       float lb[2] = {0.0f, 0.0f};
 #pragma unroll
       for (int c = 0; c < NK; ++c) {
         const int d0 = 16 * c + 8 * h;
-        const float4 *tl = reinterpret_cast<const float4 *>(at + d0), *tq = reinterpret_cast<const float4 *>(at + 16 * NK + d0);
-        const float4 l0 = tl[0], l1 = tl[1], q0 = tq[0], q1 = tq[1];
-        const float lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const u32x4 lw = *reinterpret_cast<const u32x4 *>(ah + d0), qw = *reinterpret_cast<const u32x4 *>(ah + 16 * NK + d0);
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const f16x8 xh = __builtin_bit_cast(f16x8, bx1[hf][c]);
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float x = (float)xh[i], q = __fmul_rn(x, x);
-            lb[hf] = __fmaf_rn(lw[i], x, __fmaf_rn(qw[i], (d0 + i >= g.D) ? 0.0f : q, lb[hf]));
-            if (a == 0) xx[hf] = __fadd_rn(xx[hf], (d0 + i >= g.D) ? 0.0f : q);
+          for (int u = 0; u < 4; ++u) {
+            const unsigned lu = lw[u], qu = qw[u], xu = bx1[hf][c][u];
+            lb[hf] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, lu), __builtin_bit_cast(f16x2, xu), lb[hf], false);
+            lb[hf] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, qu), xs[hf][c][u], lb[hf], false);
           }
-        }
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const float full = lb[hf] + __shfl_xor(lb[hf], 32, 64), x2 = xx[hf] + __shfl_xor(xx[hf], 32, 64);
+        const float full = lb[hf] + __shfl_xor(lb[hf], 32, 64), x2 = fmaxf(xx[hf] + __shfl_xor(xx[hf], 32, 64), 0.0f);
         lbest[hf] = fmaxf(lbest[hf], full - at[32 * NK] - at[32 * NK + 1] * sqrtf(x2));
       }
     }
