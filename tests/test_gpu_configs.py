@@ -25,6 +25,8 @@ FRONTENDS = [
     dict(raw_energy=0),                                              # energy after pre-emphasis and windowing (k_mfcc_r16<12, false>)
     dict(raw_energy=0, frame_length=320, frame_shift=160),           # ... with a short window (k_mfcc_r16<0, false>)
     dict(frame_length=320, frame_shift=160),                         # k_mfcc_r16<0, true>
+    dict(num_ceps=17, num_mel_bins=23, delta_order=3, delta_window=2),  # D = 68: k_gmm_fx2w with other K padding places
+    dict(num_ceps=16, num_mel_bins=23, delta_order=3, delta_window=2),  # D = 64: ... and a whole spare half chunk
 ]
 
 
@@ -37,6 +39,8 @@ def test_frontend_and_scores_for_other_configs(oracle, over):
         D = e.feat_dim
         ubm, spk = synthetic_gmm_system(n_speakers=2, C=96, D=D)
         e.load_gmm([ubm] + spk)
+        # the one-wave-per-SIMD kernel takes D = 64, 68, 72 (K padded to 80 with room for the constants and the reference)
+        assert e.gmm_kernel_variant.startswith("fx2w/") == (D in (64, 68, 72))
         wavs = [_wav(0, 24000), _wav(1, 9000), _wav(2, 40000)]
         for w in wavs[:2]:
             fg, Tg = e.debug_feats(w)
