@@ -127,16 +127,6 @@ __device__ __forceinline__ float fb_v_add(float a, float b) {
   asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-__device__ __forceinline__ float fb_v_mul(float a, float b) {
-  float d;
-  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ float fb_v_max3(float a, float b, float c) {
-  float d;
-  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
 
 // The logsumexp state of k_gmm_fx2w (round 3, second form).  The parameter images carry log2 e (fb_load_gmm) and the
 // quadratic item's accumulation includes -R, R an integer reference per frame that stands in two K places of the x^2
@@ -203,12 +193,6 @@ __device__ __forceinline__ void fb_fxw_slow_update(const f32x16 &p, float up, fl
     *ps = __fadd_rn(a0, a1);
     rn = fmaxf(rn, mn);
   }
-}
-
-__device__ __forceinline__ float fb_v_sub(float a, float b) {
-  float d;
-  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
 }
 
 // One item step with the logsumexp update of ANOTHER accumulator set threaded between the MFMAs, by construction.
