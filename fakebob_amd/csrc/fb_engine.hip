@@ -894,9 +894,11 @@ static int run_post_mfcc(fb_engine *e, int B) {
     FBCHK(e->vad_counter.ensure(sizeof(int)));
     HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), s));
   }
-  if (e->cfg.compress_feats) {  // make_mfcc.sh's `copy-feats --compress=true`: what VAD / deltas / CMVN read
-    fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);
-  }
+  // make_mfcc.sh's `copy-feats --compress=true`: what VAD / deltas / CMVN read.  The one-launch kernel below takes the
+  // round trip along on its LDS copy of the matrix when it can (utterances of up to 512 frames: every NES batch)
+  const bool cm = e->cfg.compress_feats != 0;
+  const bool cm_fused = cm && fb_fuse_on(e) && fb_vad_delta_cmvn_compresses(e->t_max);
+  if (cm && !cm_fused) fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);
   {  // every utterance fits the CMVN window (all NES batches): VAD, deltas, CMVN and the row offsets in one launch
     const size_t had = e->vad_pub.cap;
     FBCHK(e->vad_pub.ensure(sizeof(unsigned long long) * (size_t)B));
@@ -906,10 +908,11 @@ static int run_post_mfcc(fb_engine *e, int B) {
     }
     if (fb_fuse_on(e) && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                              e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
-                                             e->row_off.as<int>(), e->feats.as<float>())) {
+                                             e->row_off.as<int>(), e->feats.as<float>(), cm_fused ? e->mfcc.as<float>() : nullptr)) {
       e->vad_epoch += 1;
       return FB_OK;
     }
+    if (cm_fused) fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);  // (the batch did not qualify)
   }
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>(),
                 e->vad_counter.as<int>(), e->row_off.as<int>());

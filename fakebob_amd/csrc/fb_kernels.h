@@ -105,9 +105,12 @@ void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, co
                    int *vrank, int *tv, int *counter, int *row_off);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
 // VAD + deltas + CMVN + voiced-row compaction of a batch whose utterances fit the CMVN window, one launch
+// cm_out != nullptr (allowed when fb_vad_delta_cmvn_compresses(t_max)): the kernel also takes fb_launch_feat_compress's
+// place -- the round trip on its LDS copy of the matrix, the compressed matrix written to cm_out (may be mfcc itself)
+bool fb_vad_delta_cmvn_compresses(int t_max);
 bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                               int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                              float *feats);
+                              float *feats, float *cm_out);
 bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
                           const int *vrank, const int *row_off, int B, int t_max, float *feats);
 // add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk

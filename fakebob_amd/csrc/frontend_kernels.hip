@@ -716,6 +716,37 @@ __device__ __forceinline__ float fb_key_float(unsigned k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 #define FB_CM_REG 8  // keys per lane held in registers: columns of up to 512 frames
+// The column header of a CompressedMatrix column whose order-preserving keys a wave holds in registers (lane l: elements
+// l, 64 + l, ..; 0xffffffff past T): the quartile elements by bisection on the keys (32 rounds of compare + ballot +
+// scalar popcount: the decisions are wave-uniform), then Kaldi's percentile values p0 < p25 < p75 < p100.
+// clo / chi: the column's minimum / maximum.  Shared by k_feat_compress and k_vad_delta_cmvn.
+__device__ __forceinline__ void fb_cm_column_header(const unsigned (&kr)[FB_CM_REG], int T, float minv, float range, float clo,
+                                                    float chi, float &p0, float &p25, float &p75, float &p100) {
+  const int q = T / 4;
+  unsigned k25 = 0u, k75 = 0u;  // the element of rank r (0-based) is the largest key k with #{x : key(x) < k} <= r
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned c25 = k25 | (1u << bit), c75 = k75 | (1u << bit);
+    int n25 = 0, n75 = 0;
+#pragma unroll
+    for (int r = 0; r < FB_CM_REG; ++r) {
+      if (64 * r < T) {  // wave-uniform
+        n25 += __popcll(__ballot(kr[r] < c25));
+        n75 += __popcll(__ballot(kr[r] < c75));
+      }
+    }
+    if (n25 <= q) k25 = c25;
+    if (n75 <= 3 * q) k75 = c75;
+  }
+  const float v25 = fb_key_float(k25), v75 = fb_key_float(k75);
+  const int u0 = min(fb_cm_to_u16(minv, range, clo), 65532);
+  const int u25 = min(max(fb_cm_to_u16(minv, range, v25), u0 + 1), 65533);
+  const int u75 = min(max(fb_cm_to_u16(minv, range, v75), u25 + 1), 65534);
+  const int u100 = max(fb_cm_to_u16(minv, range, chi), u75 + 1);
+  p0 = fb_cm_from_u16(minv, range, u0);
+  p25 = fb_cm_from_u16(minv, range, u25);
+  p75 = fb_cm_from_u16(minv, range, u75);
+  p100 = fb_cm_from_u16(minv, range, u100);
+}
 __global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc, const int *__restrict__ frame_off,
                                                        int nc, int lds_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_key[];  // [4 waves][lds_cap]
@@ -1065,11 +1096,12 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
                                                          const int *__restrict__ frame_off, int B, int t_cap,
                                                          unsigned epoch, int *__restrict__ ticket,
                                                          unsigned long long *__restrict__ pub, int *__restrict__ tv,
-                                                         int *__restrict__ row_off, float *__restrict__ feats) {
+                                                         int *__restrict__ row_off, float *__restrict__ feats,
+                                                         float *cm_out) {  // (may be mfcc itself)
   if (fe.stop && *fe.stop) return;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   __shared__ int s_b, s_run, s_wtot[16], s_rbase;
-  __shared__ float s_thr;
+  __shared__ float s_thr, s_wlo[16], s_whi[16];
   const int nc = fe.nc, dim = fe.dim, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
@@ -1109,6 +1141,55 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
     }
   }
   __syncthreads();
+  // ---- cm_out != nullptr: Kaldi's CompressedMatrix round trip of the utterance's MFCC matrix (k_feat_compress's
+  //      arithmetic on the copy in LDS: the launcher takes this path for T <= 64 FB_CM_REG), stored back for whoever
+  //      reads the matrix later; the replicated edge rows are renewed from the compressed ones
+  if (cm_out != nullptr) {
+    float *m = s_mf + ctx * nc;  // [T][nc]
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < T * nc; i += 1024) { const float v = m[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    lo = fb_wave_min_f(lo);
+    hi = fb_wave_max_f(hi);
+    if (lane == 0) { s_wlo[w] = lo; s_whi[w] = hi; }
+    __syncthreads();
+    float minv = s_wlo[0], maxv = s_whi[0];
+    for (int i = 1; i < 16; ++i) { minv = fminf(minv, s_wlo[i]); maxv = fmaxf(maxv, s_whi[i]); }
+    if (maxv == minv) maxv = __fadd_rn(minv, __fadd_rn(1.0f, fabsf(minv)));
+    const float range = __fsub_rn(maxv, minv);
+    if (T <= 8) {  // kTwoByteAuto
+      for (int i = tid; i < T * nc; i += 1024) m[i] = fb_cm_from_u16(minv, range, fb_cm_to_u16(minv, range, m[i]));
+    } else {
+      for (int c = w; c < nc; c += 16) {  // wave = column; keys in registers
+        unsigned kr[FB_CM_REG];
+        float clo = INFINITY, chi = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < FB_CM_REG; ++r) {
+          const int i = 64 * r + lane;
+          const float v = m[(size_t)min(i, T - 1) * nc + c];
+          kr[r] = i < T ? fb_float_key(v) : 0xffffffffu;  // never below a candidate
+          clo = fminf(clo, v);
+          chi = fmaxf(chi, v);
+        }
+        clo = fb_wave_min_f(clo);
+        chi = fb_wave_max_f(chi);
+        float p0, p25, p75, p100;
+        fb_cm_column_header(kr, T, minv, range, clo, chi, p0, p25, p75, p100);
+#pragma unroll
+        for (int r = 0; r < FB_CM_REG; ++r) {
+          const int i = 64 * r + lane;
+          if (i < T) m[(size_t)i * nc + c] = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, fb_key_float(kr[r])));
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * nc; i += 1024) cm_out[(size_t)base * nc + i] = m[i];
+    for (int i = tid; i < ctx * nc; i += 1024) {
+      const int d = i % nc;
+      s_mf[i] = m[d];
+      s_mf[(ctx + T) * nc + i] = m[(size_t)(T - 1) * nc + d];
+    }
+    __syncthreads();
+  }
   // ---- VAD on the C0 column (k_vad's arithmetic: 256 strided float64 partial sums, binary tree; +-vad_ctx vote)
   const float *c0 = s_mf + ctx * nc;  // c0[t * nc]
   if (tid < 256) {
@@ -1272,12 +1353,14 @@ bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *m
   return true;
 }
 
+// true when k_vad_delta_cmvn can take the CompressedMatrix round trip of a batch whose longest utterance has t_max frames
+bool fb_vad_delta_cmvn_compresses(int t_max) { return t_max <= 64 * FB_CM_REG; }
 // returns false when the batch does not qualify (as fb_launch_delta_cmvn): the caller then runs fb_launch_vad and
 // the separate delta / CMVN kernels.  ticket: one int, zero before the first launch; pub: B x 8 bytes; epoch: a
 // number no earlier launch on these buffers used (the engine counts launches).
 bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                               int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                              float *feats) {
+                              float *feats, float *cm_out) {
   if (B <= 0) return true;
   if (t_max > fe.cmn_window) return false;
   const size_t shm = fb_delta_cmvn_lds_bytes(fe, t_max) + 16 + sizeof(double) * 256;
@@ -1292,11 +1375,11 @@ bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const floa
     optin.fetch_or(bit, std::memory_order_release);
   }
   if (fe.order == 2 && fe.dwin == 3)
-    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 3>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
+    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 3>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, cm_out);
   else if (fe.order == 2 && fe.dwin == 2)
-    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 2>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
+    hipLaunchKernelGGL((k_vad_delta_cmvn<2, 2>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, cm_out);
   else
-    hipLaunchKernelGGL((k_vad_delta_cmvn<-1, 0>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats);
+    hipLaunchKernelGGL((k_vad_delta_cmvn<-1, 0>), dim3(B), dim3(1024), shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, cm_out);
   return true;
 }
 
