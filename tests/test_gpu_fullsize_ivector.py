@@ -99,3 +99,30 @@ def test_full_size_sv_get_grad_spd50(oracle, full_engine, full_ctx, full_iv):
     assert np.abs(gg - go).max() <= SCORE_TOL * 6.0 / pg.sigma
     big = np.abs(go) > 10 * SCORE_TOL / pg.sigma
     assert np.all(np.sign(gg[big]) == np.sign(go[big]))
+
+
+def test_full_size_osi_get_grad_spd200_b201(oracle):
+    """BASELINE configs[4]'s single-GPU share: i-vector-PLDA OSI, 10 enrolled speakers, samples_per_draw = 200 -- a NES
+    batch of 201 utterances (four 64-row utterance groups through the T-matrix contraction, 201 posterior systems) --
+    one FakeBob.get_grad against oracle.get_grad with the same Philox stream."""
+    sy = synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=10)
+    sy = sy.with_enrolled(sy.enrolled, z_mean=list(np.linspace(-45.0, -35.0, 10)), z_std=list(np.linspace(8.0, 12.0, 10)))
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=_threads())
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        audio = synthetic_audio(3, 48000)
+        kw = dict(samples_per_draw=200, target=7, threshold=-1.0)
+        pg = nes_params("OSI", "targeted", seed=11, stream=2, **kw)
+        po = oracle.nes_params("OSI", "targeted", ctx.S, **kw)
+        flg, gg, alg, scg = e.get_grad(pg, audio, it=1)
+        flo, go, alo, sco = oracle.get_grad(po, ctx.fn, ctx.ctx, audio, seed=11, it=1, stream=2)
+        print("full-size OSI B = 201 get_grad: |final_loss err| %.3g, |adver_loss err| %.3g, |score err| %.3g"
+              % (abs(flg - flo), abs(alg - alo), np.abs(scg[:ctx.S] - sco).max()))
+        assert abs(alg - alo) <= SCORE_TOL and abs(flg - flo) <= SCORE_TOL
+        assert np.abs(scg[:ctx.S] - sco).max() <= SCORE_TOL
+        assert np.abs(gg - go).max() <= SCORE_TOL * 6.0 / pg.sigma
+        big = np.abs(go) > 10 * SCORE_TOL / pg.sigma
+        assert np.all(np.sign(gg[big]) == np.sign(go[big]))
+    finally:
+        e.close()
