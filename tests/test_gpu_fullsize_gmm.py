@@ -122,3 +122,33 @@ def test_config1_with_the_reference_pipelines_file_round_trips(oracle, full_syst
     finally:
         e.close()
         e0.close()
+
+
+def test_config3_csi_untargeted_get_grad_at_full_size(oracle, full_system):
+    """BASELINE configs[3]'s per-utterance work: GMM-UBM CSI (speaker models only: the first one is the base model of
+    k_gmm_fx2w's delta form) untargeted, C = 2048, spd = 50, 3 s -- one get_grad against the oracle."""
+    _, spk = full_system
+    e = Engine(0)
+    try:
+        e.load_gmm(spk)
+        e.set_system("CSI")
+        assert e.gmm_kernel_variant.startswith("fx2w/")
+        gc, miv, iv = stack_models(spk)
+        ctx = oracle.GmmSystemCtx(oracle.default_cfg(), "CSI", gc, miv, iv, nthreads=NTHR)
+        audio = synthetic_audio(4, 48000)
+        kw = dict(KW, true=2)
+        kw.pop("target"); kw.pop("threshold")
+        pg = nes_params("CSI", "untargeted", seed=7, stream=1, **kw)
+        po = oracle.nes_params("CSI", "untargeted", ctx.S, **kw)
+        flg, gg, alg, scg = e.get_grad(pg, audio, it=2)
+        flo, go, alo, sco = oracle.get_grad(po, ctx.fn, ctx.ctx, audio, seed=7, it=2, stream=1)
+        rms = float(np.sqrt(np.mean(go * go)))
+        flips = np.sign(gg) != np.sign(go)
+        print("full-size CSI get_grad (%s): score err %.2e, loss err %.2e, grad err %.2e (rms %.3f), %d sign flips" %
+              (e.gmm_kernel_variant, np.abs(scg[:ctx.S] - sco).max(), abs(alg - alo), np.abs(gg - go).max(), rms, int(flips.sum())))
+        assert abs(alg - alo) <= 1e-4 and abs(flg - flo) <= 1e-4
+        assert np.abs(scg[:ctx.S] - sco).max() <= 1e-4
+        assert np.abs(gg - go).max() <= 0.02 * rms
+        assert flips.mean() <= 1e-3 and (not flips.any() or np.abs(go[flips]).max() <= 0.02 * rms)
+    finally:
+        e.close()
