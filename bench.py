@@ -370,8 +370,9 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"
             ex = flops_launch * (3 + 3 + (M - 1) * P) * 2.0 * 16 * nk / alg_per_fc
             name = ("k_gmm_fx2w<5,6,%d> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split, "
                     "f32 accumulate on v_mfma_f32_32x32x16_f16: shared quadratic item and the UBM with 3 partial "
-                    "products, the 5 speaker models as deltas from the UBM's accumulator with %d; one wave per SIMD, "
-                    "64 frames per wave, software-pipelined)" % (P, P))
+                    "products, the 5 speaker models as deltas from the UBM's accumulator with %d; accumulators in "
+                    "log2 units relative to a per-frame reference: one v_exp_f32 + one v_add_f32 per value; one wave per "
+                    "SIMD, 64 frames per wave, software-pipelined)" % (P, P))
         else:
             ex = flops_launch * (1 + M) * 3 * 2.0 * 16 * nk / alg_per_fc
             name = "k_gmm_fx2<5,false> (two-term f16 split, 3 partial products per item, quadratic item shared)"
