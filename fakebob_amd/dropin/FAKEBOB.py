@@ -1,5 +1,3 @@
-"""Drop-in for the reference's FAKEBOB.py (same module and class name)."""
+"""Drop-in for the reference's FAKEBOB.py (same module and class name).  The attack itself has no pipeline options: the
+round trips of the reference's scoring pipeline belong to the system classes (gmm_ubm_OSI.py ... in this directory)."""
 from fakebob_amd.attack import FakeBob, UNTARGETED  # noqa: F401
-from fakebob_amd.systems import use_reference_pipeline_defaults as _ref_defaults
-
-_ref_defaults()  # this module name is the reference's: behave like its pipeline (dropin/README.md)

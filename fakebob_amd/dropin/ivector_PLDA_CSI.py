@@ -1,5 +1,6 @@
-"""Drop-in for the reference's ivector_PLDA_CSI.py (same module and class name)."""
-from fakebob_amd.systems import iv_CSI  # noqa: F401
-from fakebob_amd.systems import use_reference_pipeline_defaults as _ref_defaults
+"""Drop-in for the reference's ivector_PLDA_CSI.py: the same class name, with the reference pipeline's two file round trips
+(CompressedMatrix MFCC storage, 6-digit score text) on by default -- a subclass, nothing global is switched
+(dropin/README.md)."""
+from fakebob_amd import systems as _systems
 
-_ref_defaults()  # this module name is the reference's: behave like its pipeline (dropin/README.md)
+iv_CSI = _systems.reference_pipeline(_systems.iv_CSI)

@@ -14,36 +14,38 @@ from .engine import Engine
 from .kaldi_io import load_gmm_any
 
 
-# What a system does when neither the constructor keyword nor the environment variable says otherwise.  The library
-# default keeps full precision; importing a class through its reference module name (fakebob_amd/dropin/) switches to
-# the reference pipeline's own behaviour, see use_reference_pipeline_defaults().
-PIPELINE_DEFAULT = {"text_scores": False, "compress_feats": False}
+# The two file round trips of the reference's pipeline that the engine reproduces on the device:
+#   compress_feats  `copy-feats --compress=true` inside steps/make_mfcc.sh (gmm_ubm_kaldiHelper.py:138-140)
+#   text_scores     the 6-significant-digit score text the helpers parse (gmm_ubm_kaldiHelper.py:236-248)
+# Every system class carries its own default in `PIPELINE` -- None for the library classes below (full precision: the
+# engine's flags are left as the caller set them), REFERENCE_PIPELINE for the subclasses the drop-in modules export
+# under the reference's names (fakebob_amd/dropin/).  Nothing process-global is switched by an import.
+REFERENCE_PIPELINE = {"text_scores": True, "compress_feats": True}
 
 
-def use_reference_pipeline_defaults(on=True):
-    """The two file round trips of the reference's pipeline as the default of every system constructed afterwards:
-    `copy-feats --compress=true` inside steps/make_mfcc.sh (gmm_ubm_kaldiHelper.py:138-140) and the
-    6-significant-digit score text the helpers parse (gmm_ubm_kaldiHelper.py:236-248).  Called by the drop-in modules
-    (fakebob_amd/dropin/*.py): an unmodified attackMain.py then computes what it computes with a stock Kaldi recipe."""
-    PIPELINE_DEFAULT["text_scores"] = bool(on)
-    PIPELINE_DEFAULT["compress_feats"] = bool(on)
-
-
-def _pipeline_options(text_scores, compress_feats):
-    """The two round trips the reference's pipeline takes through files and the engine reproduces on the device:
-    text_scores (Kaldi prints scores with 6 significant digits and the helpers parse that text) and compress_feats
-    (make_mfcc.sh stores the MFCCs through Kaldi's lossy CompressedMatrix).  Precedence: constructor keyword (True or
-    False), then FB_TEXT_SCORES / FB_COMPRESS_FEATS = 0 | 1, then PIPELINE_DEFAULT.  Both keys are always returned, so
-    an explicit False also clears a flag an earlier system left on a shared engine."""
-    def pick(kw, env, key):
+def _pipeline_options(text_scores, compress_feats, default=None):
+    """Front-end overrides for the two round trips.  Precedence per flag: constructor keyword (True or False), then
+    FB_TEXT_SCORES / FB_COMPRESS_FEATS = 0 | 1, then the class default (`default`, a dict or None).  A flag that none
+    of the three names is NOT returned: constructing a library system on a shared engine leaves whatever the caller
+    set through Engine.set_frontend alone."""
+    out = {}
+    for key, kw, env in (("text_scores", text_scores, "FB_TEXT_SCORES"), ("compress_feats", compress_feats, "FB_COMPRESS_FEATS")):
         if kw is not None:
-            return bool(kw)
+            out[key] = int(bool(kw))
+            continue
         ev = os.environ.get(env)
         if ev in ("0", "1"):
-            return ev == "1"
-        return PIPELINE_DEFAULT[key]
-    return {"text_scores": int(pick(text_scores, "FB_TEXT_SCORES", "text_scores")),
-            "compress_feats": int(pick(compress_feats, "FB_COMPRESS_FEATS", "compress_feats"))}
+            out[key] = int(ev == "1")
+        elif default is not None and key in default:
+            out[key] = int(bool(default[key]))
+    return out
+
+
+def reference_pipeline(cls):
+    """The subclass of a system class that behaves like the reference's pipeline by default (both round trips on):
+    what fakebob_amd/dropin/<reference module name>.py exports under the reference's class name."""
+    return type(cls.__name__, (cls,), {"PIPELINE": dict(REFERENCE_PIPELINE), "__doc__": cls.__doc__,
+                                       "__module__": cls.__module__})
 
 
 def default_device():
@@ -65,6 +67,7 @@ def _to_audio_list(audios):
 
 class _GmmSystem(object):
     task = None
+    PIPELINE = None  # class default of the two round trips (see REFERENCE_PIPELINE)
 
     def _setup(self, group_id, models, spk_ids, utt_ids, locations, z_means, z_stds, pre_model_dir, engine,
                text_scores=None, compress_feats=None):
@@ -80,7 +83,7 @@ class _GmmSystem(object):
         if os.path.isdir(conf):
             from .config import frontend_from_kaldi_conf
             over = frontend_from_kaldi_conf(self.pre_model_dir)
-        over = dict(over, **_pipeline_options(text_scores, compress_feats))
+        over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE))
         if over:
             self._engine.set_frontend(**over)
         self._engine.load_gmm(models)
@@ -195,6 +198,7 @@ class gmm_SV(_GmmSystem):
 # ------------------------------------------------------------------ i-vector / PLDA
 class _IvSystem(object):
     task = None
+    PIPELINE = None
 
     def _setup(self, group_id, model_list, pre_model_dir, engine, system, text_scores=None, compress_feats=None):
         from .models import IvectorSystem
@@ -227,13 +231,13 @@ class _IvSystem(object):
             if os.path.isdir(conf):
                 from .config import frontend_from_kaldi_conf
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
-            over = dict(over, **_pipeline_options(text_scores, compress_feats))
+            over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE))
             if over:
                 self._engine.set_frontend(**over)
             d = load_ivector_pre_models(self.pre_model_dir)
             system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
         else:
-            over = _pipeline_options(text_scores, compress_feats)
+            over = _pipeline_options(text_scores, compress_feats, self.PIPELINE)
             if over:
                 self._engine.set_frontend(**over)
             system = system.with_enrolled(enrolled, zm, zs)

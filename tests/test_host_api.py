@@ -421,38 +421,42 @@ def test_kaldi_default_dither_is_reported():
 
 def test_pipeline_option_precedence_and_dropin_defaults(monkeypatch):
     """text_scores / compress_feats: constructor keyword (True OR False) > FB_TEXT_SCORES / FB_COMPRESS_FEATS > the
-    module default, which the reference-named drop-in modules switch to the reference pipeline's behaviour
-    (fakebob_amd/dropin/README.md).  Both keys are always passed on, so an explicit False clears a flag left on a
-    shared engine."""
-    import importlib
+    CLASS default -- None for the library classes (the flag is then not touched on the engine), both on for the
+    subclasses the reference-named drop-in modules export (fakebob_amd/dropin/README.md).  Importing a drop-in module
+    changes nothing for systems built from fakebob_amd.systems in the same process."""
     import subprocess
     import sys
     from fakebob_amd import systems
     for k in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setitem(systems.PIPELINE_DEFAULT, "text_scores", False)
-    monkeypatch.setitem(systems.PIPELINE_DEFAULT, "compress_feats", False)
-    assert systems._pipeline_options(None, None) == {"text_scores": 0, "compress_feats": 0}
-    assert systems._pipeline_options(True, None) == {"text_scores": 1, "compress_feats": 0}
+    ref = systems.REFERENCE_PIPELINE
+    assert systems._pipeline_options(None, None) == {}                        # nobody said anything: engine flags stay
+    assert systems._pipeline_options(True, None) == {"text_scores": 1}
+    assert systems._pipeline_options(None, False) == {"compress_feats": 0}   # an explicit False clears a shared engine's flag
+    assert systems._pipeline_options(None, None, ref) == {"text_scores": 1, "compress_feats": 1}
     monkeypatch.setenv("FB_TEXT_SCORES", "1")
     monkeypatch.setenv("FB_COMPRESS_FEATS", "1")
     assert systems._pipeline_options(None, None) == {"text_scores": 1, "compress_feats": 1}
     assert systems._pipeline_options(False, False) == {"text_scores": 0, "compress_feats": 0}   # keyword wins, both ways
     monkeypatch.setenv("FB_TEXT_SCORES", "0")
-    systems.use_reference_pipeline_defaults()
-    assert systems._pipeline_options(None, None) == {"text_scores": 0, "compress_feats": 1}     # env wins over default
-    monkeypatch.delenv("FB_TEXT_SCORES")
-    monkeypatch.delenv("FB_COMPRESS_FEATS")
-    assert systems._pipeline_options(None, None) == {"text_scores": 1, "compress_feats": 1}
-    # a fresh interpreter: importing a reference module name is what flips the default
+    assert systems._pipeline_options(None, None, ref) == {"text_scores": 0, "compress_feats": 1}     # env wins over the class default
+    sub = systems.reference_pipeline(systems.gmm_OSI)
+    assert issubclass(sub, systems.gmm_OSI) and sub.__name__ == "gmm_OSI" and sub.PIPELINE == ref
+    assert systems.gmm_OSI.PIPELINE is None and systems.iv_SV.PIPELINE is None
+    # a fresh interpreter: the reference module names export subclasses; the library classes are untouched
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path[:0] = [%r, %r]\n"
             "from fakebob_amd import systems\n"
-            "assert systems._pipeline_options(None, None) == {'text_scores': 0, 'compress_feats': 0}\n"
-            "import gmm_ubm_OSI, FAKEBOB\n"
-            "assert gmm_ubm_OSI.gmm_OSI is systems.gmm_OSI\n"
-            "assert systems._pipeline_options(None, None) == {'text_scores': 1, 'compress_feats': 1}\n"
+            "import gmm_ubm_OSI, gmm_ubm_CSI, gmm_ubm_SV, ivector_PLDA_OSI, ivector_PLDA_CSI, ivector_PLDA_SV, FAKEBOB\n"
+            "for mod, name in ((gmm_ubm_OSI, 'gmm_OSI'), (gmm_ubm_CSI, 'gmm_CSI'), (gmm_ubm_SV, 'gmm_SV'),\n"
+            "                  (ivector_PLDA_OSI, 'iv_OSI'), (ivector_PLDA_CSI, 'iv_CSI'), (ivector_PLDA_SV, 'iv_SV')):\n"
+            "    cls = getattr(mod, name)\n"
+            "    assert issubclass(cls, getattr(systems, name)) and cls is not getattr(systems, name)\n"
+            "    assert cls.PIPELINE == {'text_scores': True, 'compress_feats': True}\n"
+            "    assert getattr(systems, name).PIPELINE is None\n"
+            "assert systems._pipeline_options(None, None) == {}\n"
+            "from fakebob_amd.attack import FakeBob\n"
+            "assert FAKEBOB.FakeBob is FakeBob\n"
             % (os.path.join(root, "fakebob_amd", "dropin"), root))
     env = {k: v for k, v in os.environ.items() if k not in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS")}
     subprocess.run([sys.executable, "-c", code], check=True, env=env)
-    importlib.reload(systems)
