@@ -294,12 +294,9 @@ def bench_ivector(args, torch):
                                     "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,
                                     "peak_tflops": PEAK_F64_MFMA_TFLOPS,
                                     "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
-        try:  # HBM bytes per launch (both kernels) from the committed rocprofv3 PMC passes
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
-                contraction["traffic"] = json.load(r)["kernels"]["k_iv_contract_dma<lin>+<quad>"]["hbm_bytes_per_launch"]
-            contraction["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
-        except Exception:
-            pass
+        tr, prov = committed_traffic("k_iv_contract_dma<lin>+<quad>")   # HBM bytes per launch (both kernels), PMC passes
+        contraction["traffic"] = tr
+        contraction.update(prov)
         # k_iv_solve_ll: B Cholesky factorisations + two triangular solves of R x R (R^3/3 + 2 R^2
         # flops per utterance) on the float64 matrix cores
         solve_flops = B * (R ** 3 / 3.0 + 2.0 * R * R)
@@ -343,22 +340,56 @@ def bench_ivector(args, torch):
 
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
-GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6, 1>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
-TRAFFIC_FILE = "r03_traffic.json"
-# bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip): the clock drops to ~1.6 GHz
-# under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF spec peak
-MFMA16_POWER_LIMITED_TFLOPS = 1660.0
+GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
+TRAFFIC_FILE = "r04_traffic.json"
+# bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip, a round-1 PROBE, not a specification):
+# the clock drops to ~1.6 GHz under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF peak
+MFMA16_POWER_LIMITED_TFLOPS_PROBE = 1660.0
 
 
-def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"):
+def kernel_source_hash():
+    """sha256 over the HIP sources and headers the library is built from: what profiles/<TRAFFIC_FILE> was taken on
+    (tools/profile/prof_r04.sh records it) must be what runs now, or the committed PMC traffic is not this build's."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "fakebob_amd", "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(root, f), "rb") as r:
+                h.update(r.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(key):
+    """(hbm bytes per launch, provenance dict) from the committed rocprofv3 PMC passes, or (None, why): PMC counters
+    cannot be collected in-process, so the bench line carries the profile's number ONLY when the kernel sources are
+    byte-identical to the ones that were profiled -- a stale profile is reported as such, loudly, never as a number."""
+    try:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
+            tj = json.load(r)
+        now = kernel_source_hash()
+        if tj.get("kernel_source_sha16") != now:
+            print("bench.py: profiles/%s was taken on kernel sources %s, this build is %s -- roofline.traffic is NOT "
+                  "reported (re-run tools/profile/prof_r04.sh)" % (TRAFFIC_FILE, tj.get("kernel_source_sha16"), now),
+                  file=sys.stderr)
+            return None, {"traffic_stale": True, "traffic_profiled_on": tj.get("kernel_source_sha16"), "kernel_source_sha16": now}
+        return tj["kernels"][key]["hbm_bytes_per_launch"], {
+            "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch "
+                              "correction; taken on these exact kernel sources)" % TRAFFIC_FILE,
+            "traffic_profiled_on": tj.get("kernel_source_sha16"), "traffic_profiled_commit": tj.get("commit")}
+    except Exception as ex:  # noqa: BLE001
+        return None, {"traffic_error": str(ex)[:120]}
+
+
+def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3", tiles=None, M=S_SPK + 1):
     """Roofline of the dominant kernel.  `achieved` = ALGORITHMIC flops ((S+1)*C*4D per voiced frame,
     two length-D dot products per component per model as Kaldi evaluates them) / average launch duration;
     `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16 / bf16: 2.5 PF), so `frac` is a true
     fraction.  `executed_*`: the products the kernel really issues per (frame, component), K padded to 16*nk:
     k_gmm_fx2w -- the shared quadratic item and the base model with 3 partial products each, every other model as a
-    delta item with P partial products; k_gmm_fx2 / k_gmm_bx3 -- quadratic item + one item per model, 3 / 6 partial
-    products each."""
-    M = S_SPK + 1
+    delta item with the products of its component tile (tiles = (#P=1, #P=2, #P=3)); k_gmm_fx2 / k_gmm_bx3 -- quadratic
+    item + one item per model, 3 / 6 partial products each."""
     per_s = 1.0 / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
     achieved = flops_launch * per_s
     alg_per_fc = M * 4.0 * D_FEAT                                  # algorithmic flops per (frame, component)
@@ -366,13 +397,15 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"
         nk = (D_FEAT + 1 + 15) // 16
         pipe, peak = "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
         if variant.startswith("fx2w/"):
-            P = int(variant.split("/")[1])
-            ex = flops_launch * (3 + 3 + (M - 1) * P) * 2.0 * 16 * nk / alg_per_fc
-            name = ("k_gmm_fx2w<5,6,%d> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split, "
-                    "f32 accumulate on v_mfma_f32_32x32x16_f16: shared quadratic item and the UBM with 3 partial "
-                    "products, the 5 speaker models as deltas from the UBM's accumulator with %d; accumulators in "
+            n1, n2, n3 = tiles if tiles and sum(tiles) else (0, 0, 1)
+            p_avg = (n1 + 2.0 * n2 + 3.0 * n3) / (n1 + n2 + n3)
+            ex = flops_launch * (3 + 3 + (M - 1) * p_avg) * 2.0 * 16 * nk / alg_per_fc
+            name = ("k_gmm_fx2w<5,%d> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split, "
+                    "f32 accumulate on v_mfma_f32_32x32x16_f16: shared quadratic item and the base model with 3 partial "
+                    "products, the other %d models as deltas from the base model's accumulator with 1 / 2 / 3 products "
+                    "per component tile (%d / %d / %d tiles, components sorted by adaptation distance); accumulators in "
                     "log2 units relative to a per-frame reference: one v_exp_f32 + one v_add_f32 per value; one wave per "
-                    "SIMD, 64 frames per wave, software-pipelined)" % (P, P))
+                    "SIMD, 64 frames per wave, software-pipelined)" % (M, M - 1, n1, n2, n3))
         else:
             ex = flops_launch * (1 + M) * 3 * 2.0 * 16 * nk / alg_per_fc
             name = "k_gmm_fx2<5,false> (two-term f16 split, 3 partial products per item, quadratic item shared)"
@@ -385,14 +418,74 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"
          "traffic": None, "avg_launch_ms": gmm_ms_avg, "algorithmic_flops_per_launch": flops_launch,
          "kernel": name, "kernel_variant": variant, "peak_pipe": pipe,
          "executed_flops_per_launch": ex, "executed_tflops": ex * per_s, "executed_frac": ex * per_s / peak}
-    r["executed_frac_of_power_limited_ceiling"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS
+    r["executed_frac_of_power_limited_probe"] = ex * per_s / MFMA16_POWER_LIMITED_TFLOPS_PROBE
+    r["power_limited_probe_tflops"] = MFMA16_POWER_LIMITED_TFLOPS_PROBE
     if solo_ms and solo_ms > 0:
-        fl_solo = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * solo_rows
+        fl_solo = M * C_GAUSS * 4 * D_FEAT * solo_rows
         r["solo_launch_ms"] = solo_ms
         r["solo_achieved"] = fl_solo / (solo_ms * 1e-3) / 1e12
         r["solo_frac"] = r["solo_achieved"] / peak
         r["solo_executed_frac"] = r["solo_frac"] * ex / flops_launch
     return r
+
+
+class AttackSet(object):
+    """K attacks in flight on one GPU: one engine (= HIP stream + device state) each, a different utterance each,
+    driven from K persistent host threads.  run(n, timed): n NES iterations of every attack -- the first call uploads
+    the audio and resets the NES state, every later call CONTINUES the resident attack."""
+
+    def __init__(self, engs, prms, auds):
+        self.engs, self.prms, self.auds = engs, prms, auds
+        self.K = len(engs)
+        self.results = [None] * self.K
+        self.windows = [None] * self.K
+        self.started = [False] * self.K
+        self.workers = Workers(self.K, self._run)
+
+    def _run(self, k, n, timed):
+        t_in = time.perf_counter()
+        self.results[k] = self.engs[k].bench_nes(self.prms[k], self.auds[k], 0 if not self.started[k] else -1, n, time_gmm=timed)
+        self.started[k] = True
+        self.windows[k] = (t_in, time.perf_counter())
+
+    def run(self, n, timed):
+        self.workers.run(n, timed)
+
+    def restart(self):
+        """the engines' models or front-end changed: the next run() starts new attacks"""
+        self.started = [False] * self.K
+
+    def close(self):
+        self.workers.close()
+
+
+def quick_measure(torch, aset, steps, warm, single_fused=True, chain_fused=None, time_kernel=1):
+    """A secondary measurement on rank 0 (no collectives): `warm` untimed, then `steps` timed NES iterations of every
+    attack of the set between two device synchronisations, then the same step count with ONE attack in flight.
+    Returns a dict; the headline number is NOT measured here (timed_region is)."""
+    for e in aset.engs:
+        e.set_fused_chain(chain_fused)
+    aset.run(max(2, warm), False)
+    solo_ms, solo_rows = aset.engs[0].bench_gmm_kernel(10) if time_kernel == 1 and getattr(aset.engs[0], "kind", "gmm") != "iv" else (None, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    aset.run(steps, time_kernel)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": steps * aset.K / dt, "unit": "NES iterations/s", "steps": steps, "warmup": max(2, warm),
+           "attacks_in_flight": aset.K, "ms_per_step": 1e3 * dt / steps,
+           "kernel_avg_launch_ms": sum(r[1] for r in aset.results) / aset.K / steps}
+    if solo_ms:
+        out["kernel_solo_launch_ms"] = solo_ms
+    aset.engs[0].set_fused_chain(single_fused)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    r1 = aset.engs[0].bench_nes(aset.prms[0], aset.auds[0], -1, steps, time_gmm=time_kernel)
+    torch.cuda.synchronize()
+    d1 = time.perf_counter() - t1
+    out["single_attack"] = {"value": steps / d1, "ms_per_step": 1e3 * d1 / steps, "kernel_launch_ms": r1[1] / steps}
+    out["voiced_rows_per_iter"] = int(r1[2])
+    return out
 
 
 def main():
@@ -403,6 +496,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="attacks in flight per GPU (one engine/stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the extra one-attack-in-flight measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements of the default line (forced three products, realistic enrolment, "
+                         "reference-pipeline mode, GMM CSI, i-vector SV / OSI)")
     ap.add_argument("--arch", default="gmm", choices=["gmm", "iv"], help="gmm = headline (configs[1]); iv = configs[2]")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
     ap.add_argument("--same-device", action="store_true",
@@ -413,9 +509,13 @@ def main():
     ap.add_argument("--chain", default="auto", choices=["auto", "fused", "unfused"],
                     help="launch chain of the attack loop (fb_set_fused_chain): auto = 5 launches per iteration with fewer "
                          "than 3 attacks in flight, the 8 separate launches otherwise (they interleave better)")
-    ap.add_argument("--task", default="SV", choices=["SV", "OSI", "CSI"], help="--arch iv: the system (configs[2]: SV; configs[4]: OSI)")
+    ap.add_argument("--task", default=None, choices=["SV", "OSI", "CSI"],
+                    help="--arch iv: the system (configs[2]: SV, the default; configs[4]: OSI).  --arch gmm: OSI (headline, "
+                         "default) or CSI = configs[3]'s per-GPU work (GMM CSI untargeted, speaker models only)")
     ap.add_argument("--speakers", type=int, default=None, help="--arch iv: enrolled speakers (default 1 for SV, 10 otherwise)")
     ap.add_argument("--spd", type=int, default=SPD, help="--arch iv: samples_per_draw (configs[4]: 200)")
+    ap.add_argument("--enrol", default="survey", choices=["survey", "realistic"],
+                    help="synthetic speakers: SURVEY.md 8(d)'s 200-frame enrolment (headline) or 20 000 frames (models.ENROL_REALISTIC)")
     ap.add_argument("--faithful", action="store_true",
                     help="run the reference pipeline's two file round trips on the device (MFCCs through Kaldi's "
                          "CompressedMatrix, scores through 6-digit text: gmm_ubm_kaldiHelper.py:138-140, 236-248) -- "
@@ -427,51 +527,55 @@ def main():
 
     import torch  # device sync + torch.distributed (RCCL); imported before the HIP library
     if args.arch == "iv":
+        args.task = args.task or "SV"
         return bench_ivector(args, torch)
+    gmm_task = args.task or "OSI"
+    if gmm_task == "SV":
+        raise SystemExit("--arch gmm takes --task OSI (headline) or CSI")
     from fakebob_amd import parallel
     rank, world, dev_index, dist = dist_setup(args, torch)
     from fakebob_amd.engine import Engine, nes_params
-    from fakebob_amd.models import synthetic_audio, synthetic_gmm_system
+    from fakebob_amd.models import ENROL_REALISTIC, synthetic_audio, synthetic_gmm_system
 
     K = max(1, args.streams)
     fused = (K < 3) if args.chain == "auto" else (args.chain == "fused")
-    ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT)
-    models = [ubm] + spk
-    kw = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_lr=0.001, min_lr=1e-6, momentum=0.9,
-              plateau_length=5, plateau_drop=2.0, adver_thresh=0.0, max_iter=1000, target=0, threshold=0.2277)
+    ubm, spk = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT, **(ENROL_REALISTIC if args.enrol == "realistic" else {}))
+    kw_common = dict(samples_per_draw=SPD, epsilon=0.002, sigma=0.001, max_lr=0.001, min_lr=1e-6, momentum=0.9,
+                     plateau_length=5, plateau_drop=2.0, adver_thresh=0.0, max_iter=1000)
+
+    def system_of(task, ubm_, spk_):
+        """(models, attack type, NES keywords, z-norm) of the task's synthetic system"""
+        if task == "CSI":   # configs[3]: no UBM, z-normalised speaker log-likelihoods, untargeted
+            return list(spk_), "untargeted", dict(kw_common, true=0), ([-150.0] * len(spk_), [5.0] * len(spk_))
+        return [ubm_] + list(spk_), "targeted", dict(kw_common, target=0, threshold=0.2277), (None, None)
+
+    models, attack_type, kw, znorm = system_of(gmm_task, ubm, spk)
     engs, auds, prms = [], [], []
     for k in range(K):
         e = Engine(dev_index)
         if args.faithful:
             e.set_frontend(compress_feats=1, text_scores=1)
         e.load_gmm(models)
-        e.set_system("OSI")
+        e.set_system(gmm_task, *znorm)
         e.set_fused_chain(fused)
         engs.append(e)
         utt = rank * K + k                                  # a different utterance per attack
         auds.append(synthetic_audio(utt, N_SAMPLES))
-        prms.append(nes_params("OSI", "targeted", seed=42, stream=utt, **kw))
+        prms.append(nes_params(gmm_task, attack_type, seed=42, stream=utt, **kw))
     audio = auds[0]
-    results = [None] * K
-
-    windows = [None] * K
-
-    started = [False] * K
-
-    def run(k, n, timed):
-        # the first call uploads the attack's audio and resets the NES state; every later call (the declared warm-up,
-        # the timed region) CONTINUES that attack on the device: inputs are resident in HBM when the timed region starts
-        t_in = time.perf_counter()
-        results[k] = engs[k].bench_nes(prms[k], auds[k], 0 if not started[k] else -1, n, time_gmm=timed)
-        started[k] = True
-        windows[k] = (t_in, time.perf_counter())
+    n_models = len(models)
+    variant, tiles = engs[0].gmm_kernel_variant, engs[0].gmm_delta_tiles
+    if not variant.startswith("fx2w/") and GMM_MODE == "fx2":
+        print("bench.py: WARNING: this system is scored by the general kernel %s, not k_gmm_fx2w (more than %d models, "
+              "several variance groups or partial tiles)" % (variant, 10), file=sys.stderr)
 
     # outside everything: module load, first-touch allocations, the clock ramp of a cold GPU, and the same GMM
     # launch with the chip to itself
-    workers = Workers(K, run)
-    workers.run(max(2, args.precondition), False)
+    aset = AttackSet(engs, prms, auds)
+    aset.run(max(2, args.precondition), False)
     solo_ms, solo_rows = engs[0].bench_gmm_kernel(20)
-    dt = timed_region(args, torch, dist, workers, K)
+    dt = timed_region(args, torch, dist, aset.workers, K)
+    results, windows = list(aset.results), list(aset.windows)
     ms_dev = sum(r[0] for r in results) / K
     ms_gmm = sum(r[1] for r in results) / K                 # per attack: sum over its timed launches
     rows = int(sum(r[2] for r in results) / K)
@@ -495,10 +599,12 @@ def main():
         single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
                   "gmm_launch_ms": r1[1] / args.steps,
                   "note": "one attack in flight (a single launch chain), same workload, same step count"}
-    workers.close()
+    out = None
     if rank == 0:
         gmm_ms_avg = ms_gmm / args.steps
-        flops_launch = (S_SPK + 1) * C_GAUSS * 4 * D_FEAT * rows  # (S+1)*C*4D*F_voiced
+        flops_launch = n_models * C_GAUSS * 4 * D_FEAT * rows  # (S+1)*C*4D*F_voiced
+        wl = ("GMM-UBM OSI targeted, 5 speakers+UBM" if gmm_task == "OSI" else
+              "GMM CSI untargeted (BASELINE.json configs[3]'s per-GPU work), 5 speaker models, no UBM")
         out = {
             "metric": "NES iterations/sec (and scored-utts/sec) at samples_per_draw=50, 3 s@16 kHz",
             "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
@@ -508,33 +614,99 @@ def main():
                       "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)"}[GMM_MODE],
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
-            "vs_readme_nominal": its / README_GMM_ITS,
+            "vs_readme_nominal": its / README_GMM_ITS if gmm_task == "OSI" else None,
             "single_attack": single,
             "per_attack": [{"host_ms": 1e3 * (b - a), "device_ms": r[0], "gmm_ms": r[1]} for (a, b), r in zip(windows, results)],
-            "config": {"workload": "GMM-UBM OSI targeted, 5 speakers+UBM, C=2048, D=72, spd=50, "
-                                   "N=48000 (3 s @ 16 kHz), %d attacks in flight per GPU "
-                                   "(1 step = 1 NES iteration of each)%s" % (K, "; reference-pipeline round trips ON "
-                                   "(compress_feats, text_scores)" if args.faithful else ""),
-                       "faithful_pipeline": bool(args.faithful),
+            "config": {"workload": "%s, C=2048, D=72, spd=50, N=48000 (3 s @ 16 kHz), %d attacks in flight per GPU "
+                                   "(1 step = 1 NES iteration of each)%s%s"
+                                   % (wl, K, "; reference-pipeline round trips ON (compress_feats, text_scores)" if args.faithful else "",
+                                      "; speakers enrolled on 20 000 frames (models.ENROL_REALISTIC)" if args.enrol == "realistic" else ""),
+                       "faithful_pipeline": bool(args.faithful), "enrolment": args.enrol,
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
                        "launch_chain": "5 launches per iteration (fused)" if fused else "8 launches per iteration",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
+                       "gmm_kernel": variant,
+                       "gmm_delta_p": {"tiles_p1": tiles[0], "tiles_p2": tiles[1], "tiles_p3": tiles[2],
+                                       "shift_rms": engs[0].gmm_shift_rms,
+                                       "note": "component tiles (32 components) by the partial products their delta items run; "
+                                               "chosen by fb_load_gmm from the models (DESIGN.md section 5)"},
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
-            "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, engs[0].gmm_kernel_variant),
+            "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant, tiles, n_models),
                              gmm_share_of_stream_time=ms_gmm / ms_dev if ms_dev > 0 else None,
                              note="avg_launch_ms: HIP events around every launch of the timed region on each attack's own "
                                   "stream; with several attacks in flight a launch shares the chip with other attacks' "
                                   "kernels (the rocprofv3 average of the same command agrees: profiles/); solo_*: the same "
                                   "launch with the chip to itself, measured before the warm-up"),
         }
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable in-process)
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as r:
-                tr = json.load(r)["kernels"][GMM_TRAFFIC_KEY]
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)" % TRAFFIC_FILE
-        except Exception:
-            pass
-        if world == 1 and not args.no_cpu_baseline:
+        tr, prov = committed_traffic(GMM_TRAFFIC_KEY if n_models == S_SPK + 1 else GMM_TRAFFIC_KEY.replace("6", str(n_models)))
+        out["roofline"]["traffic"] = tr
+        out["roofline"].update(prov)
+    if rank == 0 and world == 1 and not args.no_secondary and not args.faithful and args.enrol == "survey" and gmm_task == "OSI" \
+            and GMM_MODE == "fx2":
+        # ---- secondary measurements of the same run (rank 0, single GPU): small step counts, same code paths.  They
+        #      bracket the headline (three delta products forced in every tile = the cost for ANY speaker models) and put
+        #      the other configurations of BASELINE.json under the driver's eyes.
+        n2 = max(10, min(args.steps, 40))
+        sec = {}
+
+        def reload(models_, task_, znorm_, prm_kw, atk, env=None, frontend=None):
+            for k_, v_ in (env or {}).items():
+                os.environ[k_] = v_
+            try:
+                for k in range(K):
+                    e = engs[k]
+                    e.set_frontend(**(frontend or dict(compress_feats=0, text_scores=0)))
+                    e.load_gmm(models_)
+                    e.set_system(task_, *znorm_)
+                    aset.prms[k] = nes_params(task_, atk, seed=42, stream=rank * K + k, **prm_kw)
+            finally:
+                for k_ in (env or {}):
+                    os.environ.pop(k_, None)
+            aset.restart()
+
+        def gmm_case(name, note, n_mod):
+            r = quick_measure(torch, aset, n2, 10, chain_fused=fused)
+            r["gmm_kernel"], r["gmm_delta_tiles"] = engs[0].gmm_kernel_variant, list(engs[0].gmm_delta_tiles)
+            fl = n_mod * C_GAUSS * 4 * D_FEAT * r["voiced_rows_per_iter"]
+            r["kernel_solo_frac"] = fl / (r["kernel_solo_launch_ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+            r["note"] = note
+            sec[name] = r
+            return r
+
+        try:
+            reload(models, "OSI", (None, None), kw, "targeted", env={"FB_GMM_DELTA_P": "3"})
+            wc = gmm_case("forced_three_products", "the headline workload with three partial products forced in every tile "
+                          "(FB_GMM_DELTA_P=3): what k_gmm_fx2w costs for speaker models adapted arbitrarily far", n_models)
+            out["roofline"]["worst_case"] = {
+                "kernel_variant": wc["gmm_kernel"], "tiles_p1_p2_p3": wc["gmm_delta_tiles"], "value": wc["value"],
+                "single_attack": wc["single_attack"]["value"], "avg_launch_ms": wc["kernel_avg_launch_ms"],
+                "solo_launch_ms": wc["kernel_solo_launch_ms"], "solo_frac": wc["kernel_solo_frac"], "steps": n2,
+                "note": "same run, same workload, P = 3 in every component tile: the bracket of `value` for real speaker models"}
+            ubm_r, spk_r = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT, **ENROL_REALISTIC)
+            reload([ubm_r] + spk_r, "OSI", (None, None), kw, "targeted")
+            gmm_case("realistic_enrolment", "speakers enrolled on 20 000 frames (models.ENROL_REALISTIC: alpha ~ 0.2-0.4 where "
+                     "the enrolment data fell), products per tile chosen by fb_load_gmm", n_models)
+            reload(models, "OSI", (None, None), kw, "targeted", frontend=dict(compress_feats=1, text_scores=1))
+            gmm_case("faithful", "the reference pipeline's two file round trips ON (CompressedMatrix MFCCs, 6-digit score "
+                     "text): the drop-in modules' default", n_models)
+            m_c, atk_c, kw_c, z_c = system_of("CSI", ubm, spk)
+            reload(m_c, "CSI", z_c, kw_c, atk_c)
+            gmm_case("gmm_csi", "BASELINE.json configs[3]'s per-GPU work: GMM CSI untargeted, 5 speaker models, no UBM "
+                     "(`--arch gmm --task CSI` is the full line)", len(m_c))
+        except Exception as ex:  # noqa: BLE001 -- the headline above is the contract; a secondary case must not lose it
+            sec["error"] = repr(ex)[:300]
+        out["secondary"] = sec
+    aset.close()
+    for e in engs:
+        e.close()
+    engs = []
+    if rank == 0 and out is not None and "secondary" in out and "error" not in out["secondary"]:
+        try:
+            out["secondary"].update(secondary_ivector(torch, dev_index, K))
+        except Exception as ex:  # noqa: BLE001
+            out["secondary"]["ivector_error"] = repr(ex)[:300]
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and gmm_task == "OSI":
             ckw = dict(kw)
             out["cpu_baseline"] = cpu_baseline(audio, models, ckw, args.faithful)
             out["gpu_over_cpu_port"] = its / out["cpu_baseline"]["value"]
@@ -542,8 +714,37 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for e in engs:
-        e.close()
+
+
+def secondary_ivector(torch, dev_index, K):
+    """i-vector-PLDA SV spd=50 (configs[2]) and OSI, 10 speakers, spd=200 (configs[4]'s share of one GPU) with small step
+    counts: the numbers `--arch iv` reports in full, under the default line."""
+    from fakebob_amd.engine import Engine, nes_params
+    from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+    sec = {}
+    for name, task, n_spk, spd, steps in (("ivector_sv", "SV", 1, SPD, 20), ("ivector_osi_b201", "OSI", 10, 200, 10)):
+        sy = synthetic_ivector_system(C=C_GAUSS, D=D_FEAT, R=400, L=200, n_speakers=n_spk)
+        sy = sy.with_enrolled(sy.enrolled, [-40.0] * n_spk, [10.0] * n_spk)
+        kw = dict(samples_per_draw=spd, epsilon=0.002, sigma=0.001, max_iter=1000, threshold=1.0)
+        if task != "SV":
+            kw["target"] = 0
+        engs = []
+        for k in range(K):
+            e = Engine(dev_index)
+            e.load_ivector(sy, task)
+            engs.append(e)
+        aset = AttackSet(engs, [nes_params(task, "targeted", seed=42, stream=k, **kw) for k in range(K)],
+                         [synthetic_audio(k, N_SAMPLES) for k in range(K)])
+        try:
+            r = quick_measure(torch, aset, steps, 4, chain_fused=(K < 3), time_kernel=2)
+            r["kernel_timed"] = "k_iv_solve_ll"
+            r["note"] = "i-vector-PLDA %s, %d enrolled, spd=%d (%d utterances per NES batch), C=2048, R=400" % (task, n_spk, spd, 2 * (spd // 2) + 1)
+            sec[name] = r
+        finally:
+            aset.close()
+            for e in engs:
+                e.close()
+    return sec
 
 
 if __name__ == "__main__":

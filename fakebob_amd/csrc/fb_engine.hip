@@ -119,7 +119,7 @@ struct fb_engine {
   int evg_n = 0;
   int t_max = 0;
   std::vector<int32_t> h_frame_rec;
-  DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
+  DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, mfcc_cm, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
   std::vector<int> h_frame_off, h_chunk_off;
   bool any_long = false;  // some utterance has T > cmn_window
@@ -228,7 +228,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -429,10 +429,11 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
-  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0;
+  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0, delta_t3 = 0, delta_t2 = 0;
+  e->gmm_delta_rms = 0.0;
   // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
   // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
-  const bool want_delta = G == 1 && M >= 2 && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
+  const bool want_delta = G == 1 && M >= 2 && M <= FB_FXW_MAX_M && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -512,32 +513,94 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
       // item.  The deltas are float32 differences (exact by Sterbenz's lemma for the close values adaptation
       // produces, correctly rounded otherwise).
       //
-      // Products per K chunk of the delta items.  P = 2 drops the frames' second f16 term -- an error of 2^-12 |delta . x|
-      // per (frame, component), random in sign from frame to frame --, P = 1 also the deltas' second term.
-      // b_k = 2^-12 |delta_k * (|mu_k| + 3 sigma_k)|_2 bounds the former where component k matters (x within 3 sigma of
-      // its mean); on the utterance averages the error measured in a float64 numpy model of the split is ~0.07 rms(b)
-      // for P = 2 and ~0.14 rms(b) for P = 1.  The thresholds keep that prediction below 6e-6,
-      // less than half a float32 ulp of the ~-150 results and inside the ~3.3e-6 float32 accumulation error every
-      // variant carries (tests/test_gpu_parity.py).  Models adapted further (enrolment on many frames, a small tau,
-      // unrelated means) get more products, up to the full three -- the arithmetic of the non-delta kernels.
-      double sumsq = 0.0;
-      for (int m = 1; m < M; ++m)
-        for (int c = 0; c < C; ++c)
+      // Products per K chunk of the delta items, PER COMPONENT TILE.  P = 2 drops the frames' second f16 term -- an
+      // error of 2^-12 |delta . x| per (frame, component), random in sign from frame to frame --, P = 1 also the
+      // deltas' second term.  b_mk = 2^-12 |delta_mk * (|mu_k| + 3 sigma_k)|_2 bounds the former where component k
+      // matters (x within 3 sigma of its mean).  A frame's error is that of the components that explain it, so the error
+      // of an utterance average is ~c sqrt(sum_k p_k b_mk^2), p_k the share of frames component k explains -- its weight
+      // w_k under the model's own distribution --, with c ~ 0.07 for P = 2 and ~0.14 for P = 1 measured in a float64
+      // numpy model of the split (with equal weights that is the 0.07 / 0.14 rms_k(b) of round 3).
+      // Means-only MAP adaptation moves a component by alpha_k = n_k / (n_k + tau) of the way to the enrolment data's
+      // mean (gmm-global-est-map.cc:31,81): the components the enrolment data occupied move far, the others hardly.  So
+      // the components are SORTED by their contribution w_k max_m b_mk^2 (the order is free under logsumexp; the same
+      // permutation for the quadratic item, the base model and every delta image), and the leading tiles get three
+      // products, the next ones two, the tail one: the smallest sets for which the predicted error of the worst model,
+      //     e^2 = 0.07^2 sum_{k in P = 2 tiles} w_k b_mk^2 + 0.14^2 sum_{k in P = 1 tiles} w_k b_mk^2,
+      // stays below (6e-6)^2 -- under half a float32 ulp of the ~-150 results and inside the ~3.3e-6 float32
+      // accumulation error every variant carries (tests/test_gpu_parity.py).  Models adapted far everywhere (enrolment
+      // on many frames, a small tau, unrelated means) get three products in every tile -- the arithmetic of the non-delta
+      // kernels.
+      std::vector<double> b2((size_t)(M - 1) * C, 0.0), wk(C, 0.0), key(C, 0.0);
+      {
+        const double LOG2PI = 1.8378770664093454835606594728112;
+        double wsum = 0.0;
+        for (int c = 0; c < C; ++c) {  // w_k from the base model's gconst (DiagGmm::ComputeGconsts)
+          double lw = (double)gconsts[c] + 0.5 * D * LOG2PI;
           for (int k = 0; k < D; ++k) {
-            const double ivk = (double)iv[(size_t)c * D + k];
-            const double reach = (fabs((double)miv[(size_t)c * D + k]) + 3.0 * sqrt(ivk)) / ivk;  // |mu| + 3 sigma
-            const double dl = (double)miv[((size_t)m * C + c) * D + k] - (double)miv[(size_t)c * D + k];
-            sumsq += dl * dl * reach * reach;
+            const double ivk = (double)iv[(size_t)c * D + k], mk = (double)miv[(size_t)c * D + k];
+            lw += 0.5 * (mk * mk / ivk - log(ivk));
           }
-      const double rms_b = ldexp(sqrt(sumsq / ((double)(M - 1) * C)), -12);
-      int want_p = rms_b <= 4.3e-5 ? 1 : (rms_b <= 8.6e-5 ? 2 : 3);
-      const char *pe = getenv("FB_GMM_DELTA_P");  // tests: force the number of products
+          wk[c] = std::isfinite(lw) ? exp(std::min(lw, 0.0)) : 0.0;
+          wsum += wk[c];
+        }
+        for (int c = 0; c < C; ++c) wk[c] = wsum > 0.0 ? wk[c] / wsum : 1.0 / C;
+        for (int m = 1; m < M; ++m)
+          for (int c = 0; c < C; ++c) {
+            double sq = 0.0;
+            for (int k = 0; k < D; ++k) {
+              const double ivk = (double)iv[(size_t)c * D + k];
+              const double reach = (fabs((double)miv[(size_t)c * D + k]) + 3.0 * sqrt(ivk)) / ivk;  // |mu| + 3 sigma
+              const double dl = (double)miv[((size_t)m * C + c) * D + k] - (double)miv[(size_t)c * D + k];
+              sq += dl * dl * reach * reach;
+            }
+            b2[(size_t)(m - 1) * C + c] = ldexp(sq, -24);
+            // (the floor keeps a component no frame is expected in from hiding an arbitrarily large shift in the tail)
+            key[c] = std::max(key[c], std::max(wk[c], 0.01 / C) * b2[(size_t)(m - 1) * C + c]);
+          }
+      }
+      std::vector<int> perm(C);
+      for (int c = 0; c < C; ++c) perm[c] = c;
+      std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return key[x] > key[y]; });
+      // e1[t] / e2[t]: worst model's sum over the components of the tiles >= t / of tile t alone
+      std::vector<double> tail(n_tiles + 1, 0.0);
+      std::vector<std::vector<double>> tsum(M - 1, std::vector<double>(n_tiles, 0.0));
+      for (int m = 0; m < M - 1; ++m)
+        for (int t = 0; t < n_tiles; ++t)
+          for (int cc = 0; cc < 32; ++cc) {
+            const int c = perm[t * 32 + cc];
+            tsum[m][t] += std::max(wk[c], 0.01 / C) * b2[(size_t)m * C + c];
+          }
+      auto worst_sum = [&](int t_lo, int t_hi) {
+        double w = 0.0;
+        for (int m = 0; m < M - 1; ++m) {
+          double a = 0.0;
+          for (int t = t_lo; t < t_hi; ++t) a += tsum[m][t];
+          w = std::max(w, a);
+        }
+        return w;
+      };
+      const double budget2 = 6.0e-6 * 6.0e-6, ce1 = 0.14 * 0.14, ce2 = 0.07 * 0.07;
+      int t2 = n_tiles, t3 = n_tiles;  // tiles [0, t3): P = 3, [t3, t2): P = 2, [t2, n_tiles): P = 1
+      while (t2 > 0 && ce1 * worst_sum(t2 - 1, n_tiles) <= 0.75 * budget2) --t2;  // (the P = 1 tail may use 3/4 of the budget)
+      t3 = t2;
+      {
+        const double left = budget2 - ce1 * worst_sum(t2, n_tiles);
+        while (t3 > 0 && ce2 * worst_sum(t3 - 1, t2) <= left) --t3;
+      }
+      const char *pe = getenv("FB_GMM_DELTA_P");  // tests / worst-case benchmark: the same number of products in every tile
       if (pe && *pe) {
         const int v = atoi(pe);
         if (v < 1 || v > 3) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_P must be 1, 2 or 3 (got '%s')", pe);
-        want_p = v;
+        t3 = v == 3 ? n_tiles : 0;
+        t2 = v >= 2 ? n_tiles : 0;
       }
-      e->gmm_delta_rms = rms_b;
+      {  // (reported by fb_gmm_kernel_variant: the equal-weight statistic of round 3)
+        double sumsq = 0.0;
+        for (double v : b2) sumsq += v;
+        e->gmm_delta_rms = sqrt(sumsq / ((double)(M - 1) * C));
+      }
+      const int want_p = (n_tiles - t2 >= t2 - t3 && n_tiles - t2 >= t3) ? 1 : (t2 - t3 >= t3 ? 2 : 3);  // what most tiles run
+      auto tile_p = [&](int t) { return t < t3 ? 3 : (t < t2 ? 2 : 1); };
 
       // The images are in LOG2 units: every parameter is multiplied by log2 e in float64 and then split into its f16
       // terms -- the accumulators of k_gmm_fx2w then hold the exponent of 2 directly and its logsumexp update needs
@@ -585,7 +648,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
               return &im[(((size_t)term * NKF + ch) * 64 + lane) * 8 + i];
             };
             for (int cc = 0; cc < 32; ++cc) {
-              const int c = t * 32 + cc;
+              const int c = perm[t * 32 + cc];
               double cst = m == 0 ? L2E * (double)gconsts[c]
                                   : (m > 0 ? L2E * (double)(gconsts[(size_t)m * C + c] - gconsts[c]) : 0.0);
               for (int k = 0; k < D; ++k) {
@@ -596,7 +659,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
                 const double a = f16r(v);
                 put16(a, at(0, k, cc));
                 put16(v - a, at(1, k, cc));
-                if (m > 0 && want_p == 1)  // the dropped second term at the component's mean (mu' = mu 2^kd)
+                if (m > 0 && tile_p(t) == 1)  // the dropped second term at the component's mean (mu' = mu 2^kd)
                   cst += (v - a) * ldexp((double)miv[(size_t)c * D + k] / (double)iv[(size_t)c * D + k], kd[k]);
               }
               if (m < 0) {  // the frames' reference stands in their x^2 operand as -(R mod 2048), -(R div 2048) (gmm_wide_kernel.hip)
@@ -672,7 +735,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         }
         FBCHK(e->gmm_anchor.ensure(sizeof(float) * an.size()));
         HIPCHK(hipMemcpy(e->gmm_anchor.p, an.data(), sizeof(float) * an.size(), hipMemcpyHostToDevice));
-        if (fits) delta_p = want_p;
+        if (fits) { delta_p = want_p; delta_t3 = t3; delta_t2 = t2; }
       }
     }
   }
@@ -731,6 +794,8 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
   g.images_fx = reinterpret_cast<decltype(g.images_fx)>(e->gmm_images_fx.p);
   g.delta_p = mode == FB_GMM_MODE_FX2 ? delta_p : 0;
+  g.delta_t3 = g.delta_p ? delta_t3 : 0;
+  g.delta_t2 = g.delta_p ? delta_t2 : 0;
   g.images_fd = g.delta_p ? reinterpret_cast<decltype(g.images_fd)>(e->gmm_images_fd.p) : nullptr;
   g.anchor = g.delta_p ? e->gmm_anchor.as<float>() : nullptr;
   g.item_model = e->gmm_items.as<int>();
@@ -898,7 +963,15 @@ static int run_post_mfcc(fb_engine *e, int B) {
   // round trip along on its LDS copy of the matrix when it can (utterances of up to 512 frames: every NES batch)
   const bool cm = e->cfg.compress_feats != 0;
   const bool cm_fused = cm && fb_fuse_on(e) && fb_vad_delta_cmvn_compresses(e->t_max);
-  if (cm && !cm_fused) fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);
+  // (out of place -- every workgroup of k_feat_compress reduces the header from the whole input matrix --, then the two
+  //  buffers swap roles: e->mfcc is the matrix the later stages and fb_debug_mfcc read)
+  auto compress = [&]() -> int {
+    FBCHK(e->mfcc_cm.ensure(sizeof(float) * (size_t)e->h_frame_off[B] * fe.nc));
+    fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->mfcc_cm.as<float>(), e->frame_off.as<int>(), B, e->t_max);
+    std::swap(e->mfcc, e->mfcc_cm);
+    return FB_OK;
+  };
+  if (cm && !cm_fused) FBCHK(compress());
   {  // every utterance fits the CMVN window (all NES batches): VAD, deltas, CMVN and the row offsets in one launch
     const size_t had = e->vad_pub.cap;
     FBCHK(e->vad_pub.ensure(sizeof(unsigned long long) * (size_t)B));
@@ -912,7 +985,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
       e->vad_epoch += 1;
       return FB_OK;
     }
-    if (cm_fused) fb_launch_feat_compress(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max);  // (the batch did not qualify)
+    if (cm_fused) FBCHK(compress());  // (the batch did not qualify)
   }
   fb_launch_vad(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->vrank.as<int>(), e->tv.as<int>(),
                 e->vad_counter.as<int>(), e->row_off.as<int>());
@@ -1987,6 +2060,16 @@ extern "C" int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms) {
   if (shift_rms) *shift_rms = e->gmm_delta_rms;
   if (e->kind == 0 && fb_gmm_use_wide(e->gmm)) return 10 + e->gmm.delta_p;
   return e->gmm.mode;
+}
+
+extern "C" int fb_gmm_delta_tiles(fb_engine *e, int *tiles_p1, int *tiles_p2, int *tiles_p3) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  const bool wide = e->kind == 0 && fb_gmm_use_wide(e->gmm);
+  if (tiles_p3) *tiles_p3 = wide ? e->gmm.delta_t3 : 0;
+  if (tiles_p2) *tiles_p2 = wide ? e->gmm.delta_t2 - e->gmm.delta_t3 : 0;
+  if (tiles_p1) *tiles_p1 = wide ? e->gmm.n_tiles - e->gmm.delta_t2 : 0;
+  return wide ? 1 : 0;
 }
 
 extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T_out) {

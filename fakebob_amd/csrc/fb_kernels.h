@@ -100,7 +100,8 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
 // counter: one device int, zero before the first launch (the kernel leaves it at zero); row_off[B+1]
 // = exclusive scan of max(tv, 0), written by the workgroup that finishes last
 // Kaldi CompressedMatrix round trip of every utterance's MFCC matrix, in place (t_max: longest utterance, frames)
-void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B, int t_max);
+void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, float *out, const int *frame_off, int B,
+                             int t_max);  // out != mfcc: every workgroup reads the whole input matrix
 void fb_launch_vad(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                    int *vrank, int *tv, int *counter, int *row_off);
 // row_off[b] = sum_{b'<b} tv[b'] ; row_off[B] = total
@@ -138,15 +139,20 @@ struct FbGmmDev {
   const unsigned int __attribute__((ext_vector_type(4))) * images_fx;
   // k_gmm_fx2w (one variance group): images [n_tiles][1 + M][2][NKF][64] x 16 B of {Q, base model 0, delta_1 ..
   // delta_{M-1}}, delta_m = (means_invvars, gconst) of model m MINUS the base model's, all times log2 e and without
-  // power-of-two scaling (the frames are used unscaled); delta_p = partial products per K chunk the delta items are
-  // evaluated with (1 .. 3; 0: no delta images); anchor = the frames' balancing factors and the components whose
-  // log2-likelihoods start the kernel's per-frame reference (layout: fb_load_gmm)
+  // common power-of-two factor: every dimension is balanced by exact powers of two of its own, 2^kd / 2^kq, applied to
+  // the frames in the kernel and inversely to the parameters here.  The COMPONENTS are stored sorted by how far the
+  // other models moved them from the base model (the order is free under logsumexp), so that the partial products per K
+  // chunk a delta item needs fall from tile to tile: tiles [0, delta_t3) are evaluated with 3, [delta_t3, delta_t2)
+  // with 2, the rest with 1.  delta_p = the count most tiles use (1 .. 3; 0: no delta images); anchor = the frames'
+  // balancing factors and the components whose log2-likelihoods start the kernel's per-frame reference (layout:
+  // fb_load_gmm)
   const unsigned int __attribute__((ext_vector_type(4))) * images_fd;
-  int delta_p;
+  int delta_p, delta_t3, delta_t2;
   const float *anchor;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
+#define FB_FXW_MAX_M 10   // models k_gmm_fx2w takes: (1 + M) 10 KB items + the state of 2 M x 256 frames = 156 KB of LDS at M = 10
 #define FB_FXW_ANCHORS 2  // anchor components of k_gmm_fx2w's per-frame reference (FbGmmDev::anchor)
 #define FB_GMM_MODE_BX3 1
 #define FB_GMM_MODE_FX2 2
@@ -170,9 +176,10 @@ static inline bool fb_device_needs_optin(std::atomic<unsigned long long> &mask, 
 // true when fb_launch_gmm runs the one-wave-per-SIMD scoring kernel k_gmm_fx2w (256-frame strips, one round of <= 256
 // workgroups): the engine sizes the component chunks for it
 bool fb_gmm_use_wide(const FbGmmDev &g);
-// gmm_wide_kernel.hip: the launch of k_gmm_fx2w (tpc = component tiles per chunk); called by fb_launch_gmm
+// gmm_wide_kernel.hip: the launch of k_gmm_fx2w (chunk c scores the component tiles c, c + n_chunks, ...); called by
+// fb_launch_gmm
 void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
-                        int n_chunks, int tpc, float *part_m, float *part_s);
+                        int n_chunks, float *part_m, float *part_s);
 // part_m/part_s: [n_chunks][M][rows_pad]
 void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                    int rows_cap, int n_chunks, float *part_m, float *part_s);

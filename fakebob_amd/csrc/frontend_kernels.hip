@@ -705,7 +705,10 @@ __device__ __forceinline__ float fb_wave_max_f(float v) {
 //      image of the floats: 32 rounds, each a wave-wide count of the elements below two candidate keys (compare +
 //      ballot + scalar popcount, so the decision is wave-uniform) -- keys in registers for T <= 512, else staged in LDS
 //      (lds_cap per wave), else re-read from global memory every round;
-//   3. every element -> byte -> float, in place.
+//   3. every element -> byte -> float, written to a SECOND matrix: the (utterance, column group) workgroups of an
+//      utterance all reduce the header of step 1 from the whole matrix, so the input must stay as it is while any of
+//      them runs (in place a workgroup could read columns another one had already rewritten -- the rounded maximum of a
+//      compressed column is not always the original's -- and the header would depend on the block schedule).
 // Round 2 ranked every element against every other straight from global memory: T dependent L2 round trips per 64
 // elements, 207 us per NES batch -- the longest kernel of the reference-pipeline mode.
 __device__ __forceinline__ unsigned fb_float_key(float v) {  // a < b  <=>  key(a) < key(b)  (no NaNs; -0 < +0)
@@ -747,8 +750,8 @@ __device__ __forceinline__ void fb_cm_column_header(const unsigned (&kr)[FB_CM_R
   p75 = fb_cm_from_u16(minv, range, u75);
   p100 = fb_cm_from_u16(minv, range, u100);
 }
-__global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc, const int *__restrict__ frame_off,
-                                                       int nc, int lds_cap) {
+__global__ __launch_bounds__(256) void k_feat_compress(const float *__restrict__ mfcc, float *__restrict__ out,
+                                                       const int *__restrict__ frame_off, int nc, int lds_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_key[];  // [4 waves][lds_cap]
   __shared__ float s_lo[4], s_hi[4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -762,17 +765,18 @@ __global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc,
     lo = fb_wave_min_f(lo);
     hi = fb_wave_max_f(hi);
     if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
-    __syncthreads();  // also: every wave has read the matrix before any column is rewritten
+    __syncthreads();
     minv = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
     maxv = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
   }
   const int c = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wv);
   if (c >= nc) return;
-  float *col = mfcc + (size_t)base * nc + c;
+  const float *col = mfcc + (size_t)base * nc + c;
+  float *ocol = out + (size_t)base * nc + c;
   if (maxv == minv) maxv = __fadd_rn(minv, __fadd_rn(1.0f, fabsf(minv)));
   const float range = __fsub_rn(maxv, minv);
   if (T <= 8) {  // kTwoByteAuto
-    if (lane < T) col[(size_t)lane * nc] = fb_cm_from_u16(minv, range, fb_cm_to_u16(minv, range, col[(size_t)lane * nc]));
+    if (lane < T) ocol[(size_t)lane * nc] = fb_cm_from_u16(minv, range, fb_cm_to_u16(minv, range, col[(size_t)lane * nc]));
     return;
   }
   const int q = T / 4;
@@ -839,19 +843,19 @@ __global__ __launch_bounds__(256) void k_feat_compress(float *__restrict__ mfcc,
 #pragma unroll
     for (int r = 0; r < FB_CM_REG; ++r) {
       const int i = 64 * r + lane;
-      if (i < T) col[(size_t)i * nc] = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, fb_key_float(kr[r])));
+      if (i < T) ocol[(size_t)i * nc] = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, fb_key_float(kr[r])));
     }
   } else {
     for (int i = lane; i < T; i += 64) {
-      float *x = col + (size_t)i * nc;
-      *x = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, in_lds ? fb_key_float(sk[i]) : *x));
+      ocol[(size_t)i * nc] = fb_cm_from_char(p0, p25, p75, p100, fb_cm_to_char(p0, p25, p75, p100, in_lds ? fb_key_float(sk[i]) : col[(size_t)i * nc]));
     }
   }
 }
-void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, float *mfcc, const int *frame_off, int B, int t_max) {
+void fb_launch_feat_compress(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, float *out, const int *frame_off, int B,
+                             int t_max) {
   const int cap = t_max <= 64 * FB_CM_REG ? 1 : std::min(t_max, 3840);  // keys per wave in LDS (4 x 15 KB: no opt-in needed)
   hipLaunchKernelGGL(k_feat_compress, dim3(B, (fe.nc + 3) / 4), dim3(256), sizeof(unsigned) * 4 * (size_t)cap, s, mfcc,
-                     frame_off, fe.nc, cap);
+                     out, frame_off, fe.nc, cap);
 }
 
 // ------------------------------------------------------------------ deltas
@@ -1092,7 +1096,7 @@ __global__ __launch_bounds__(1024) void k_delta_cmvn(FbFrontendDev fe, const flo
 //     writes the total (row_off[B], what the GMM kernel reads as its row count).
 // Arithmetic, summation orders and results are those of k_vad + k_delta_cmvn, bit for bit.
 template <int ORDER, int WIN>
-__global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const float *__restrict__ mfcc,
+__global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const float *mfcc,  // (no __restrict__: cm_out may be the same buffer)
                                                          const int *__restrict__ frame_off, int B, int t_cap,
                                                          unsigned epoch, int *__restrict__ ticket,
                                                          unsigned long long *__restrict__ pub, int *__restrict__ tv,

@@ -530,7 +530,7 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
                    int rows_cap, int n_chunks, float *part_m, float *part_s) {
   if (rows_cap <= 0) return;
   const int tpc = (g.n_tiles + n_chunks - 1) / n_chunks;
-  if (fb_gmm_use_wide(g)) fb_launch_gmm_wide(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
+  if (fb_gmm_use_wide(g)) fb_launch_gmm_wide(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s);
   else if (g.mode == FB_GMM_MODE_FX2) launch_gmm_fx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
   else launch_gmm_bx<false>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s);
 }

@@ -7,6 +7,7 @@
 // read them directly as their B operand at the full rate (tools/probes/mfma_operand_probe.hip).
 #include <float.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fb_kernels.h"
 #include "gmm_split.h"
@@ -294,9 +295,9 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
   out1 = x1;
 }
 
-template <int NK, int M, int P>
+template <int NK, int M>
 __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__restrict__ feats,
-                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                     const int *__restrict__ n_rows_ptr, int n_chunks,
                                                      int rows_cap, float *__restrict__ part_m,
                                                      float *__restrict__ part_s, int xcd_map) {
   if (g.stop && *g.stop) return;
@@ -508,10 +509,18 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
 #pragma unroll
   for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = rc[m & 1]; st_s[m * 256 + tid] = 0.0f; }
 
-  const int tile0 = chunk_i * tiles_per_chunk;
-  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
-  const int n_t = tile1 - tile0, total_items = n_t * NI;
-  const u32x4 *gimg = g.images_fd + (size_t)tile0 * NI * IMG4;
+  // Component tiles of this chunk: chunk_i, chunk_i + n_chunks, ... (strided, so that every chunk gets the same mix of
+  // the tile classes below).  fb_load_gmm stores the components SORTED by how far the other models moved them from
+  // the base model (the order is free under logsumexp), so the products per K chunk a delta item needs (P, above
+  // fb_fxw_step) fall from tile to tile: tiles [0, delta_t3) run P = 3, [delta_t3, delta_t2) P = 2, the rest P = 1.
+  const int n_t = chunk_i < g.n_tiles ? (g.n_tiles - chunk_i + n_chunks - 1) / n_chunks : 0;
+  auto tiles_below = [&](int bound) {  // how many of this chunk's tiles have an index < bound
+    const int c = bound > chunk_i ? (bound - chunk_i + n_chunks - 1) / n_chunks : 0;
+    return c < n_t ? c : n_t;
+  };
+  const int n_p3 = tiles_below(g.delta_t3), n_p32 = tiles_below(g.delta_t2);
+  const u32x4 *gimg = g.images_fd;
+  auto tile_of = [&](int t) { return chunk_i + (t < n_t - 1 ? t : n_t - 1) * n_chunks; };  // (clamped: see srcA below)
 
   // ---- parameter stream.  A workgroup barrier per item costs ~400 cycles at one wave per SIMD (the probe's mode 12
   // against 11), so the barrier is taken twice per TILE: slot A holds items 0 .. GA-1, slot B items GA .. NI-1.
@@ -559,13 +568,14 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   FbFxwUpd uu;
   float wd[2] = {1.0f, 1.0f};  // 2^(rp - rc): the factor of the two deferred updates behind a moved reference
   FXW_STAMP(3);
-  fb_fxw_fetch<GA, NPIECE>(gimg + lane, ring_lds, wv);  // group A of the first tile
+  fb_fxw_fetch<GA, NPIECE>(gimg + (size_t)tile_of(0) * NI * IMG4 + lane, ring_lds, wv);  // group A of the first tile
   publish();
   FXW_STAMP(4);
   u32x4 z1, z2;  // chunk 0 of the item in front (fb_fxw_step)
   constexpr int PW_A = (GA * NPIECE + 3) / 4, PW_B = (GB * NPIECE + 3) / 4;  // LDS-DMA pieces per wave for a group
-  for (int t = 0; t < n_t; ++t) {
-    const int it0 = t * NI;
+  // one tile with P products per K chunk in its delta items (a compile-time constant: the tile is straight-line code)
+  auto tile = [&](auto pc, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
     // a rescue of the last tile proposed a new reference for some frame: from this tile on (the two deferred updates
     // below still belong to the old one, rp)
     rp[0] = rc[0]; rp[1] = rc[1];
@@ -591,9 +601,9 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       }
     }
     // this wave's share of the groups requested during this tile: group B of this tile (while A runs), group A of the
-    // next one (while B runs); past the chunk's end the last group is read again and never used
-    const u32x4 *srcB = gimg + (size_t)min(it0 + GA, total_items - GB) * IMG4 + (size_t)wv * (PW_B * 64) + lane;
-    const u32x4 *srcA = gimg + (size_t)min(it0 + NI, total_items - GA) * IMG4 + (size_t)wv * (PW_A * 64) + lane;
+    // chunk's next one (while B runs); past the chunk's end the last tile's group A is read again and never used
+    const u32x4 *srcB = gimg + ((size_t)tile_of(t) * NI + GA) * IMG4 + (size_t)wv * (PW_B * 64) + lane;
+    const u32x4 *srcA = gimg + (size_t)tile_of(t + 1) * NI * IMG4 + (size_t)wv * (PW_A * 64) + lane;
     const unsigned dstB = ring_lds + SLOTB4 * 16 + (unsigned)wv * (PW_B * 1024), dstA = ring_lds + (unsigned)wv * (PW_A * 1024);
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < NI; ++jj) {   // compile-time item index within the tile: 0 = Q, 1 + m = model m
@@ -655,6 +665,12 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       }
       if (jj == GA - 1 || jj == NI - 1) publish();
     }
+  };
+  {
+    int t = 0;
+    for (; t < n_p3; ++t) tile(std::integral_constant<int, 3>{}, t);
+    for (; t < n_p32; ++t) tile(std::integral_constant<int, 2>{}, t);
+    for (; t < n_t; ++t) tile(std::integral_constant<int, 1>{}, t);
   }
   FXW_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -686,9 +702,9 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   FXW_STAMP(7);
 }
 
-template <int NK, int M, int P>
-static void launch_gmm_fxw_p(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
-                             int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
+template <int NK, int M>
+static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
+                             int rows_cap, int n_chunks, float *part_m, float *part_s) {
   const int strips = (rows_cap + 255) / 256;
   dim3 grid((unsigned)strips, (unsigned)n_chunks);
   int xcd_map = 0;
@@ -702,43 +718,33 @@ static void launch_gmm_fxw_p(hipStream_t s, const FbGmmDev &g, const float *feat
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (ldsb > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gmm_fx2w<NK, M, P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gmm_fx2w<NK, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) == hipSuccess)
       optin.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_gmm_fx2w<NK, M, P>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap, part_m, part_s,
+  hipLaunchKernelGGL((k_gmm_fx2w<NK, M>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, n_chunks, rows_cap, part_m, part_s,
                      xcd_map);
-}
-template <int NK, int M>
-static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
-                             int rows_cap, int n_chunks, int tpc, float *part_m, float *part_s) {
-  switch (g.delta_p) {  // products per K chunk of the delta items, chosen by fb_load_gmm
-    case 1: launch_gmm_fxw_p<NK, M, 1>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 2: launch_gmm_fxw_p<NK, M, 2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    default: launch_gmm_fxw_p<NK, M, 3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-  }
 }
 // k_gmm_fx2w is instantiated for the shapes the reference's systems have with the recipe's 72-dimensional features
 // (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models (SV: UBM + 1; OSI: UBM + up
 // to 9 speakers; CSI: up to 10 speakers).  Everything else runs on k_gmm_fx2.
-#define FB_FXW_MAX_M 10  // (1 + M) 10 KB items + the state of 2 M x 256 frames: 156 KB of LDS at M = 10
 bool fb_gmm_use_wide(const FbGmmDev &g) {
   const bool off = getenv("FB_GMM_NARROW") != nullptr;  // read per call: the tests switch it inside one process
   return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && (g.D & 3) == 0 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
          g.M <= FB_FXW_MAX_M && g.item_model_host_q_first && g.delta_p >= 1 && g.images_fd != nullptr && g.anchor != nullptr;
 }
 void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
-                        int n_chunks, int tpc, float *part_m, float *part_s) {
+                        int n_chunks, float *part_m, float *part_s) {
   switch (g.M) {
-    case 2: launch_gmm_fxw_t<5, 2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 3: launch_gmm_fxw_t<5, 3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 4: launch_gmm_fxw_t<5, 4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 5: launch_gmm_fxw_t<5, 5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 6: launch_gmm_fxw_t<5, 6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 7: launch_gmm_fxw_t<5, 7>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 8: launch_gmm_fxw_t<5, 8>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 9: launch_gmm_fxw_t<5, 9>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
-    case 10: launch_gmm_fxw_t<5, 10>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
+    case 2: launch_gmm_fxw_t<5, 2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 3: launch_gmm_fxw_t<5, 3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 4: launch_gmm_fxw_t<5, 4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 5: launch_gmm_fxw_t<5, 5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 6: launch_gmm_fxw_t<5, 6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 7: launch_gmm_fxw_t<5, 7>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 8: launch_gmm_fxw_t<5, 8>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 9: launch_gmm_fxw_t<5, 9>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+    case 10: launch_gmm_fxw_t<5, 10>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
     default: break;  // fb_gmm_use_wide() admits only the cases above
   }
 }

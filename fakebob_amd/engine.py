@@ -74,6 +74,7 @@ class Engine(object):
         self.n_models = M
         self._gmm_shape = (Cn, D)
         self.task = "OSI"
+        self.kind = "gmm"
 
     def load_ivector(self, system, task="OSI"):
         """system: models.IvectorSystem"""
@@ -131,6 +132,16 @@ class Engine(object):
         if rc < 0:
             N.check(rc)
         return {1: "bx3", 2: "fx2"}.get(rc) or "fx2w/%d" % (rc - 10)
+
+    @property
+    def gmm_delta_tiles(self):
+        """(tiles with 1, 2, 3 partial products per K chunk in their delta items): k_gmm_fx2w's per-tile choice for the
+        loaded model (fb_gmm_delta_tiles); (0, 0, 0) when another kernel scores it."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        rc = self._L.fb_gmm_delta_tiles(self._h, C.byref(a), C.byref(b), C.byref(c))
+        if rc < 0:
+            N.check(rc)
+        return (a.value, b.value, c.value)
 
     @property
     def gmm_shift_rms(self):

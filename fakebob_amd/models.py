@@ -99,27 +99,37 @@ def synthetic_ubm_moments(C=2048, D=72, seed=2001):
     return w, mu, var
 
 
-def synthetic_speaker_means(w, mu, spk=0, seed=2100, tau=10.0, frames=200.0):
+def synthetic_speaker_means(w, mu, spk=0, seed=2100, tau=10.0, frames=200.0, occupancy_power=1.0):
     """Mean-only MAP adaptation (build_spk_models.py:170 update_flags 'm'; [EXT] A.8) from a
-    synthetic 200-voiced-frame enrolment utterance with uneven occupancy."""
+    synthetic enrolment of `frames` voiced frames (200) with uneven occupancy
+    n_k ~ w_k u_k^occupancy_power, u ~ Exp(1): alpha_k = n_k / (n_k + tau) of the way to the enrolment mean."""
     rng = np.random.default_rng(seed + spk)
     C, D = mu.shape
     s = _dim_scale(D)
     delta = rng.normal(size=(C, D)) * (0.3 * s)
-    u = rng.exponential(1.0, size=C)
+    u = rng.exponential(1.0, size=C) ** occupancy_power
     n = frames * w * u / np.sum(w * u)
     alpha = n / (n + tau)
     return mu + alpha[:, None] * delta
 
 
-def synthetic_gmm_system(n_speakers=5, C=2048, D=72, seed_ubm=2001, seed_spk=2100):
+# enrolment sizes of the synthetic speakers: SURVEY.md 8(d)'s single 200-frame utterance (alpha ~ 0.01: the headline
+# workload), and what build_spk_models.py:184-224 does with a speaker's whole enrolment set -- tens of thousands of
+# frames, alpha ~ 0.2 - 0.4 where the data fell: the models the scoring kernel meets in a real deployment
+ENROL_SURVEY = dict(enrol_frames=200.0, tau=10.0, occupancy_power=1.0)
+ENROL_REALISTIC = dict(enrol_frames=20000.0, tau=10.0, occupancy_power=2.0)
+
+
+def synthetic_gmm_system(n_speakers=5, C=2048, D=72, seed_ubm=2001, seed_spk=2100, enrol_frames=200.0, tau=10.0,
+                         occupancy_power=1.0):
     """Returns (ubm, [speaker models]) as DiagGmm; speakers share weights and variances with
-    the UBM (so the engine's shared-quadratic path applies, as for real MAP-adapted models)."""
+    the UBM (so the engine's shared-quadratic path applies, as for real MAP-adapted models).
+    Defaults = ENROL_SURVEY; synthetic_gmm_system(**ENROL_REALISTIC) is the heavily enrolled variant."""
     w, mu, var = synthetic_ubm_moments(C, D, seed_ubm)
     ubm = DiagGmm.from_moments(w, mu, var)
     spk = []
     for s in range(n_speakers):
-        mu_s = synthetic_speaker_means(w, mu, s, seed_spk)
+        mu_s = synthetic_speaker_means(w, mu, s, seed_spk, tau=tau, frames=enrol_frames, occupancy_power=occupancy_power)
         m = DiagGmm.from_internal(w, (mu_s / var).astype(np.float32), ubm.inv_vars)
         spk.append(m)
     return ubm, spk

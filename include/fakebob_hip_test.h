@@ -31,11 +31,15 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
  * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
 int fb_gmm_kernel_mode(fb_engine *e);
 /* The kernel fb_score_* / the NES loop launch for the loaded GMM system: 1 = k_gmm_bx3, 2 = k_gmm_fx2 (any number of
- * variance groups, partial tiles, more than 6 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 6 models: the
- * speaker models are scored as deltas from model 0 with P = 1 .. 3 partial products per K chunk; P is chosen by
- * fb_load_gmm from how far the models were adapted -- *shift_rms (nullable) returns that statistic -- and
- * FB_GMM_DELTA_P forces it; FB_GMM_NARROW=1 selects k_gmm_fx2 instead).  Negative FB_E_* without a model. */
+ * variance groups, partial tiles, more than 10 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 10 models: the
+ * speaker models are scored as deltas from model 0 with 1 .. 3 partial products per K chunk, chosen by fb_load_gmm PER
+ * 32-COMPONENT TILE from how far the tile's components were adapted; P = the count most tiles run, *shift_rms
+ * (nullable) returns the rms adaptation statistic; FB_GMM_DELTA_P forces one count for every tile; FB_GMM_NARROW=1
+ * selects k_gmm_fx2 instead).  Negative FB_E_* without a model. */
 int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms);
+/* k_gmm_fx2w's tile classes for the loaded model: how many component tiles run 1 / 2 / 3 partial products per K chunk
+ * in their delta items (all zero, return value 0, when another kernel scores the model; 1 otherwise). */
+int fb_gmm_delta_tiles(fb_engine *e, int *tiles_p1, int *tiles_p2, int *tiles_p3);
 
 /* the GMM kernel the engine scores with, on T rows of D features handed in as they are (no front-end): per-frame
  * log-likelihoods out[m * T + t] of every model (gmm-global-get-frame-likes without --average).  Lets the tests reach

@@ -109,6 +109,50 @@ def test_gmm_split_kernels_are_f32_equivalent(oracle, full_system, monkeypatch):
     assert np.abs(raws["fx2w"] - raws["fx2"]).max() <= 2e-5
 
 
+@pytest.mark.parametrize("enrol", ["frames500", "frames1000", "realistic"])
+def test_products_per_component_tile_follow_the_enrolment(oracle, monkeypatch, enrol):
+    """fb_load_gmm sorts the components by how far the speaker models moved them from the UBM and gives every
+    32-component tile its own number of delta products (Engine.gmm_delta_tiles).  Speakers enrolled on more data than
+    SURVEY.md 8(d)'s 200 frames (alpha_k = n_k / (n_k + tau), gmm-global-est-map.cc:31,81) get a MIX of tile classes --
+    500 / 1 000 frames -- or, enrolled on 20 000 frames (build_spk_models.py:184-224 takes a speaker's whole enrolment
+    set), three products nearly everywhere.  Whatever the mix, the scores must stay within float32 rounding of the
+    float64 oracle and as close to it as the exact bf16 split; one product everywhere (forced) shows what the rule buys."""
+    from fakebob_amd.engine import Engine
+    from fakebob_amd.models import ENROL_REALISTIC, synthetic_gmm_system
+    kw = {"frames500": dict(enrol_frames=500.0), "frames1000": dict(enrol_frames=1000.0), "realistic": ENROL_REALISTIC}[enrol]
+    ubm, spk = synthetic_gmm_system(5, 2048, 72, **kw)
+    cfg = oracle.default_cfg()
+    wavs = [_wav(0), _wav(1), _wav(2, 20000), _wav(5, 30000)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, _ = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
+    err, sys_err, tiles = {}, {}, {}
+    for name, env in (("auto", {}), ("p1", {"FB_GMM_DELTA_P": "1"}), ("p3", {"FB_GMM_DELTA_P": "3"}), ("bx3", {"FB_GMM_MODE": "bx3"})):
+        for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            tiles[name] = e.gmm_delta_tiles
+            raw, _ = e.score_raw(wavs)
+        finally:
+            e.close()
+        err[name] = float(np.abs(raw - raw_o).max())
+        sys_err[name] = float(np.abs((raw[:, 1:] - raw[:, :1]) - (raw_o[:, 1:] - raw_o[:, :1])).max())
+    print("enrolment %s: tiles (P=1, P=2, P=3) %s  max |err| raw %s  speaker - UBM %s" % (enrol, tiles["auto"], err, sys_err))
+    n1, n2, n3 = tiles["auto"]
+    assert n1 + n2 + n3 == 64 and tiles["p1"] == (64, 0, 0) and tiles["p3"] == (0, 0, 64) and tiles["bx3"] == (0, 0, 0)
+    if enrol == "realistic":
+        assert n3 >= 48                      # the full cost nearly everywhere: never a wrong score
+    else:
+        assert n3 >= 4 and n1 >= 4           # a real mix: the sorted order separates far-moved components from the rest
+    assert err["auto"] <= 2e-5 and err["p3"] <= 2e-5, err
+    assert err["auto"] <= 2.0 * err["bx3"] + 2e-6, err
+    assert sys_err["auto"] <= 2.0 * sys_err["bx3"] + 2e-6, sys_err
+    assert err["p1"] > 2.0 * err["auto"], err          # the rule is not vacuous for these models
+
+
 def test_far_adapted_models_keep_three_products(oracle, monkeypatch):
     """The reduced delta products of k_gmm_fx2w are only for speaker models close to model 0.  A model adapted from a
     few frames with a small tau (alpha -> 1: means moved by ~0.3 sigma in every component) must be given the full

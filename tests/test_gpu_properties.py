@@ -101,20 +101,32 @@ def test_ivector_scores_do_not_depend_on_batch_composition():
         e.close()
 
 
-def test_fused_and_unfused_launch_chains_are_bit_identical(monkeypatch):
+@pytest.mark.parametrize("pipeline", [(0, 0), (1, 0), (0, 1), (1, 1)], ids=["plain", "compress", "text", "compress+text"])
+@pytest.mark.parametrize("how", ["env", "api"])
+def test_fused_and_unfused_launch_chains_are_bit_identical(monkeypatch, pipeline, how):
     """The 5-launch NES chain (k_update_perturb, k_vad_delta_cmvn, k_gmm_finalize_loss) and the 8-launch chain
-    (FB_NO_FUSE=1) run the same arithmetic in the same orders: adversarial audio, float64 state and the whole trace
-    must be bit-identical, early stop included."""
+    (FB_NO_FUSE=1, or Engine.set_fused_chain(False) -- what bench.py and attack_main do with three or more attacks in
+    flight) run the same arithmetic in the same orders: adversarial audio, float64 state and the whole trace must be
+    bit-identical, early stop included -- also with the reference pipeline's round trips on (the drop-in modules'
+    default), where the 8-launch chain runs the CompressedMatrix round trip as the stand-alone k_feat_compress and the
+    fused chain as a phase of k_vad_delta_cmvn.  Repeated runs of the 8-launch chain must agree with each other too
+    (k_feat_compress's header once depended on the block schedule)."""
+    compress, text = pipeline
     ubm, spk = synthetic_gmm_system(n_speakers=3, C=128, D=72)
     audio = synthetic_audio(9, 16000)
     outs = []
-    for no_fuse in (False, True):
-        if no_fuse:
-            monkeypatch.setenv("FB_NO_FUSE", "1")
-        else:
-            monkeypatch.delenv("FB_NO_FUSE", raising=False)
+    monkeypatch.delenv("FB_NO_FUSE", raising=False)
+    for no_fuse in (False, True, True):
+        if how == "env":
+            if no_fuse:
+                monkeypatch.setenv("FB_NO_FUSE", "1")
+            else:
+                monkeypatch.delenv("FB_NO_FUSE", raising=False)
         e = Engine(0)
         try:
+            e.set_frontend(compress_feats=compress, text_scores=text)
+            if how == "api":
+                e.set_fused_chain(not no_fuse)
             e.load_gmm([ubm] + spk)
             e.set_system("OSI")
             s0 = e.system_scores(e.score_raw([(audio * 32768).astype(np.int16)])[0])[0]
@@ -124,10 +136,39 @@ def test_fused_and_unfused_launch_chains_are_bit_identical(monkeypatch):
                 outs.append(e.attack(p, audio))
         finally:
             e.close()
-    for a, b in zip(outs[:2], outs[2:]):
-        assert a[1] == b[1] and a[3].shape == b[3].shape
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for k in (2, 4):
+        for a, b in zip(outs[:2], outs[k:k + 2]):
+            assert a[1] == b[1] and a[3].shape == b[3].shape
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert outs[1][3].shape[0] < 40                      # the second attack really stopped early
+
+
+def test_feat_compress_kernel_is_deterministic_and_matches_the_fused_phase(oracle):
+    """k_feat_compress (stand-alone, one workgroup per (utterance, 4 columns)) against the phase of k_vad_delta_cmvn
+    (one workgroup per utterance) and against the oracle's fbo_compress_roundtrip: the same MFCC matrix bit for bit,
+    many times over -- the header every workgroup reduces must come from the uncompressed matrix only."""
+    ubm, spk = synthetic_gmm_system(n_speakers=1, C=64, D=72)
+    wav = (synthetic_audio(4, 40000) * 32768).astype(np.int16)
+    mats = []
+    for fused in (True, False):
+        e = Engine(0)
+        try:
+            e.set_frontend(compress_feats=1)
+            e.set_fused_chain(fused)
+            e.load_gmm([ubm] + spk)
+            for _ in range(6 if not fused else 1):
+                mats.append(e.debug_mfcc(wav))
+        finally:
+            e.close()
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        plain = e.debug_mfcc(wav)
+    finally:
+        e.close()
+    want = oracle.compress_roundtrip(plain)
+    for m in mats:
+        assert np.array_equal(m.view(np.uint32), want.view(np.uint32))
 
 
 def test_more_utterances_than_compute_units(oracle):

@@ -374,11 +374,26 @@ def test_bench_roofline_object_and_traffic_file_follow_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     assert r["frac"] < r["executed_frac"] < 1.0                           # utilisation of the pipe the MFMAs run on
     assert abs(r["solo_frac"] - flops / 110e-6 / 1e12 / want_peak) < 1e-9
+    # per-tile products: the executed flops follow the tile histogram (P = 1 everywhere: (6 + 5) * 160 per (frame, component))
+    r1 = bench._gmm_roofline(flops, 0.06, 0.06, 15300, "fx2w/1", (64, 0, 0))
+    r3 = bench._gmm_roofline(flops, 0.06, 0.06, 15300, "fx2w/3", (0, 0, 64))
+    rm = bench._gmm_roofline(flops, 0.06, 0.06, 15300, "fx2w/1", (32, 0, 32))
+    assert abs(r1["executed_flops_per_launch"] / flops - 11 * 160 / 1728.0) < 1e-12
+    assert abs(r3["executed_flops_per_launch"] / flops - 21 * 160 / 1728.0) < 1e-12
+    assert abs(rm["executed_flops_per_launch"] - 0.5 * (r1["executed_flops_per_launch"] + r3["executed_flops_per_launch"])) < 1.0
     with open(os.path.join(root, "profiles", bench.TRAFFIC_FILE)) as f:
-        tr = json.load(f)["kernels"]
+        tj = json.load(f)
+    tr = tj["kernels"]
     for key in (bench.GMM_TRAFFIC_KEY, "k_iv_contract_dma<lin>+<quad>"):
         assert tr[key]["hbm_bytes_per_launch"] > 0
-    assert bench.GMM_TRAFFIC_KEY in tr
+    # the committed PMC traffic is reported only for the kernel sources it was taken on (a hash of csrc/): a stale
+    # profile gives None + traffic_stale, never another build's number
+    assert len(tj["kernel_source_sha16"]) == 16
+    val, prov = bench.committed_traffic(bench.GMM_TRAFFIC_KEY)
+    if tj["kernel_source_sha16"] == bench.kernel_source_hash():
+        assert val == tr[bench.GMM_TRAFFIC_KEY]["hbm_bytes_per_launch"] and prov["traffic_profiled_on"] == tj["kernel_source_sha16"]
+    else:
+        assert val is None and prov["traffic_stale"] is True
 
 
 def test_kaldi_text_spmatrix_is_lower_triangular_and_writers_round_trip(tmp_path):
