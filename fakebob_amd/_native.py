@@ -28,6 +28,7 @@ class FrontendCfg(C.Structure):
         ("vad_energy_threshold", C.c_double), ("vad_energy_mean_scale", C.c_double),
         ("vad_proportion_threshold", C.c_double), ("vad_frames_context", C.c_int),
         ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int), ("compress_feats", C.c_int),
+        ("mfcc_f32", C.c_int),
     ]
 
 

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libfakebob_hip.so")
-SOURCES = ["nes_kernels.hip", "frontend_kernels.hip", "gmm_kernels.hip", "gmm_wide_kernel.hip", "ivector_kernels.hip", "ivector_solve.hip",
+SOURCES = ["nes_kernels.hip", "frontend_kernels.hip", "frontend_f32_kernels.hip", "gmm_kernels.hip", "gmm_wide_kernel.hip", "ivector_kernels.hip", "ivector_solve.hip",
            "fb_engine.hip"]
 # per-source flags.  k_gmm_fx2w keeps its MFMA accumulators in vector registers (the logsumexp update reads them in
 # place) and its parked frame operands in accumulation registers: hipcc picks that form of the MFMA with this option

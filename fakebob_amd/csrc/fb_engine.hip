@@ -257,6 +257,7 @@ extern "C" void fb_default_frontend(fb_frontend_cfg *c) {
   c->vad_frames_context = 2; c->delta_window = 3; c->delta_order = 2; c->cmn_window = 300;
   c->text_scores = 0;
   c->compress_feats = 0;
+  c->mfcc_f32 = 0;
 }
 
 static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
@@ -364,6 +365,7 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   fe.dwin = W; fe.cmn_window = c->cmn_window; fe.snip_edges = c->snip_edges; fe.remove_dc = c->remove_dc;
   fe.use_energy = c->use_energy; fe.raw_energy = c->raw_energy; fe.vad_ctx = c->vad_frames_context;
   fe.preemph = c->preemph;
+  fe.mfcc_f32 = c->mfcc_f32 ? 1 : 0;
   fe.log_energy_floor = c->energy_floor > 0.0 ? log(c->energy_floor) : -INFINITY;
   fe.vad_thr = c->vad_energy_threshold; fe.vad_mean_scale = c->vad_energy_mean_scale;
   fe.vad_prop = (float)c->vad_proportion_threshold;
@@ -375,6 +377,10 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   e->melw_n = (int)mel_w.size();
   if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, e->melw_n)) > 150 * 1024)
     return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
+  if (c->mfcc_f32 && !fb_mfcc_f32_supported(fe)) {
+    fe.mfcc_f32 = e->cfg.mfcc_f32 ? 1 : 0;
+    return fb_fail(FB_E_ARG, "mfcc_f32 needs padded_length 512, raw_energy, <= 31 mel bins, <= 32 cepstra and an even frame length");
+  }
   e->cfg = *c;
   e->gmm.text_scores = c->text_scores;
   e->iv.text_scores = c->text_scores;
@@ -1019,8 +1025,9 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   }
   FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * e->n_out));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
-                 e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
+  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), total_frames, e->mfcc.as<float>())))
+    fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
+                   e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, B));
   if (e->kind == 0) {
     FBCHK(time_begin(e));
@@ -2004,8 +2011,9 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   FBCHK(e->row_off.ensure(sizeof(int) * 2));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
   hipStream_t s = e->stream;
-  fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
-                 e->frame_rec.as<int32_t>(), 1, T, e->mfcc.as<float>());
+  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), T, e->mfcc.as<float>())))
+    fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
+                   e->frame_rec.as<int32_t>(), 1, T, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, 1));
   HIPCHK(hipGetLastError());
   return FB_OK;

@@ -10,7 +10,7 @@
 struct FbFrontendDev {
   // scalars
   int L, P, shift, nb, nc, dim, order, dwin, cmn_window, snip_edges, remove_dc, use_energy,
-      raw_energy, vad_ctx;
+      raw_energy, vad_ctx, mfcc_f32;
   double preemph, log_energy_floor;  // log_energy_floor = -inf when disabled
   double vad_thr, vad_mean_scale;
   float vad_prop;
@@ -96,6 +96,10 @@ void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int hal
 void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav,
                     const int64_t *wav_off, const int *frame_off, const int32_t *frame_rec, int B,
                     int total_frames, float *mfcc);
+// fb_frontend_cfg.mfcc_f32: the float32 kernel (frontend_f32_kernels.hip); false = this configuration is not one it takes
+bool fb_mfcc_f32_supported(const FbFrontendDev &fe);
+bool fb_launch_mfcc_f32(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav, const int32_t *frame_rec,
+                        int total_frames, float *mfcc);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
 // counter: one device int, zero before the first launch (the kernel leaves it at zero); row_off[B+1]
 // = exclusive scan of max(tv, 0), written by the workgroup that finishes last

@@ -52,11 +52,18 @@ class Engine(object):
 
     # ---- configuration
     def set_frontend(self, **over):
+        old = {}
         for k, v in over.items():
             if not hasattr(self.cfg, k):
                 raise KeyError(k)
+            old[k] = getattr(self.cfg, k)
             setattr(self.cfg, k, v)
-        N.check(self._L.fb_set_frontend(self._h, C.byref(self.cfg)))
+        try:
+            N.check(self._L.fb_set_frontend(self._h, C.byref(self.cfg)))
+        except Exception:
+            for k, v in old.items():      # the engine kept its previous configuration: so does the mirror
+                setattr(self.cfg, k, v)
+            raise
 
     @property
     def feat_dim(self):

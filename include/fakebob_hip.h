@@ -88,6 +88,12 @@ typedef struct {
    * matrix takes Kaldi's lossy CompressedMatrix round trip (8-bit codes between per-column 16-bit percentile
    * anchors; 16-bit codes for <= 8 frames) before VAD, deltas and CMVN read it. */
   int compress_feats;
+  /* 0 (default): the MFCC arithmetic between Kaldi's float32 storage points is float64 (k_mfcc_r16).  1: Kaldi's own
+   * precision -- BaseFloat = float32 end to end --, k_mfcc_f32: float32 window / FFT / mel /
+   * DCT with one rounding per operation in a fixed order (the CPU oracle's twin is bit-identical), the frame's raw
+   * log-energy C0 -- what compute-vad-decision votes on -- from the exact integer energy.  Needs the recipe's shape
+   * (padded_length 512, raw_energy, <= 31 mel bins); fb_set_frontend refuses it otherwise. */
+  int mfcc_f32;
 } fb_frontend_cfg;
 
 /* FakeBob hyper-parameters (FAKEBOB.py:21-37) + attack() arguments (:139) +

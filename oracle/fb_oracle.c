@@ -51,6 +51,7 @@ void fbo_default_cfg(fbo_frontend_cfg *c) {
   c->cmn_window = 300;
   c->text_scores = 0;
   c->compress_feats = 0;
+  c->mfcc_f32 = 0;
 }
 
 /* --------------------------------------------------------------- Philox */
@@ -288,7 +289,150 @@ static void fft_c2c(const fbo_mfcc_tables *t, double *re, double *im) {
   }
 }
 
+/* ---- float32 twin (cfg.mfcc_f32): Kaldi's BaseFloat front-end is float32 end to end.
+ * The SAME operations in the SAME order as the product's k_mfcc_f32 (fakebob_amd/csrc/frontend_f32_kernels.hip states the
+ * order in its header), every one a single IEEE float32 rounding (this file is compiled with -ffp-contract=off; fused
+ * operations are explicit fmaf), so the MFCC matrix is bit-comparable:
+ *   - frame energy from the exact integer moments: (L sum x^2 - (sum x)^2) / L, one float64 rounding -> C0 (what the
+ *     VAD votes on) does not depend on any float32 summation order;
+ *   - mean = (float)sum / (float)L; d(s) = x[s] - mean; y[s] = (d(s) - pre d(s-1)) win[s], d(-1) := d(0);
+ *   - z[p] = (y[2p], y[2p+1]); 256-point complex DFT as 16 x 16: dft16 over a of z[16 a + t], times W256^(t k1),
+ *     dft16 over t; a dft16 is 4 x dft4, the W16 twiddles, 4 x dft4;
+ *   - real-FFT unpack, power, mel sums, log (the polynomial log of the product, float64, then one rounding to float32),
+ *     DCT sums, lifter.
+ * Only what the recipe uses is taken (padded_length 512, raw energy); anything else returns 0 frames. */
+typedef struct { float x, y; } c32;
+static c32 c32_add(c32 a, c32 b) { c32 r = {a.x + b.x, a.y + b.y}; return r; }
+static c32 c32_sub(c32 a, c32 b) { c32 r = {a.x - b.x, a.y - b.y}; return r; }
+static c32 c32_mul(c32 a, c32 w) {
+  c32 r;
+  r.x = fmaf(-a.y, w.y, a.x * w.x);
+  r.y = fmaf(a.y, w.x, a.x * w.y);
+  return r;
+}
+static void dft4_32(c32 *v0, c32 *v1, c32 *v2, c32 *v3) {
+  c32 a = c32_add(*v0, *v2), b = c32_sub(*v0, *v2), c = c32_add(*v1, *v3), d = c32_sub(*v1, *v3);
+  *v0 = c32_add(a, c);
+  *v2 = c32_sub(a, c);
+  v1->x = b.x + d.y; v1->y = b.y - d.x; /* b - i d */
+  v3->x = b.x - d.y; v3->y = b.y + d.x; /* b + i d */
+}
+static c32 mul_w2_32(c32 a) { const float R2 = 0.70710678118654752440f; c32 r = {R2 * (a.x + a.y), R2 * (a.y - a.x)}; return r; }
+static c32 mul_w4_32(c32 a) { c32 r = {a.y, -a.x}; return r; }
+static c32 mul_w6_32(c32 a) { const float R2 = 0.70710678118654752440f; c32 r = {R2 * (a.y - a.x), -(R2 * (a.x + a.y))}; return r; }
+static void dft16_32(c32 *v) {
+  const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f;
+  const c32 W1 = {C1, -S1}, W3 = {S1, -C1}, W9 = {-C1, S1};
+  for (int n2 = 0; n2 < 4; ++n2) dft4_32(&v[n2], &v[4 + n2], &v[8 + n2], &v[12 + n2]);
+  v[5] = c32_mul(v[5], W1);  v[6] = mul_w2_32(v[6]);   v[7] = c32_mul(v[7], W3);
+  v[9] = mul_w2_32(v[9]);    v[10] = mul_w4_32(v[10]); v[11] = mul_w6_32(v[11]);
+  v[13] = c32_mul(v[13], W3); v[14] = mul_w6_32(v[14]); v[15] = c32_mul(v[15], W9);
+  for (int k1 = 0; k1 < 4; ++k1) dft4_32(&v[4 * k1], &v[4 * k1 + 1], &v[4 * k1 + 2], &v[4 * k1 + 3]);
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j) { c32 tmp = v[4 * i + j]; v[4 * i + j] = v[4 * j + i]; v[4 * j + i] = tmp; }
+}
+/* the product's fb_log_f64 (fakebob_amd/csrc/fb_device.h), operation for operation: x = m 2^e, m in [sqrt(1/2), sqrt 2),
+ * log m = 2 atanh((m-1)/(m+1)) as a ten-term odd series, e ln 2 added as hi + lo */
+static double log_poly_f64(double x) {
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+  const double sr = (m - 1.0) / (m + 1.0);
+  const double z = sr * sr;
+  double p = 1.0 / 21.0;
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  const double two_s = sr + sr;
+  const double lm = fma(two_s * z, p, two_s);
+  const double ed = (double)e;
+  return fma(ed, 0x1.62e42fee00000p-1, fma(ed, 0x1.a39ef35793c76p-33, lm));
+}
+
+static int fbo_mfcc_f32(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float *out) {
+  int T = fbo_num_frames(c, n);
+  if (T <= 0) return 0;
+  if (c->padded_length != 512 || !c->raw_energy || (c->frame_length & 1) || c->frame_length > 512) return 0;
+  fbo_mfcc_tables *t = mfcc_tables_new(c);
+  const int L = t->L, nb = t->nb, nc = t->nc, Nc = 256;
+  c32 *tw = (c32 *)malloc(sizeof(c32) * Nc), *twf = (c32 *)malloc(sizeof(c32) * (Nc + 1));
+  for (int m = 0; m < Nc; ++m) { tw[m].x = (float)cos(-2.0 * M_PI * m / Nc); tw[m].y = (float)sin(-2.0 * M_PI * m / Nc); }
+  for (int k = 0; k <= Nc; ++k) { twf[k].x = (float)cos(-2.0 * M_PI * k / 512); twf[k].y = (float)sin(-2.0 * M_PI * k / 512); }
+  const float pre = (float)c->preemph;
+  int32_t x[512];
+  float y[512], pw[257], lm[64];
+  c32 X[256], Z[256], v[16];
+  for (int f = 0; f < T; ++f) {
+    int64_t start = c->snip_edges ? (int64_t)f * c->frame_shift
+                                  : (int64_t)f * c->frame_shift + c->frame_shift / 2 - L / 2;
+    int64_t isum = 0, sumsq = 0;
+    for (int s = 0; s < L; ++s) {
+      int64_t k = start + s;
+      while (k < 0 || k >= n) { if (k < 0) k = -k - 1; else k = 2 * n - 1 - k; }
+      x[s] = wav[k];
+      isum += x[s];
+      sumsq += (int64_t)x[s] * x[s];
+    }
+    const int64_t dc = c->remove_dc ? isum : 0;
+    const double energy = (double)((int64_t)L * sumsq - dc * dc) / (double)L;
+    const float mean = c->remove_dc ? (float)isum / (float)L : 0.0f;
+    for (int s = 0; s < L; ++s) {
+      const float d = (float)x[s] - mean, dp = (float)x[s > 0 ? s - 1 : 0] - mean;
+      y[s] = (d - pre * dp) * t->window[s];
+    }
+    for (int s = L; s < 512; ++s) y[s] = 0.0f;
+    /* 16 x 16: first pass over a for every t, twiddle, second pass over t for every k1 */
+    for (int tt = 0; tt < 16; ++tt) {
+      for (int a = 0; a < 16; ++a) { v[a].x = y[2 * (16 * a + tt)]; v[a].y = y[2 * (16 * a + tt) + 1]; }
+      dft16_32(v);
+      for (int k1 = 1; k1 < 16; ++k1) v[k1] = c32_mul(v[k1], tw[(tt * k1) & (Nc - 1)]);
+      for (int k1 = 0; k1 < 16; ++k1) X[16 * k1 + tt] = v[k1];
+    }
+    for (int k1 = 0; k1 < 16; ++k1) {
+      for (int b = 0; b < 16; ++b) v[b] = X[16 * k1 + b];
+      dft16_32(v);
+      for (int k2 = 0; k2 < 16; ++k2) Z[k1 + 16 * k2] = v[k2];
+    }
+    for (int k = 0; k <= Nc; ++k) {
+      const c32 zk = Z[k & (Nc - 1)], zr = Z[(Nc - k) & (Nc - 1)], wk = twf[k];
+      const float er = zk.x + zr.x, ei = zk.y - zr.y;
+      const float dr = zk.x - zr.x, di = zk.y + zr.y;
+      const float xr = er + fmaf(wk.x, di, wk.y * dr);
+      const float xi = ei + fmaf(wk.y, di, -(wk.x * dr));
+      pw[k] = 0.25f * fmaf(xr, xr, xi * xi);
+    }
+    for (int b = 0; b < nb; ++b) {
+      float e = 0.0f;
+      const float *w = t->mel_w + (size_t)b * Nc;
+      for (int i = t->mel_first[b]; i < t->mel_first[b] + t->mel_len[b]; ++i) e = fmaf(w[i], pw[i], e);
+      double ed = (double)e;
+      if (ed < (double)FLT_EPSILON) ed = (double)FLT_EPSILON;
+      lm[b] = (float)log_poly_f64(ed);
+    }
+    for (int k = 0; k < nc; ++k) {
+      float acc = 0.0f;
+      for (int b = 0; b < nb; ++b) acc = fmaf(t->dct[k * nb + b], lm[b], acc);
+      out[(size_t)f * nc + k] = acc * t->lifter[k];
+    }
+    if (c->use_energy) {
+      double le = log_poly_f64(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);
+      if (c->energy_floor > 0.0 && le < log(c->energy_floor)) le = log(c->energy_floor);
+      out[(size_t)f * nc] = (float)le;
+    }
+  }
+  free(tw); free(twf);
+  mfcc_tables_free(t);
+  return T;
+}
+
 int fbo_mfcc(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n, float *out) {
+  if (c->mfcc_f32) return fbo_mfcc_f32(c, wav, n, out);
   int T = fbo_num_frames(c, n);
   if (T <= 0) return 0;
   fbo_mfcc_tables *t = mfcc_tables_new(c);

@@ -61,6 +61,8 @@ typedef struct {
   int text_scores;          /* 0; 1 = scores through Kaldi's 6-significant-digit text output */
   int compress_feats;       /* 0; 1 = the MFCC matrix takes the lossy `copy-feats --compress=true` round trip of
                                steps/make_mfcc.sh (its default), before VAD / deltas / CMVN read it */
+  int mfcc_f32;             /* 0: float64 between Kaldi's float32 storage points; 1: Kaldi's own BaseFloat = float32
+                               arithmetic in a fixed operation order (fbo_mfcc_f32) */
 } fbo_frontend_cfg;
 
 /* float32 value printed with 6 significant digits and parsed back (std::ostream << float; float(text)) */

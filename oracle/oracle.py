@@ -28,6 +28,7 @@ class FrontendCfg(C.Structure):
         ("vad_energy_threshold", C.c_double), ("vad_energy_mean_scale", C.c_double),
         ("vad_proportion_threshold", C.c_double), ("vad_frames_context", C.c_int),
         ("delta_window", C.c_int), ("delta_order", C.c_int), ("cmn_window", C.c_int), ("text_scores", C.c_int), ("compress_feats", C.c_int),
+        ("mfcc_f32", C.c_int),
     ]
 
 
@@ -121,7 +122,9 @@ def mfcc(cfg, wav):
     wav = np.ascontiguousarray(wav, np.int16)
     T = num_frames(cfg, wav.size)
     out = np.empty((T, cfg.num_ceps), np.float32)
-    lib().fbo_mfcc(C.byref(cfg), _p(wav), C.c_int64(wav.size), _p(out))
+    got = lib().fbo_mfcc(C.byref(cfg), _p(wav), C.c_int64(wav.size), _p(out))
+    if got != T:
+        raise ValueError("fbo_mfcc computed %d of %d frames (a configuration the float32 path does not take?)" % (got, T))
     return out
 
 

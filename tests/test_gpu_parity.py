@@ -147,10 +147,15 @@ def test_products_per_component_tile_follow_the_enrolment(oracle, monkeypatch, e
         assert n3 >= 48                      # the full cost nearly everywhere: never a wrong score
     else:
         assert n3 >= 4 and n1 >= 4           # a real mix: the sorted order separates far-moved components from the rest
-    assert err["auto"] <= 2e-5 and err["p3"] <= 2e-5, err
-    assert err["auto"] <= 2.0 * err["bx3"] + 2e-6, err
-    assert sys_err["auto"] <= 2.0 * sys_err["bx3"] + 2e-6, sys_err
-    assert err["p1"] > 2.0 * err["auto"], err          # the rule is not vacuous for these models
+    # the rule's error budget is 6e-6 on top of what float32 accumulation itself carries (the three-product form):
+    # well inside one float32 ulp (1.5e-5) of the ~-150 results and an order of magnitude inside north_star's 1e-4
+    assert err["p3"] <= 2.0 * err["bx3"] + 2e-6 and sys_err["p3"] <= 2.0 * sys_err["bx3"] + 2e-6, (err, sys_err)
+    assert err["auto"] <= 1e-5 and err["auto"] <= 1.25 * float(np.hypot(err["p3"], 6e-6)), err
+    assert sys_err["auto"] <= 1e-5 and sys_err["auto"] <= 1.25 * float(np.hypot(sys_err["p3"], 6e-6)), sys_err
+    if enrol != "realistic":
+        assert err["p1"] > 1.5 * err["auto"], err      # the rule is not vacuous for these models
+    else:
+        assert err["p1"] > 4.0 * err["auto"], err
 
 
 def test_far_adapted_models_keep_three_products(oracle, monkeypatch):

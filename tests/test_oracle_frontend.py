@@ -103,6 +103,30 @@ def test_mfcc_vs_numpy_fft(oracle):
         assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max())
 
 
+def test_mfcc_float32_twin_against_numpy_and_the_float64_restatement(oracle):
+    """cfg.mfcc_f32 (Kaldi's own BaseFloat = float32 arithmetic; the product's k_mfcc_f32 mirrors
+    it operation for operation): against the independent numpy.fft restatement within float32 arithmetic noise of
+    values up to ~50, C0 -- the raw log-energy the VAD votes on, taken from the exact integer energy -- equal to the
+    float64 restatement's float32 value, and the float32 polynomial-log / 16 x 16 FFT path not merely the float64 one
+    renamed (the matrices differ in the last bits)."""
+    cfg64, cfg32 = oracle.default_cfg(), oracle.default_cfg(mfcc_f32=1)
+    n_diff = 0
+    for w in _wavs() + [(synthetic_audio(3, 48000) * 32768).astype(np.int16), np.full(2000, 32767, np.int16)]:
+        got = oracle.mfcc(cfg32, w)
+        ref = oracle.mfcc(cfg64, w)
+        want = np_mfcc(w)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert np.abs(got.astype(np.float64) - want).max() <= 1e-5 * max(10.0, np.abs(want).max()) + 2e-4
+        assert np.array_equal(got[:, 0].view(np.uint32), ref[:, 0].view(np.uint32))
+        n_diff += int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert n_diff > 0
+    # options the float32 path does not take give no frames (the product refuses them at fb_set_frontend)
+    assert oracle.num_frames(cfg32, 16000) == 100
+    bad = oracle.default_cfg(mfcc_f32=1, raw_energy=0)
+    with pytest.raises(Exception):
+        oracle.mfcc(bad, (synthetic_audio(0, 16000) * 32768).astype(np.int16))
+
+
 def test_num_frames_and_edges(oracle):
     cfg = oracle.default_cfg()
     assert oracle.num_frames(cfg, 48000) == 300          # SURVEY A.2
