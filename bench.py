@@ -110,14 +110,14 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(audio, models, params_kw, faithful=False):
+def cpu_baseline(audio, models, params_kw, faithful=False, mfcc_f32=0):
     """Times the CPU oracle (the build's C restatement of the identical computation; Kaldi itself
     cannot be installed offline) on one full NES iteration of the same workload, 1 thread --
     the reference's default n_jobs=1 (attackMain.sh:34)."""
     from oracle import oracle as O
     from fakebob_amd.models import stack_models
     gc, miv, iv = stack_models(models)
-    ocfg = O.default_cfg(compress_feats=1, text_scores=1) if faithful else O.default_cfg()
+    ocfg = O.default_cfg(compress_feats=1, text_scores=1, mfcc_f32=mfcc_f32) if faithful else O.default_cfg(mfcc_f32=mfcc_f32)
     ctx = O.GmmSystemCtx(ocfg, "OSI", gc, miv, iv, nthreads=1)
     po = O.nes_params("OSI", "targeted", ctx.S, **params_kw)
     t0 = time.perf_counter()
@@ -220,6 +220,7 @@ def bench_ivector(args, torch):
     engs = []
     for k in range(K):
         e = Engine(dev_index)
+        e.set_frontend(mfcc_f32=int(args.frontend == "f32"))
         e.load_ivector(sy, task)
         e.set_fused_chain(fused)
         engs.append(e)
@@ -322,7 +323,7 @@ def bench_ivector(args, torch):
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             import numpy as np
-            ctx = O.IvSystemCtx(O.default_cfg(), sy, nthreads=1)
+            ctx = O.IvSystemCtx(O.default_cfg(mfcc_f32=int(args.frontend == "f32")), sy, nthreads=1)
             n_s = min(B, SPD + 1)                                # a bounded sample: at most 51 utterances (seconds of CPU work)
             wavs = [(synthetic_audio(u, N_SAMPLES) * 32768).astype(np.int16) for u in range(n_s)]
             t0 = time.perf_counter()
@@ -520,6 +521,9 @@ def main():
                     help="run the reference pipeline's two file round trips on the device (MFCCs through Kaldi's "
                          "CompressedMatrix, scores through 6-digit text: gmm_ubm_kaldiHelper.py:138-140, 236-248) -- "
                          "the drop-in modules' default; the headline line is measured without them")
+    ap.add_argument("--frontend", default="f32", choices=["f32", "f64"],
+                    help="MFCC arithmetic: f32 = Kaldi's own BaseFloat precision (fb_frontend_cfg.mfcc_f32, k_mfcc_f32; C0 from "
+                         "the exact integer energy), f64 = float64 between Kaldi's float32 storage points (k_mfcc_r16)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even with one rank (exercises RCCL on a 1-GPU box)")
     args = ap.parse_args()
@@ -553,6 +557,7 @@ def main():
     engs, auds, prms = [], [], []
     for k in range(K):
         e = Engine(dev_index)
+        e.set_frontend(mfcc_f32=int(args.frontend == "f32"))
         if args.faithful:
             e.set_frontend(compress_feats=1, text_scores=1)
         e.load_gmm(models)
@@ -610,8 +615,8 @@ def main():
             "value": its, "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; f64 front-end/NES)",
-                      "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; f64 front-end/NES)"}[GMM_MODE],
+            "dtype": {"fx2": "f32 (GMM: two-term f16 split on MFMA, f32 accumulate, f32-equivalent; %s MFCC; f64 NES)",
+                      "bx3": "f32 (GMM: exact bf16x3 split on MFMA, f32 accumulate; %s MFCC; f64 NES)"}[GMM_MODE] % args.frontend,
             "data": "synthetic",
             "scored_utts_per_s": its * (SPD + 1),
             "vs_readme_nominal": its / README_GMM_ITS if gmm_task == "OSI" else None,
@@ -622,6 +627,8 @@ def main():
                                    % (wl, K, "; reference-pipeline round trips ON (compress_feats, text_scores)" if args.faithful else "",
                                       "; speakers enrolled on 20 000 frames (models.ENROL_REALISTIC)" if args.enrol == "realistic" else ""),
                        "faithful_pipeline": bool(args.faithful), "enrolment": args.enrol,
+                       "frontend_precision": {"f32": "float32 MFCC (Kaldi's BaseFloat; C0 from the exact integer energy), float64 "
+                                                     "deltas / CMVN sums", "f64": "float64 between Kaldi's float32 storage points"}[args.frontend],
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
                        "launch_chain": "5 launches per iteration (fused)" if fused else "8 launches per iteration",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
@@ -689,6 +696,12 @@ def main():
             reload(models, "OSI", (None, None), kw, "targeted", frontend=dict(compress_feats=1, text_scores=1))
             gmm_case("faithful", "the reference pipeline's two file round trips ON (CompressedMatrix MFCCs, 6-digit score "
                      "text): the drop-in modules' default", n_models)
+            if args.frontend == "f32":
+                reload(models, "OSI", (None, None), kw, "targeted", frontend=dict(compress_feats=0, text_scores=0, mfcc_f32=0))
+                gmm_case("frontend_f64", "the headline workload with the float64-between-storage-points MFCC kernel "
+                         "(k_mfcc_r16) instead of the float32 one", n_models)
+                for e_ in engs:
+                    e_.set_frontend(mfcc_f32=1)
             m_c, atk_c, kw_c, z_c = system_of("CSI", ubm, spk)
             reload(m_c, "CSI", z_c, kw_c, atk_c)
             gmm_case("gmm_csi", "BASELINE.json configs[3]'s per-GPU work: GMM CSI untargeted, 5 speaker models, no UBM "
@@ -702,13 +715,13 @@ def main():
     engs = []
     if rank == 0 and out is not None and "secondary" in out and "error" not in out["secondary"]:
         try:
-            out["secondary"].update(secondary_ivector(torch, dev_index, K))
+            out["secondary"].update(secondary_ivector(torch, dev_index, K, int(args.frontend == "f32")))
         except Exception as ex:  # noqa: BLE001
             out["secondary"]["ivector_error"] = repr(ex)[:300]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and gmm_task == "OSI":
             ckw = dict(kw)
-            out["cpu_baseline"] = cpu_baseline(audio, models, ckw, args.faithful)
+            out["cpu_baseline"] = cpu_baseline(audio, models, ckw, args.faithful, int(args.frontend == "f32"))
             out["gpu_over_cpu_port"] = its / out["cpu_baseline"]["value"]
         emit(out)
     if dist is not None:
@@ -716,7 +729,7 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_ivector(torch, dev_index, K):
+def secondary_ivector(torch, dev_index, K, mfcc_f32=1):
     """i-vector-PLDA SV spd=50 (configs[2]) and OSI, 10 speakers, spd=200 (configs[4]'s share of one GPU) with small step
     counts: the numbers `--arch iv` reports in full, under the default line."""
     from fakebob_amd.engine import Engine, nes_params
@@ -731,6 +744,7 @@ def secondary_ivector(torch, dev_index, K):
         engs = []
         for k in range(K):
             e = Engine(dev_index)
+            e.set_frontend(mfcc_f32=mfcc_f32)
             e.load_ivector(sy, task)
             engs.append(e)
         aset = AttackSet(engs, [nes_params(task, "targeted", seed=42, stream=k, **kw) for k in range(K)],
