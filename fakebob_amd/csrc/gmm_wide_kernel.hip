@@ -265,26 +265,41 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
     }
     if (kk == (KP > 3 ? 3 : KP - 1) && c < dn) fb_glds16(dsrc + (dq0 + c) * 64, ddst + (unsigned)(dq0 + c) * 1024u);
     if constexpr (UPD) {
-      const int sl0 = (g * NS) / NG, sl1 = ((g + 1) * NS) / NG;  // the 20 slices dealt evenly over the gaps
+      // the 20 slices as 80 single instructions -- a slice = {addition half 0, addition half 1, exponential half 0,
+      // exponential half 1} --, dealt evenly over the gaps: with 30 MFMAs per step a gap carries two or three of them
+      // (whole slices put four into two gaps of three and stretched each by ~3 ns -- valu_cost_probe's "2 v_exp + 2 v_add
+      // behind an MFMA" --: k_gmm_fx2w with three products per delta item 99 -> 82 us, round 4)
+      const int m0 = (g * 4 * NS) / NG, m1 = ((g + 1) * 4 * NS) / NG;
 #pragma unroll
-      for (int sl = sl0; sl < sl1; ++sl) {
-        // value r's exponential is added TWO slices after it was issued: with two slices in a gap an addition would
-        // otherwise read a transcendental result with only transcendentals in between -- an s_nop each, 70 per tile
+      for (int mm = m0; mm < m1; ++mm) {
+        const int sl = mm >> 2, part = mm & 3;
+        // value r's exponential is added TWO slices after it was issued: an addition must not read a transcendental
+        // result with only transcendentals in between -- an s_nop each, 70 per tile
         const int r = sl - 1;          // the value whose exponential this slice issues (0 .. 15)
         const int ra = sl - 3;         // the value this slice adds (its exponential is ea)
-        if (sl == 0) { u.so0 = ps[0]; u.so1 = ps[256]; }
-        if (ra == 0) { se0 = ea0; se1 = ea1; }                                        // value 0 starts the even sums
-        else if (ra == 1) { sd0 = ea0; sd1 = ea1; }                                   // value 1 the odd ones
-        else if (ra >= 2 && ra <= 15 && !(ra & 1)) { se0 = fb_v_add(se0, ea0); se1 = fb_v_add(se1, ea1); }
-        else if (ra >= 2 && ra <= 15) { sd0 = fb_v_add(sd0, ea0); sd1 = fb_v_add(sd1, ea1); }
-        ea0 = eb0; ea1 = eb1;
-        if (r >= 0 && r <= 15) { eb0 = fb_v_exp(p0[r]); eb1 = fb_v_exp(p1[r]); }
-        if (sl == NS - 1) {  // (value 15 was added in this slice: ra = 16 - ... see the static_assert below)
-          // the state is relative to the set's reference unless a rescue moved the frame's reference between the tile
-          // the set belongs to and this one: wd is 2^(old - new) then, 1 otherwise (kernel, tile boundary)
-          u.sn0 = DEFERRED ? fb_v_fma(fb_v_add(se0, sd0), wd0, u.so0) : fb_v_add(fb_v_add(se0, sd0), u.so0);
-          u.sn1 = DEFERRED ? fb_v_fma(fb_v_add(se1, sd1), wd1, u.so1) : fb_v_add(fb_v_add(se1, sd1), u.so1);
-          ps[0] = u.sn0; ps[256] = u.sn1;
+        if (part == 0) {
+          if (ra == 0) se0 = ea0;                                        // value 0 starts the even sums
+          else if (ra == 1) sd0 = ea0;                                   // value 1 the odd ones
+          else if (ra >= 2 && ra <= 15 && !(ra & 1)) se0 = fb_v_add(se0, ea0);
+          else if (ra >= 2 && ra <= 15) sd0 = fb_v_add(sd0, ea0);
+        } else if (part == 1) {
+          if (ra == 0) se1 = ea1;
+          else if (ra == 1) sd1 = ea1;
+          else if (ra >= 2 && ra <= 15 && !(ra & 1)) se1 = fb_v_add(se1, ea1);
+          else if (ra >= 2 && ra <= 15) sd1 = fb_v_add(sd1, ea1);
+          ea0 = eb0; ea1 = eb1;
+        } else if (part == 2) {
+          if (sl == 0) { u.so0 = ps[0]; u.so1 = ps[256]; }
+          if (r >= 0 && r <= 15) eb0 = fb_v_exp(p0[r]);
+        } else {
+          if (r >= 0 && r <= 15) eb1 = fb_v_exp(p1[r]);
+          if (sl == NS - 1) {  // (value 15 was added in this slice's first two parts)
+            // the state is relative to the set's reference unless a rescue moved the frame's reference between the tile
+            // the set belongs to and this one: wd is 2^(old - new) then, 1 otherwise (kernel, tile boundary)
+            u.sn0 = DEFERRED ? fb_v_fma(fb_v_add(se0, sd0), wd0, u.so0) : fb_v_add(fb_v_add(se0, sd0), u.so0);
+            u.sn1 = DEFERRED ? fb_v_fma(fb_v_add(se1, sd1), wd1, u.so1) : fb_v_add(fb_v_add(se1, sd1), u.so1);
+            ps[0] = u.sn0; ps[256] = u.sn1;
+          }
         }
       }
     }
