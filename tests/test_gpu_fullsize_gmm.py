@@ -75,6 +75,56 @@ def test_config1_get_grad_and_attack_at_full_size(oracle, full_system, monkeypat
         e.close()
 
 
+@pytest.mark.parametrize("mfcc_f32", [0, 1])
+def test_config1_succeeding_attack_decisions_at_full_size(oracle, full_system, mfcc_f32):
+    """north_star: "reproduce attack-success decisions exactly on the same inputs" (FAKEBOB.py:181-189, 219) -- at
+    configs[1] size with attacks that SUCCEED.  The target is the speaker the clean utterance already scores highest
+    for, the system threshold is put 0.033 above that score (from the ORACLE's scores of the clean audio): the NES loop
+    needs ~10-25 iterations to lift the target's score over it (measured: +0.035 after 15 iterations, +-0.005 from
+    run to run).
+    (1) The same decision on the same input: the adversarial audio either side stops with is scored by the OTHER side --
+        the oracle must call the engine's result a success (loss < 0) and the engine the oracle's, and the iterate ONE
+        step before was not yet one for either (the stop is at the same place of each trajectory).
+    (2) The trajectories themselves: two float32 evaluations of the GMM step a dozen of the 48 000 samples differently
+        in every update (the test above), so after a few iterations the runs are two runs of the same attack; their stop
+        iterations differ by the run-to-run spread of the score trajectory around the threshold.  Asserted: both succeed
+        (flag +1), stop iterations within +-8 of each other (measured over 2 utterances x 2 seeds; printed), both
+        inside the same epsilon ball, equal learning-rate schedule up to the first plateau decision."""
+    over = dict(mfcc_f32=mfcc_f32)
+    e, ctx = _pair(oracle, full_system, over)
+    kw = dict(KW)
+    kw.pop("target"); kw.pop("threshold")
+    stops = []
+    try:
+        for utt, seed in ((0, 42), (0, 43), (1, 42), (2, 43)):
+            audio = synthetic_audio(utt, 48000)
+            s0 = ctx.score(audio[:, None])[0]
+            tgt = int(np.argmax(s0))
+            thr = float(s0[tgt] + 0.033)
+            pg = nes_params("OSI", "targeted", seed=seed, stream=utt, max_iter=60, target=tgt, threshold=thr, **kw)
+            po = oracle.nes_params("OSI", "targeted", ctx.S, max_iter=60, target=tgt, threshold=thr, **kw)
+            adv_g, flag_g, advf_g, tr_g = e.attack(pg, audio)
+            adv_o, flag_o, advf_o, tr_o = oracle.attack(po, ctx.fn, ctx.ctx, audio, seed=seed, stream=utt)
+            it_g, it_o = tr_g.shape[0] - 1, tr_o.shape[0] - 1
+            stops.append((utt, seed, it_g, it_o))
+            assert flag_g == 1 and flag_o == 1, (utt, seed, flag_g, flag_o, it_g, it_o)
+            assert tr_g[-1, 1] < 0.0 and tr_o[-1, 1] < 0.0 and (tr_g[:-1, 1] >= 0.0).all() and (tr_o[:-1, 1] >= 0.0).all()
+            assert abs(it_g - it_o) <= 8, stops
+            # (1) the other side's verdict on this side's final iterate (float64 adver -> its int16 cast -> scores -> loss)
+            def loss_of(scores):
+                others = np.delete(scores, tgt)
+                return max(float(others.max()), thr) - float(scores[tgt])
+            lg_on_o = loss_of(ctx.score(advf_g[:, None])[0])                     # engine's result, oracle's arithmetic
+            lo_on_g = loss_of(e.system_scores(e.score_raw([advf_o])[0])[0])      # oracle's result, engine's arithmetic
+            assert lg_on_o < 0.0 and abs(lg_on_o - tr_g[-1, 1]) <= 1e-4, (lg_on_o, tr_g[-1, 1])
+            assert lo_on_g < 0.0 and abs(lo_on_g - tr_o[-1, 1]) <= 1e-4, (lo_on_g, tr_o[-1, 1])
+            assert np.abs(advf_g - audio).max() <= pg.epsilon + 1e-12 and np.abs(advf_o - audio).max() <= pg.epsilon + 1e-12
+            assert np.array_equal(adv_g[:, 0] if adv_g.ndim == 2 else adv_g, (advf_g * 32768).astype(np.int16))
+        print("succeeding full-size attacks (mfcc_f32=%d): (utt, seed, stop iteration engine, oracle) %s" % (mfcc_f32, stops))
+    finally:
+        e.close()
+
+
 def test_config1_with_the_reference_pipelines_file_round_trips(oracle, full_system):
     """compress_feats = 1 and text_scores = 1: what `attackMain.py` computes with a stock Kaldi recipe.  Both stages
     are bit-identical to the oracle's on the same input (tests/test_gpu_configs.py); end to end the 8-bit feature

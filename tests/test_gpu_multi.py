@@ -92,3 +92,37 @@ def test_driver_under_torchrun_matches_a_single_process_run(tmp_path, backend):
             assert len(ta) == len(tb)
             for ra, rb in zip(ta, tb):
                 assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu_weak_scaling_arithmetic():
+    """`python bench.py --gpus 2` outside torchrun re-executes itself under torch.distributed.run with one rank per
+    GPU; with --same-device --dist-backend gloo both ranks share cuda:0, which runs the whole N > 1 path of the bench on
+    a one-GPU box on every driver run: the self-launch, RANK / WORLD_SIZE handling, the barrier + max-over-ranks timing,
+    the all-reduced step counters (asserted inside bench.py: world x steps x attacks) and rank 0's single JSON line.
+    The weak-scaling arithmetic is checked against an N = 1 run of the same per-rank work: two ranks on one device do
+    twice the steps, so `value` lies between the N = 1 value (perfect serialisation of the two ranks' kernels) and
+    twice it (never: they share the chip), with room for launch-gap filling."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    common = ["--steps", "30", "--warmup", "5", "--streams", "1", "--no-cpu-baseline", "--no-secondary", "--no-single",
+              "--precondition", "20"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0 only
+        return json.loads(lines[0])
+    one = run([])
+    two = run(["--gpus", "2", "--same-device", "--dist-backend", "gloo"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["steps"] == 30 and two["config"]["attacks_in_flight_per_gpu"] == 1
+    for d in (one, two):
+        assert d["metric"].startswith("NES iterations/sec") and d["unit"] == "NES iterations/s"
+        assert abs(d["scored_utts_per_s"] - 51 * d["value"]) <= 1e-6 * d["scored_utts_per_s"]
+    # value = (world x steps x attacks) / max-over-ranks time
+    assert abs(two["value"] - 2 * 30 / (two["ms_per_step"] * 30 * 1e-3)) <= 1e-6 * two["value"]
+    assert abs(one["value"] - 1 * 30 / (one["ms_per_step"] * 30 * 1e-3)) <= 1e-6 * one["value"]
+    print("bench N=1 %.0f it/s, N=2 ranks on one device %.0f it/s" % (one["value"], two["value"]))
+    assert 0.8 * one["value"] <= two["value"] <= 2.05 * one["value"]
