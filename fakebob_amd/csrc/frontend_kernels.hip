@@ -970,6 +970,32 @@ __global__ __launch_bounds__(256) void k_cmvn_sliding(FbFrontendDev fe, const fl
     }
   }
 }
+// The CMVN column sum of an utterance's delta features, float64, in a FIXED blocked order: FB_CMVN_PARTS blocks of
+// ceil(T / FB_CMVN_PARTS) frames, each summed frame by frame from zero, the block sums combined left to right.  (Kaldi's
+// running window sum is the straight frame-by-frame order; float64 makes the difference ~1e-16 relative, and one order
+// shared by every kernel below keeps them bit-identical to each other: k_vad_delta_cmvn_p splits an utterance over
+// FB_CMVN_PARTS workgroups, one block each.)
+#define FB_CMVN_PARTS 4
+__device__ __forceinline__ double fb_cmvn_colsum(const float *__restrict__ s_df, int T, int dim, int d) {
+  const int tq = (T + FB_CMVN_PARTS - 1) / FB_CMVN_PARTS;
+  double tot = 0.0;
+#pragma unroll
+  for (int p = 0; p < FB_CMVN_PARTS; ++p) {
+    const int t0 = min(T, p * tq), t1 = min(T, t0 + tq);
+    double acc = 0.0;
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {  // the loads of 8 frames are issued before their (dependent) adds
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)x[u];
+    }
+    for (; t < t1; ++t) acc += (double)s_df[t * dim + d];
+    tot = p == 0 ? acc : tot + acc;
+  }
+  return tot;
+}
 // add-deltas | apply-cmvn-sliding | select-voiced-frames for utterances that fit the CMVN window
 // (every NES batch): one workgroup per utterance keeps the MFCCs and the delta features in LDS, so
 // the delta features never travel to HBM.  The mean is the float64 sum over the frames in order
@@ -1058,19 +1084,7 @@ __global__ __launch_bounds__(1024) void k_delta_cmvn(FbFrontendDev fe, const flo
     }
   }
   __syncthreads();
-  if (tid < dim) {  // frames in order; the loads of 8 frames are issued before their (dependent) adds
-    double acc = 0.0;
-    int t = 0;
-    for (; t + 8 <= T; t += 8) {
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + tid];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)x[u];
-    }
-    for (; t < T; ++t) acc += (double)s_df[t * dim + tid];
-    s_sum[tid] = acc;
-  }
+  if (tid < dim) s_sum[tid] = fb_cmvn_colsum(s_df, T, dim, tid);
   __syncthreads();
   // ---- CMVN + voiced-row compaction: wave = frame, lane = dimension
   const int rbase = row_off[b];
@@ -1275,19 +1289,7 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
   }
   __syncthreads();
   const double alpha = (double)(float)(-1.0 / (double)T);
-  if (tid < dim) {  // frames in order; the loads of 8 frames are issued before their (dependent) adds
-    double acc = 0.0;
-    int t = 0;
-    for (; t + 8 <= T; t += 8) {
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + tid];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)x[u];
-    }
-    for (; t < T; ++t) acc += (double)s_df[t * dim + tid];
-    s_sum[tid] = __dmul_rn(alpha, acc);  // the shift CMVN adds
-  }
+  if (tid < dim) s_sum[tid] = __dmul_rn(alpha, fb_cmvn_colsum(s_df, T, dim, tid));  // the shift CMVN adds
   // ---- row offset: voiced counts of the utterances before this one (published above by their workgroups), read by
   //      the waves the sums leave idle (dim <= 128 here: waves 2 .. 15; otherwise by everybody, after the sums)
   {
@@ -1325,6 +1327,241 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
     if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[idx], s_sum[d]);
   }
 }
+// k_vad_delta_cmvn with an utterance split over FB_CMVN_PARTS workgroups of 256 threads (round 4: one workgroup per
+// utterance kept 51 of 256 compute units busy for 25 us per NES batch).  Part p owns the frames [p tq, (p + 1) tq), tq =
+// ceil(T / FB_CMVN_PARTS):
+//   * every part takes the whole C0 column (T floats) and repeats the VAD of the utterance -- mean, votes, ranks: a few
+//     hundred operations -- so each knows all voiced ranks and the count; part 0 publishes the count (pub / tv);
+//   * deltas of the own frames from the own MFCC rows +- the delta context (rows clamped at the utterance's ends, as
+//     Kaldi clamps the frame index);
+//   * the CMVN column sums need every frame: each part sums its own block (fb_cmvn_colsum's order), stores the dim
+//     float64 block sums and raises a flag (launch epoch, release), then reads the other parts' (acquire, spinning on
+//     a stale epoch) and combines the blocks left to right -- the same float64 result in every part, bit for bit what
+//     the one-workgroup kernels compute;
+//   * row offset from the published counts of the utterances before this one, voiced rows of the own frames written at
+//     their final position.
+// Workgroups draw (utterance, part) from a ticket: part p of utterance b has ticket FB_CMVN_PARTS b + p, so every
+// workgroup with a smaller ticket is running or done.  A part also waits for LATER tickets -- the other parts of its own
+// utterance --, which cannot deadlock: at any time at most one utterance is only partly started, every other started
+// utterance has all its parts running and completes without anybody else's help, freeing its slots.
+template <int ORDER, int WIN>
+__global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, const float *__restrict__ mfcc,
+                                                          const int *__restrict__ frame_off, int B, int t_cap,
+                                                          unsigned epoch, int *__restrict__ ticket,
+                                                          unsigned long long *__restrict__ pub, int *__restrict__ tv,
+                                                          int *__restrict__ row_off, float *__restrict__ feats,
+                                                          double *__restrict__ part_sum, unsigned *__restrict__ part_flag) {
+  if (fe.stop && *fe.stop) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  __shared__ int s_tk, s_run, s_wtot[4], s_rbase;
+  __shared__ float s_thr;
+  constexpr int NP = FB_CMVN_PARTS;
+  const int nc = fe.nc, dim = fe.dim, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    const int tk = atomicAdd(ticket, 1);
+    if (tk == B * NP - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else will draw
+    s_tk = tk;
+    s_run = 0;
+  }
+  __syncthreads();
+  const int b = s_tk / NP, part = s_tk - b * NP;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const int order = ORDER > 0 ? ORDER : fe.order, dwin = ORDER > 0 ? WIN : fe.dwin;
+  const int maxlen = 2 * order * dwin + 1, ctx = order * dwin;
+  const int tq = (T + NP - 1) / NP, tq_cap = (t_cap + NP - 1) / NP;
+  const int t0 = min(T, part * tq), t1 = min(T, t0 + tq), Tn = t1 - t0;   // own frames
+  double *s_sum = s_dyn;                                        // [dim]
+  double *s_sc = s_sum + dim;                                   // [(order+1)][maxlen]
+  double *s_red = s_sc + (order + 1) * maxlen;                  // [256]
+  float *s_c0 = reinterpret_cast<float *>(s_red + 256);         // [t_cap] C0 of every frame of the utterance
+  float *s_mf = s_c0 + ((t_cap + 1) & ~1);                      // [ctx + tq_cap + ctx][nc] own rows, edges clamped
+  float *s_df = s_mf + (size_t)(tq_cap + 2 * ctx) * nc;         // [tq_cap][dim]
+  int *s_vr = reinterpret_cast<int *>(s_df + (size_t)tq_cap * dim);  // [t_cap]
+  for (int i = tid; i < (order + 1) * maxlen; i += 256) s_sc[i] = fe.dscale[i];
+  {
+    const float *src = mfcc + (size_t)base * nc;
+    for (int t = tid; t < T; t += 256) s_c0[t] = src[(size_t)t * nc];
+    const int n = (Tn + 2 * ctx) * nc;
+    for (int i = tid; i < n; i += 256) {
+      const int r = i / nc, d = i - r * nc;
+      const int tt = min(max(t0 - ctx + r, 0), T - 1);          // Kaldi clamps the frame index at both ends
+      s_mf[i] = src[(size_t)tt * nc + d];
+    }
+  }
+  __syncthreads();
+  // ---- VAD of the whole utterance on the C0 column (k_vad's arithmetic: 256 strided float64 partial sums, binary tree)
+  {
+    double prt = 0.0;
+    for (int t = tid; t < T; t += 256) prt += (double)s_c0[t];
+    s_red[tid] = prt;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] += s_red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) s_thr = (float)(fe.vad_thr + fe.vad_mean_scale * s_red[0] / (double)T);
+  __syncthreads();
+  const float thr = s_thr;
+  for (int tb = 0; tb < T; tb += 256) {
+    const int t = tb + tid;
+    int v = 0;
+    if (t < T) {
+      int num = 0, den = 0;
+      for (int t2 = t - fe.vad_ctx; t2 <= t + fe.vad_ctx; ++t2)
+        if (t2 >= 0 && t2 < T) { ++den; if (s_c0[t2] > thr) ++num; }
+      v = ((float)num >= (float)den * fe.vad_prop) ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(v);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wtot[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < w; ++i) woff += s_wtot[i];
+    if (t < T) s_vr[t] = v ? (s_run + woff + pre) : -1;
+    __syncthreads();
+    if (tid == 0) s_run += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    __syncthreads();
+  }
+  const int n_voiced = s_run;
+  if (tid == 0 && part == 0) {
+    tv[b] = n_voiced;
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
+  if constexpr (ORDER > 0) {
+#pragma unroll
+    for (int i = 0; i <= ORDER; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * ORDER * WIN + 1; ++j) creg[i][j] = s_sc[i * (2 * ORDER * WIN + 1) + j];
+  }
+  // ---- add-deltas of the own frames: thread = (frame, coefficient) pairs in flat order; float64 taps in order
+  for (int idx = tid; idx < Tn * nc; idx += 256) {
+    const int t = idx / nc, d = idx - t * nc;                   // t: own frame index; its row in s_mf is t + ctx
+    if constexpr (ORDER > 0) {
+#pragma unroll
+      for (int i = 0; i <= ORDER; ++i) {
+        constexpr int ML = 2 * ORDER * WIN + 1;
+        const int off = i * WIN;
+        float x[ML];
+        const float *row = s_mf + (t + ctx - off) * nc + d;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j <= 2 * off) x[j] = row[j * nc];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < ML; ++j)
+          if (j <= 2 * off) acc = __dadd_rn(acc, __dmul_rn(creg[i][j], (double)x[j]));
+        s_df[t * dim + i * nc + d] = (float)acc;
+      }
+    } else {
+      for (int i = 0; i <= order; ++i) {
+        const double *sc = s_sc + i * maxlen;
+        const int off = i * dwin;
+        double acc = 0.0;
+        for (int j = 0; j <= 2 * off; ++j)
+          acc = __dadd_rn(acc, __dmul_rn(sc[j], (double)s_mf[(t + ctx - off + j) * nc + d]));
+        s_df[t * dim + i * nc + d] = (float)acc;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- this part's block of the CMVN column sums (frame by frame from zero), published for the other parts
+  const double alpha = (double)(float)(-1.0 / (double)T);
+  double own = 0.0;
+  for (int d = tid; d < dim; d += 256) {   // (dim <= 256: at most one dimension per thread)
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 8 <= Tn; t += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s_df[(t + u) * dim + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)x[u];
+    }
+    for (; t < Tn; ++t) acc += (double)s_df[t * dim + d];
+    own = acc;
+    part_sum[((size_t)b * NP + part) * dim + d] = acc;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&part_flag[b * NP + part], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- row offset: voiced counts of the utterances before this one (wave 1 .. 3), the other parts' flags (wave 0)
+  {
+    int mine = 0;
+    if (tid >= 64) {
+      for (int i = tid - 64; i < b; i += 192) {
+        unsigned long long v;
+        do {
+          v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(v >> 32) != epoch);
+        const int c = (int)(unsigned)v;
+        mine += c > 0 ? c : 0;
+      }
+    } else if (tid < NP && tid != part) {
+      while (__hip_atomic_load(&part_flag[b * NP + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) { }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) s_wtot[w] = mine;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other parts' block sums are read by other threads than the pollers
+  for (int d = tid; d < dim; d += 256) {
+    double tot = 0.0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const double v = p == part ? own : __hip_atomic_load(&part_sum[((size_t)b * NP + p) * dim + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot = p == 0 ? v : tot + v;
+    }
+    s_sum[d] = __dmul_rn(alpha, tot);  // the shift CMVN adds
+  }
+  if (tid == 0) {
+    const int a = s_wtot[1] + s_wtot[2] + s_wtot[3];
+    s_rbase = a;
+    if (part == 0) {
+      row_off[b] = a;
+      if (b == B - 1) row_off[B] = a + (n_voiced > 0 ? n_voiced : 0);
+    }
+  }
+  __syncthreads();
+  // ---- CMVN + voiced-row compaction of the own frames: thread = (frame, dimension) pairs in flat order
+  const int rbase = s_rbase;
+  for (int idx = tid; idx < Tn * dim; idx += 256) {
+    const int t = idx / dim, d = idx - t * dim;
+    const int r = s_vr[t0 + t];
+    if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[idx], s_sum[d]);
+  }
+}
+size_t fb_vad_delta_cmvn_p_lds_bytes(const FbFrontendDev &fe, int t_cap) {
+  const int maxlen = 2 * fe.order * fe.dwin + 1, tq_cap = (t_cap + FB_CMVN_PARTS - 1) / FB_CMVN_PARTS;
+  return sizeof(double) * (size_t)(fe.dim + (fe.order + 1) * maxlen + 256) +
+         sizeof(float) * ((size_t)((t_cap + 1) & ~1) + (size_t)(tq_cap + 2 * fe.order * fe.dwin) * fe.nc + (size_t)tq_cap * fe.dim) +
+         sizeof(int) * (size_t)t_cap + 16;
+}
+// part_sum: B x FB_CMVN_PARTS x dim doubles, part_flag: B x FB_CMVN_PARTS unsigned (zero before the first launch; they
+// carry the epoch like pub).  Returns false when the batch does not qualify.
+size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B) { return (size_t)B * FB_CMVN_PARTS * fe.dim; }
+size_t fb_vad_parts_flags(int B) { return (size_t)B * FB_CMVN_PARTS; }
+bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
+                                int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
+                                float *feats, double *part_sum, unsigned *part_flag) {
+  if (B <= 0) return true;
+  if (t_max > fe.cmn_window || fe.dim > 256) return false;
+  const size_t shm = fb_vad_delta_cmvn_p_lds_bytes(fe, t_max);
+  if (shm > 64 * 1024) return false;
+  const dim3 grid((unsigned)(B * FB_CMVN_PARTS)), blk(256);
+  if (fe.order == 2 && fe.dwin == 3)
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+  else if (fe.order == 2 && fe.dwin == 2)
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+  else
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+  return true;
+}
+
 size_t fb_delta_cmvn_lds_bytes(const FbFrontendDev &fe, int t_cap) {
   const int maxlen = 2 * fe.order * fe.dwin + 1;
   return sizeof(double) * (size_t)(fe.dim + (fe.order + 1) * maxlen) +

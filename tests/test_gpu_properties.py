@@ -171,6 +171,38 @@ def test_feat_compress_kernel_is_deterministic_and_matches_the_fused_phase(oracl
         assert np.array_equal(m.view(np.uint32), want.view(np.uint32))
 
 
+def test_split_and_whole_utterance_vad_delta_cmvn_kernels_are_bit_identical(monkeypatch, oracle):
+    """k_vad_delta_cmvn_p (an utterance over four workgroups that exchange their blocks of the CMVN column sums) against
+    the one-workgroup kernel (FB_VAD_WHOLE=1) and the three-launch chain: the same features and scores bit for bit, on a
+    ragged batch with utterances of 1, 2, 3, 5 frames (parts without frames) and of the full CMVN window."""
+    ubm, spk = synthetic_gmm_system(n_speakers=2, C=64, D=72)
+    lens = [160, 320, 480, 800, 1600, 4000, 16000, 30001, 48000, 47999, 7777]
+    wavs = [(synthetic_audio(u, n) * 32768).astype(np.int16) for u, n in enumerate(lens)]
+    got = {}
+    for name, env, fused in (("split", {}, True), ("whole", {"FB_VAD_WHOLE": "1"}, True), ("three", {}, False)):
+        monkeypatch.delenv("FB_VAD_WHOLE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(0)
+        try:
+            e.set_fused_chain(fused)
+            e.load_gmm([ubm] + spk)
+            raws = [e.score_raw(wavs) for _ in range(3)]                      # repeated: the exchange flags carry epochs
+            feats = [e.debug_feats(w)[0] for w in (wavs[0], wavs[3], wavs[8])]
+            got[name] = (raws, feats)
+        finally:
+            e.close()
+    monkeypatch.delenv("FB_VAD_WHOLE", raising=False)
+    for name in ("whole", "three"):
+        for (ra, ta), (rb, tb) in zip(got["split"][0], got[name][0]):
+            assert np.array_equal(ta, tb) and np.array_equal(ra, rb), name
+        for fa, fb in zip(got["split"][1], got[name][1]):
+            assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), name
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, tv_o = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=8)
+    assert np.array_equal(got["split"][0][0][1], tv_o) and np.abs(got["split"][0][0][0] - raw_o).max() <= 1e-4
+
+
 def test_more_utterances_than_compute_units(oracle):
     """700 short utterances in one scoring batch: k_vad_delta_cmvn's workgroups (one per utterance, indices from a
     ticket, row offsets from the published counts of all earlier utterances) cannot all be resident at once."""
