@@ -105,7 +105,7 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter, vad_pub, vad_part, vad_pflag, fin_counter, ctl, ctl_ls, trace_dev, ticks, enr_ll, enr_aux, enr_stats;
+  DevBuf frame_rec, vad_counter, vad_pub, vad_part, fin_counter, ctl, ctl_ls, trace_dev, ticks, enr_ll, enr_aux, enr_stats;
   std::vector<double> iter_seconds;  // per-iteration device times of the last fb_attack / fb_attack_ext
   long long bench_it = -1;  // fb_bench_nes: next iteration index of the attack left resident (-1: none)
   int64_t bench_N = 0;
@@ -113,6 +113,7 @@ struct fb_engine {
   long long pre_iter = -1;  // >= 0: wav / zbuf / dist_part already hold the NES batch of this iteration (k_update_perturb)
   int pre_ndp = 0;
   bool defer_finalize = false;  // run_scoring leaves the GMM finalisation to the fused finalize + loss launch
+  int vad_part_B = -1, vad_part_dim = -1;  // slot layout the sentinel-filled exchange buffer of k_vad_delta_cmvn_p was prepared for
   unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernel on vad_pub (its published counts carry the epoch)
   FbCtlDev *h_ctl = nullptr;  // pinned
   hipEvent_t evg_ring[2 * 16] = {};
@@ -228,7 +229,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->vad_pflag, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -979,21 +980,23 @@ static int run_post_mfcc(fb_engine *e, int B) {
   };
   if (cm && !cm_fused) FBCHK(compress());
   {  // every utterance fits the CMVN window (all NES batches): VAD, deltas, CMVN and the row offsets in one launch
-    const size_t had = e->vad_pub.cap, had_f = e->vad_pflag.cap;
+    const size_t had = e->vad_pub.cap, had_p = e->vad_part.cap;
     FBCHK(e->vad_pub.ensure(sizeof(unsigned long long) * (size_t)B));
-    FBCHK(e->vad_pflag.ensure(sizeof(unsigned) * fb_vad_parts_flags(B)));
     FBCHK(e->vad_part.ensure(sizeof(double) * fb_vad_parts_doubles(fe, B)));
-    if (e->vad_pub.cap != had || e->vad_pflag.cap != had_f || e->vad_epoch == 0xffffffffu) {  // fresh buffers, or the epoch counter is about to wrap
+    if (e->vad_pub.cap != had || e->vad_part.cap != had_p || e->vad_epoch == 0xffffffffu || e->vad_part_B != B || e->vad_part_dim != fe.dim) {
+      // fresh buffers, another slot layout, or the epoch counter is about to wrap
       HIPCHK(hipMemsetAsync(e->vad_pub.p, 0, e->vad_pub.cap, s));
-      HIPCHK(hipMemsetAsync(e->vad_pflag.p, 0, e->vad_pflag.cap, s));
+      HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->vad_part.p), (int)FB_VAD_SENTINEL32, e->vad_part.cap / 4, s));
       e->vad_epoch = 0;
+      e->vad_part_B = B;
+      e->vad_part_dim = fe.dim;
     }
     // without the CompressedMatrix phase an utterance is split over four workgroups (k_vad_delta_cmvn_p); FB_VAD_WHOLE=1
     // keeps the one-workgroup kernel (A/B; same results bit for bit)
     if (fb_fuse_on(e) && !cm_fused && getenv("FB_VAD_WHOLE") == nullptr &&
         fb_launch_vad_delta_cmvn_p(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                    e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
-                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>(), e->vad_pflag.as<unsigned>())) {
+                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>())) {
       e->vad_epoch += 1;
       return FB_OK;
     }

@@ -9,6 +9,7 @@
 // Precision policy = the oracle's: float64 between Kaldi's float32 storage points.
 #include <float.h>
 
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 
@@ -619,12 +620,14 @@ __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__re
   __shared__ int s_last;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&tv[b], s_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    // (agent-scope store, agent-scope counter, agent-scope loads below: only this thread's store has to be complete
+    //  before its increment -- no device-wide fences, see k_gmm_finalize_loss)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     s_last = (atomicAdd(counter, 1) == B - 1);
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   // exclusive scan of max(tv, 0): thread = contiguous slice, wave scan by shuffles, 4 wave totals
   const int per = (B + 255) / 256;
   const int lo = threadIdx.x * per, hi = min(B, lo + per);
@@ -1246,8 +1249,8 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
   const int n_voiced = s_run;
   if (tid == 0) {
     tv[b] = n_voiced;
-    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);   // (epoch and count in one word: nothing else to order, no fence)
   }
   double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
   if constexpr (ORDER > 0) {
@@ -1299,7 +1302,7 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
       for (int i = tid - first; i < b; i += nth) {
         unsigned long long v;
         do {
-          v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } while ((unsigned)(v >> 32) != epoch);
         const int c = (int)(unsigned)v;
         mine += c > 0 ? c : 0;
@@ -1335,9 +1338,8 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
 //   * deltas of the own frames from the own MFCC rows +- the delta context (rows clamped at the utterance's ends, as
 //     Kaldi clamps the frame index);
 //   * the CMVN column sums need every frame: each part sums its own block (fb_cmvn_colsum's order), stores the dim
-//     float64 block sums and raises a flag (launch epoch, release), then reads the other parts' (acquire, spinning on
-//     a stale epoch) and combines the blocks left to right -- the same float64 result in every part, bit for bit what
-//     the one-workgroup kernels compute;
+//     float64 block sums, polls the other parts' slots until they hold a sum and combines the blocks left to right --
+//     the same float64 result in every part, bit for bit what the one-workgroup kernels compute;
 //   * row offset from the published counts of the utterances before this one, voiced rows of the own frames written at
 //     their final position.
 // Workgroups draw (utterance, part) from a ticket: part p of utterance b has ticket FB_CMVN_PARTS b + p, so every
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
                                                           unsigned epoch, int *__restrict__ ticket,
                                                           unsigned long long *__restrict__ pub, int *__restrict__ tv,
                                                           int *__restrict__ row_off, float *__restrict__ feats,
-                                                          double *__restrict__ part_sum, unsigned *__restrict__ part_flag) {
+                                                          double *__restrict__ part_sum) {
   if (fe.stop && *fe.stop) return;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   __shared__ int s_tk, s_run, s_wtot[4], s_rbase;
@@ -1427,8 +1429,8 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   const int n_voiced = s_run;
   if (tid == 0 && part == 0) {
     tv[b] = n_voiced;
-    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);   // (epoch and count in one word: nothing else to order)
   }
   double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
   if constexpr (ORDER > 0) {
@@ -1468,8 +1470,17 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     }
   }
   __syncthreads();
-  // ---- this part's block of the CMVN column sums (frame by frame from zero), published for the other parts
+  // ---- this part's block of the CMVN column sums (frame by frame from zero), exchanged with the other parts.
+  //      No flags and no fences: a block sum is ONE 64-bit word, stored and polled with relaxed agent-scope atomics; a
+  //      slot that still holds the sentinel (a NaN no sum can be: a NaN sum is stored as another NaN) has not been
+  //      written yet.  Two slot sets alternate with the launch epoch; every part puts the sentinel back into its slots of
+  //      the OTHER set, which the previous launch used and the next one will.  (Device-wide release / acquire fences -- L2
+  //      write-back and invalidate on a multi-XCD part -- cost this kernel 17 us when every thread issued one, and
+  //      still ~2 us per workgroup with one release store + one acquire fence.)
   const double alpha = (double)(float)(-1.0 / (double)T);
+  const unsigned long long SENT = FB_VAD_SENTINEL;
+  unsigned long long *cur = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)(epoch & 1u) * B * NP * dim;
+  unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((epoch + 1u) & 1u) * B * NP * dim;
   double own = 0.0;
   for (int d = tid; d < dim; d += 256) {   // (dim <= 256: at most one dimension per thread)
     double acc = 0.0;
@@ -1483,43 +1494,45 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     }
     for (; t < Tn; ++t) acc += (double)s_df[t * dim + d];
     own = acc;
-    part_sum[((size_t)b * NP + part) * dim + d] = acc;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+    if (acc != acc) bits = 0x7ff8000000000001ull;
+    __hip_atomic_store(&cur[((size_t)b * NP + part) * dim + d], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&nxt[((size_t)b * NP + part) * dim + d], SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(&part_flag[b * NP + part], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- row offset: voiced counts of the utterances before this one (wave 1 .. 3), the other parts' flags (wave 0)
+  // ---- row offset: voiced counts of the utterances before this one (the count travels IN the polled word)
   {
     int mine = 0;
-    if (tid >= 64) {
-      for (int i = tid - 64; i < b; i += 192) {
-        unsigned long long v;
-        do {
-          v = __hip_atomic_load(&pub[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((unsigned)(v >> 32) != epoch);
-        const int c = (int)(unsigned)v;
-        mine += c > 0 ? c : 0;
-      }
-    } else if (tid < NP && tid != part) {
-      while (__hip_atomic_load(&part_flag[b * NP + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) { }
+    for (int i = tid; i < b; i += 256) {
+      unsigned long long v;
+      do {
+        v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((unsigned)(v >> 32) != epoch);
+      const int c = (int)(unsigned)v;
+      mine += c > 0 ? c : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if (lane == 0) s_wtot[w] = mine;
   }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other parts' block sums are read by other threads than the pollers
   for (int d = tid; d < dim; d += 256) {
     double tot = 0.0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const double v = p == part ? own : __hip_atomic_load(&part_sum[((size_t)b * NP + p) * dim + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double v = own;
+      if (p != part) {
+        unsigned long long bits;
+        do {
+          bits = __hip_atomic_load(&cur[((size_t)b * NP + p) * dim + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (bits == SENT);
+        v = __longlong_as_double((long long)bits);
+      }
       tot = p == 0 ? v : tot + v;
     }
     s_sum[d] = __dmul_rn(alpha, tot);  // the shift CMVN adds
   }
+  __syncthreads();
   if (tid == 0) {
-    const int a = s_wtot[1] + s_wtot[2] + s_wtot[3];
+    const int a = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
     s_rbase = a;
     if (part == 0) {
       row_off[b] = a;
@@ -1541,24 +1554,40 @@ size_t fb_vad_delta_cmvn_p_lds_bytes(const FbFrontendDev &fe, int t_cap) {
          sizeof(float) * ((size_t)((t_cap + 1) & ~1) + (size_t)(tq_cap + 2 * fe.order * fe.dwin) * fe.nc + (size_t)tq_cap * fe.dim) +
          sizeof(int) * (size_t)t_cap + 16;
 }
-// part_sum: B x FB_CMVN_PARTS x dim doubles, part_flag: B x FB_CMVN_PARTS unsigned (zero before the first launch; they
-// carry the epoch like pub).  Returns false when the batch does not qualify.
-size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B) { return (size_t)B * FB_CMVN_PARTS * fe.dim; }
-size_t fb_vad_parts_flags(int B) { return (size_t)B * FB_CMVN_PARTS; }
+// part_sum: two slot sets of B x FB_CMVN_PARTS x dim 64-bit words, every word FB_VAD_SENTINEL before the first launch (and
+// whenever the epoch counter is reset).  Returns false when the batch does not qualify.
+size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B) { return (size_t)2 * B * FB_CMVN_PARTS * fe.dim; }
 bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                                 int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                                float *feats, double *part_sum, unsigned *part_flag) {
+                                float *feats, double *part_sum) {
   if (B <= 0) return true;
   if (t_max > fe.cmn_window || fe.dim > 256) return false;
-  const size_t shm = fb_vad_delta_cmvn_p_lds_bytes(fe, t_max);
+  size_t shm = fb_vad_delta_cmvn_p_lds_bytes(fe, t_max);
   if (shm > 64 * 1024) return false;
+  // One workgroup per compute unit while the grid fits the chip: the dispatcher otherwise stacks the four parts of an
+  // utterance on ONE unit (35 KB of LDS and 256 threads each fit four times) and the split buys nothing -- measured:
+  // 39.6 us stacked against 24.7 us for the one-workgroup kernel.  Asking for more than half of a unit's LDS keeps
+  // them apart.
+  if (B * FB_CMVN_PARTS <= 256) {
+    static std::atomic<unsigned long long> optin{0};
+    unsigned long long bit = 0;
+    bool ok = true;
+    if (fb_device_needs_optin(optin, &bit)) {
+      const void *fns[] = {reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 3>), reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 2>),
+                           reinterpret_cast<const void *>(k_vad_delta_cmvn_p<-1, 0>)};
+      for (const void *fn : fns)
+        ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+      if (ok) optin.fetch_or(bit, std::memory_order_release);
+    }
+    if (ok) shm = std::max(shm, (size_t)82 * 1024);
+  }
   const dim3 grid((unsigned)(B * FB_CMVN_PARTS)), blk(256);
   if (fe.order == 2 && fe.dwin == 3)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
   else if (fe.order == 2 && fe.dwin == 2)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
   else
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, part_flag);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
   return true;
 }
 

@@ -663,12 +663,17 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
     if (g.text_scores && tvb > 0) avg = fb_round6(avg);
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(raw + (size_t)b * g.M + m),
                        (unsigned long long)__double_as_longlong(avg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    // The score was stored with an agent-scope (write-through) atomic, the arrival counter is an agent-scope atomic and
+    // the last arriver reads the scores with agent-scope loads: what has to be ordered is only this thread's store
+    // before its own increment -- wait for the store to complete.  (A device-wide release fence here writes back the
+    // whole L2 of the XCD, an acquire fence on the other side invalidates it: 306 workgroups x both were most of this
+    // kernel's time on the eight-XCD MI355X.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     s_last = (atomicAdd(counter, 1) == (int)(gridDim.x * gridDim.y) - 1);
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
                             true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
