@@ -100,6 +100,10 @@ struct fb_engine {
   int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
   int iv_zeroC = -1;  // ... for this component count (position of the zero rows)
   int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
+  DevBuf iv_prog, iv_ticket;  // k_iv_solve_rw: progress words, ticket
+  unsigned iv_rw_epoch = 0;
+  int iv_rw_B = -1, iv_rw_R = -1;
+  bool iv_linv_dirty = false;  // k_iv_solve_ll used the slot buffer as plain scratch: refill before k_iv_solve_rw polls it
   // system
   int task = FB_TASK_OSI;
   DevBuf zmean, zstd;
@@ -233,7 +237,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -958,6 +962,16 @@ static int time_end(fb_engine *e, int what = 1) {
 }
 
 static bool fb_fuse_on(const fb_engine *e);
+// k_iv_solve_rw (four workgroups per matrix) is the LATENCY form of the posterior solve: it finishes a batch of 51 systems
+// sooner, on 204 compute units instead of 51 -- right for one attack per GPU, wrong when several attacks share the chip
+// and the idle units are what their kernels run on.  fb_set_fused_chain(e, 1) -- what the drivers choose for one or two
+// attacks in flight -- selects it; FB_IV_SOLVE=rw | ll forces either.
+static bool fb_iv_use_rw(const fb_engine *e) {
+  const char *ev = getenv("FB_IV_SOLVE");
+  if (ev && strcmp(ev, "rw") == 0) return true;
+  if (ev && strcmp(ev, "ll") == 0) return false;
+  return e->fuse_opt == 1;
+}
 // mfcc -> VAD (+ row offsets) -> deltas -> CMVN -> voiced-row compaction
 static int run_post_mfcc(fb_engine *e, int B) {
   const FbFrontendDev &fe = e->fe;
@@ -1089,7 +1103,24 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
         e->iv_A_B = B;
       }
     }
-    FBCHK(e->iv_linv.ensure(sizeof(double) * (size_t)B * ((iv.R + 31) / 32) * 1024));
+    {  // k_iv_solve_rw's slot sets (sentinel-filled), progress words and ticket; k_iv_solve_ll uses the first set only
+      const size_t had = e->iv_linv.cap, had_p = e->iv_prog.cap;
+      FBCHK(e->iv_linv.ensure(sizeof(double) * fb_iv_solve_rw_linv_doubles(iv, B)));
+      FBCHK(e->iv_prog.ensure(sizeof(unsigned) * fb_iv_solve_rw_prog_words(iv, B)));
+      if (!e->iv_ticket.p) {
+        FBCHK(e->iv_ticket.ensure(sizeof(int)));
+        HIPCHK(hipMemsetAsync(e->iv_ticket.p, 0, sizeof(int), s));
+      }
+      if (e->iv_linv.cap != had || e->iv_prog.cap != had_p || e->iv_rw_B != B || e->iv_rw_R != iv.R || e->iv_rw_epoch >= 0xfffff0u ||
+          (e->iv_linv_dirty && fb_iv_use_rw(e))) {
+        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->iv_linv.p), (int)0x7ff87ff8u, e->iv_linv.cap / 4, s));
+        HIPCHK(hipMemsetAsync(e->iv_prog.p, 0, e->iv_prog.cap, s));
+        e->iv_rw_epoch = 0;
+        e->iv_rw_B = B;
+        e->iv_rw_R = iv.R;
+        e->iv_linv_dirty = false;
+      }
+    }
     FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
     FBCHK(e->iv_fail.ensure(sizeof(int)));
     FBCHK(e->iv_active.ensure(sizeof(int) * (size_t)(iv.C + 1)));
@@ -1113,8 +1144,18 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
     FBCHK(time_begin(e, 2));
-    fb_launch_iv_solve_ll(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
-                          e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    // FB_IV_SOLVE=ll keeps the one-workgroup-per-matrix kernel (A/B); otherwise the row-wise kernel whenever its grid of
+    // 4 workgroups per matrix is resident at once, which is when the chip has idle units to give it
+    if (fb_iv_use_rw(e) &&
+        fb_launch_iv_solve_rw(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B, e->iv_A.as<double>(),
+                              e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>(), e->iv_prog.as<unsigned>(),
+                              e->iv_ticket.as<int>(), e->iv_rw_epoch + 1)) {
+      e->iv_rw_epoch += 1;
+    } else {
+      e->iv_linv_dirty = true;
+      fb_launch_iv_solve_ll(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
+                            e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+    }
     FBCHK(time_end(e, 2));
     FB_DBG_SYNC(e, "solve");
     fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());

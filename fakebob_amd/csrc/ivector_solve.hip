@@ -403,6 +403,326 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_iv_solve_rw (round 4): the same factorisation ROW-WISE over G workgroups per matrix.  One workgroup per matrix has a
+// floor of ~200 us -- 13 serial 32 x 32 block factorisations of 7 us with seven waves idle, and at samples_per_draw = 50
+// only 51 of 256 compute units have a matrix at all.  Here block row rb (32 rows: tile rows 2 rb, 2 rb + 1; the right-hand
+// side rides along as row R) belongs to workgroup rb % G, which does everything for it, column by column ("up-looking"
+// Cholesky):
+//     for c < rb:  S = A[rb, c] - sum_{q < c} L[rb, q] L[c, q]^T      (needs L[c, 0 .. c-1]: row c's off-diagonals)
+//                  L[rb, c] = S L_cc^-T                                (needs row c COMPLETE: its inverted factor)
+//     diagonal:    S = A[rb, rb] + I - sum_{q < rb} L[rb, q] L[rb, q]^T, factor + invert (wave 0, fb_sv_chol32), publish
+// Block rows complete strictly in order, but when row rb - 1 completes the owner of row rb has everything else behind
+// it: what is left is ONE panel solve, one 32 x 32 x 32 update of its diagonal block (the earlier contributions are
+// summed beforehand) and its own factorisation -- the serial chain is hop + solve + update + factor per row, and the
+// bulk (the sums over q for the next rows) runs on the other workgroups of the matrix meanwhile.
+// Cross-workgroup traffic without device-wide fences (a release / acquire pair writes back / invalidates an XCD's whole
+// L2 on the eight-XCD MI355X: microseconds each, k_vad_delta_cmvn_p's lesson): every L block and inverse is written with
+// agent-scope (write-through) stores and read with agent-scope loads;
+//   * prog[b][rb] = (epoch << 8) | n: block row rb has its first n column blocks in memory (n = rb: off-diagonals done,
+//     n = rb + 1: complete).  Written by one thread after a workgroup barrier behind s_waitcnt vmcnt(0) of every storing
+//     thread -- the stores are complete, i.e. visible at agent scope, before the flag is issued;
+//   * the inverted diagonal factors are polled as DATA: two slot sets alternate with the launch epoch, a slot holding the
+//     sentinel NaN has not been written (the owner puts the sentinel back into the other set's slots for the launch after
+//     next) -- the hop of the serial chain is one memory round trip, not flag-then-data.
+// Workgroups draw (matrix, g) from a ticket, g fastest: every smaller ticket is running or done; a workgroup waits only
+// for block rows below its own, and a matrix whose G workgroups have all started needs nobody else -- at most one matrix
+// is partly started at any time, so waiting cannot deadlock.
+#define FB_RW_SENT 0x7ff87ff87ff87ff8ull
+__device__ __forceinline__ double fb_rw_ld(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void fb_rw_st(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int G>
+__global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restrict__ quad, const double *__restrict__ linp,
+                                                     int n_kchunks, int B, double *__restrict__ AugAll,
+                                                     double *__restrict__ LinvAll, double *__restrict__ ivec,
+                                                     int *__restrict__ fail, unsigned *__restrict__ prog,
+                                                     int *__restrict__ ticket, unsigned epoch) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  __shared__ int s_tk;
+  const int R = iv.R, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  if (tid == 0) {
+    const int tk = atomicAdd(ticket, 1);
+    if (tk == B * G - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tk = tk;
+  }
+  __syncthreads();
+  const int b = s_tk / G, g = s_tk - b * G;
+  const int nbr = (R + 1 + FB_SV_NB - 1) / FB_SV_NB;   // block rows incl. the right-hand side (row R)
+  const int npanel = (R + FB_SV_NB - 1) / FB_SV_NB;    // diagonal blocks
+  double *Q = quad + (size_t)b * iv.triR;
+  double *aug = AugAll + (size_t)b * R;
+  const long long aug_off = (long long)(aug - Q), zero_off = (long long)((AugAll + (size_t)B * R) - Q);
+  auto roff = [&](int r) -> long long { return r < R ? (long long)((r * (r + 1)) >> 1) : aug_off; };
+  const size_t lset = (size_t)B * npanel * FB_SV_NB * FB_SV_NB;
+  double *Lcur = LinvAll + (size_t)(epoch & 1u) * lset + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
+  double *Lnxt = LinvAll + (size_t)((epoch + 1u) & 1u) * lset + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
+  unsigned *pg = prog + (size_t)b * (nbr + 1);
+  double *rhs = smd;                          // [R] (back substitution)
+  double *Dg = rhs + ((R + 1) & ~1);          // [32][33] the diagonal block on its way to wave 0; later scratch
+  double *Di = Dg + FB_SV_NB * FB_SV_LD;      // [32][33] an inverted diagonal factor
+  double *bc = Di + FB_SV_NB * FB_SV_LD;      // [128] column broadcast of the factorisation
+  double *Sx = bc + 128;                      // [32][34] the block being formed, row-major (A-operand layout of the solve)
+  double *pr = Sx + FB_SV_NB * FB_SV_LDC;     // [4 sub-tiles][16][17] the second K half's partial sums
+  double *red = pr + 4 * 16 * 17;             // [16][33] partial sums of the back substitution
+  const int st = wv & 3, th = st >> 1, tc = st & 1, kh = wv >> 2;   // wave -> 16 x 16 sub-tile (th, tc), K half kh
+
+  auto wait_prog = [&](int row, unsigned need) {  // one thread polls, the barrier releases the workgroup
+    if (tid == 0) {
+      unsigned v;
+      do {
+        v = __hip_atomic_load(&pg[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((v >> 8) != (epoch & 0xffffffu) || (v & 0xffu) < need);
+    }
+    __syncthreads();
+  };
+  auto publish = [&](int row, unsigned n) {       // every thread's stores are complete, then the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&pg[row], ((epoch & 0xffffffu) << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // acc(sub-tile st) = sum over the panels q = kh, kh + 2, .. < nq of L[rows r0 + 16 th .., q] L[rows c0 + 16 tc .., q]^T
+  auto accumulate = [&](int r0, int c0, int nq) -> fb_d4 {
+    fb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int ra = r0 + 16 * th + l15, rbb = c0 + 16 * tc + l15;
+    const double *pa = Q + (ra <= R ? roff(ra) : zero_off) + 8 * l4;
+    const double *pb = Q + (rbb < R ? roff(rbb) : zero_off) + 8 * l4;
+    double a0[8], b0[8], a1[8], b1[8];
+    auto load8 = [&](const double *p, double (&f)[8]) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = fb_rw_ld(p + u);
+    };
+    int q = kh;
+    if (q < nq) { load8(pa + FB_SV_NB * q, a0); load8(pb + FB_SV_NB * q, b0); }
+    for (; q < nq; q += 4) {   // two panels of this K half per trip, the next one requested before the multiply
+      const bool h1 = q + 2 < nq, h2 = q + 4 < nq;
+      if (h1) { load8(pa + FB_SV_NB * (q + 2), a1); load8(pb + FB_SV_NB * (q + 2), b1); }
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s8], b0[s8], acc, 0, 0, 0);
+      if (h2) { load8(pa + FB_SV_NB * (q + 4), a0); load8(pb + FB_SV_NB * (q + 4), b0); }
+      if (h1) {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s8], b1[s8], acc, 0, 0, 0);
+      }
+    }
+    return acc;
+  };
+  // Sx = A[block] (+ I on the diagonal) - (acc of K half 0 + acc of K half 1), zero where the block has no element
+  auto form_block = [&](int r0, int c0, int nq, bool diag) {
+    const fb_d4 acc = accumulate(r0, c0, nq);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[(st * 16 + l4 + 4 * i) * 17 + l15] = acc[i];
+    }
+    double av[4];
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + 16 * th + l4 + 4 * i, cc = c0 + 16 * tc + l15;
+        const bool ok = rr <= R && cc < R && cc <= rr;
+        av[i] = fb_rw_ld(Q + (ok ? roff(rr) + cc : zero_off)) + ((ok && rr == cc) ? 1.0 : 0.0);   // (A = I + quad; an element is read before its L value replaces it)
+      }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + 16 * th + l4 + 4 * i, cc = c0 + 16 * tc + l15;
+        const bool ok = rr <= R && cc < R && (!diag || cc <= rr);
+        const double v = av[i] - (acc[i] + pr[(st * 16 + l4 + 4 * i) * 17 + l15]);
+        Sx[(16 * th + l4 + 4 * i) * FB_SV_LDC + 16 * tc + l15] = ok ? v : 0.0;
+      }
+    }
+    __syncthreads();
+  };
+
+  // the right-hand side (sum of the lin partials) is prepared by the workgroup with the longest wait before its first
+  // row, g = G - 1, and announced as prog[nbr]
+  if (g == G - 1) {
+    for (int r = tid; r < R; r += nt) {
+      double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const double *lp = linp + (size_t)b * R + r;
+      int ch = 0;
+      for (; ch + 8 <= n_kchunks; ch += 8) {
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
+      }
+      for (int sl = 0; ch + sl < n_kchunks; ++sl) a8[sl] += lp[(size_t)(ch + sl) * B * R];
+      double acc = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) acc += a8[sl];
+      fb_rw_st(&aug[r], acc + (r == 0 ? iv.prior_offset : 0.0));
+    }
+    publish(nbr, 1u);
+  }
+
+  for (int rb = g; rb < nbr; rb += G) {
+    const int r0 = FB_SV_NB * rb;
+    const bool has_diag = r0 < R;
+    const int nb = has_diag ? min(FB_SV_NB, R - r0) : 0;
+    if (r0 + FB_SV_NB > R) wait_prog(nbr, 1u);          // this block row holds the right-hand side
+    if (has_diag) {  // the other slot set's inverse of this row: sentinel again for the launch after next
+      for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(Lnxt + (size_t)rb * FB_SV_NB * FB_SV_NB + i), FB_RW_SENT,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the diagonal block's sum over the columns already solved is carried along: dsum = sum_{q < c} L[rb,q] L[rb,q]^T is
+    // formed at the end from memory except for the last column, whose block is still in LDS
+    for (int c = 0; c < rb && c < npanel; ++c) {
+      if (c > 0) wait_prog(c, (unsigned)c);              // L[c, 0 .. c-1] in memory
+      form_block(r0, FB_SV_NB * c, c, false);            // Sx = A[rb, c] - sum_{q < c} ...
+      // the inverse of row c's factor, polled as data
+      for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + i);
+        unsigned long long bits;
+        do {
+          bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (bits == FB_RW_SENT);
+        Di[(i >> 5) * FB_SV_LD + (i & 31)] = __longlong_as_double((long long)bits);
+      }
+      __syncthreads();
+      // X = Sx Linv^T on the matrix cores: waves 0 .. 3, sub-tile (th, tc); stored to the matrix and kept in Xl
+      if (kh == 0) {
+        fb_d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(Sx[(16 * th + l15) * FB_SV_LDC + 4 * s8 + l4],
+                                                   Di[(16 * tc + l15) * FB_SV_LD + 4 * s8 + l4], x, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = r0 + 16 * th + l4 + 4 * i, cc = FB_SV_NB * c + 16 * tc + l15;
+          if (rr <= R && cc < R) fb_rw_st(Q + roff(rr) + cc, x[i]);
+        }
+      }
+      // the stores are complete before anybody (this workgroup's next column included) reads them back
+      publish(rb, (unsigned)(c + 1));
+    }
+    if (has_diag) {
+      // diagonal block: A + I - sum_{q < rb} L[rb,q] L[rb,q]^T (read back from memory: own stores, complete since the
+      // publish above), then wave 0 factors and inverts it in registers
+      form_block(r0, r0, rb, true);
+      if (wv == 0) {
+        double X[FB_SV_NB];
+        const int rr = lane & 31;
+        if (lane < FB_SV_NB) {
+#pragma unroll
+          for (int cc = 0; cc < FB_SV_NB; ++cc) {
+            const double v = Sx[rr * FB_SV_LDC + cc];
+            X[cc] = (rr < nb && cc < nb) ? (cc <= rr ? v : 0.0) : (rr == cc ? 1.0 : 0.0);
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < FB_SV_NB; ++cc) X[cc] = (rr == cc) ? 1.0 : 0.0;
+        }
+        const bool bad = fb_sv_chol32(X, bc, lane);
+        if (bad && lane == 0) atomicMax(fail, b + 1);
+        if (lane < FB_SV_NB) {
+#pragma unroll
+          for (int cc = 0; cc < FB_SV_NB; ++cc)
+            if (rr < nb && cc <= rr) fb_rw_st(Q + roff(r0 + rr) + r0 + cc, X[cc]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < FB_SV_NB; ++r) {
+            Di[r * FB_SV_LD + rr] = X[r];
+            double v = X[r];
+            if ((unsigned long long)__double_as_longlong(v) == FB_RW_SENT) v = __longlong_as_double(0x7ff8000000000001ll);
+            fb_rw_st(Lcur + ((size_t)rb * FB_SV_NB + r) * FB_SV_NB + rr, v);
+          }
+        }
+      }
+      __syncthreads();
+      // rows of this block row behind a short diagonal block (only the right-hand side can be there): X = S L^-T
+      if (r0 + nb <= R && r0 + FB_SV_NB > R && kh == 0) {
+        fb_d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(Sx[(16 * th + l15) * FB_SV_LDC + 4 * s8 + l4],
+                                                   Di[(16 * tc + l15) * FB_SV_LD + 4 * s8 + l4], x, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = r0 + 16 * th + l4 + 4 * i, cc = r0 + 16 * tc + l15;
+          if (rr <= R && rr >= r0 + nb && cc < r0 + nb) fb_rw_st(Q + roff(rr) + cc, x[i]);
+        }
+      }
+      publish(rb, (unsigned)(rb + 1));
+    }
+  }
+  if ((nbr - 1) % G != g) return;   // the owner of the last block row goes on with the back substitution
+  // everything the other workgroups wrote went through to memory before they published; one invalidate and plain loads do
+  wait_prog(nbr - 1, (unsigned)(min(nbr - 1, npanel - 1) + 1));
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  auto rowp = [&](int r) -> double * { return Q + roff(r); };
+  for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
+  __syncthreads();
+  for (int pi = npanel - 1; pi >= 0; --pi) {
+    const int j0 = pi * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
+    const int gq = tid >> 5, c = tid & 31;
+    double acc = 0.0;
+    if (c < nb) {  // eight rows of this thread's group in flight at a time
+      for (int k = j0 + nb + gq; k < R; k += 128) {
+        double lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lv[u] = rowp(min(k + 16 * u, R - 1))[j0 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(k + 16 * u < R ? lv[u] : 0.0, rhs[min(k + 16 * u, R - 1)], acc);
+      }
+    }
+    red[gq * FB_SV_LD + c] = acc;
+    for (int idx = tid; idx < FB_SV_NB * FB_SV_NB; idx += nt)
+      Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = Lcur[(size_t)pi * FB_SV_NB * FB_SV_NB + idx];
+    __syncthreads();
+    if (tid < FB_SV_NB) {
+      double sm = 0.0;
+#pragma unroll
+      for (int gg = 0; gg < 16; ++gg) sm += red[gg * FB_SV_LD + tid];
+      Dg[tid] = tid < nb ? rhs[j0 + tid] - sm : 0.0;
+    }
+    __syncthreads();
+    if (tid < FB_SV_NB) {  // x = L11^-T t
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < FB_SV_NB; ++q) {
+        const double t = Di[q * FB_SV_LD + tid] * Dg[q];
+        x += (q >= tid && q < nb) ? t : 0.0;
+      }
+      if (tid < nb) rhs[j0 + tid] = x;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
+}
+
+// LinvAll: TWO slot sets of B x npanel x 32 x 32 doubles, every word FB_RW_SENT before the first launch / after an epoch
+// restart; prog: B x (block rows + 1) unsigned, zero then; ticket: one int, zero.  Returns false when the grid of B x G
+// workgroups would not be resident at once (the caller then runs k_iv_solve_ll).
+#define FB_RW_G 4
+size_t fb_iv_solve_rw_linv_doubles(const FbIvDev &iv, int B) { return (size_t)2 * B * ((iv.R + 31) / 32) * 1024; }
+size_t fb_iv_solve_rw_prog_words(const FbIvDev &iv, int B) { return (size_t)B * ((iv.R + 1 + 31) / 32 + 1); }
+bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks, int B,
+                           double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch) {
+  const int R = iv.R;
+  if (B * FB_RW_G > 256 || R < 64) return false;
+  const size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17 + 16 * FB_SV_LD);
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (fb_device_needs_optin(optin, &bit)) {  // one workgroup per compute unit: more than half of its LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_rw<FB_RW_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return false;
+    optin.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(k_iv_solve_rw<FB_RW_G>, dim3(B * FB_RW_G), dim3(512), std::max(shm, (size_t)82 * 1024), s, iv,
+                     const_cast<double *>(quad), linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+  return true;
+}
+
 template <int NTR>
 static void launch_solve_ll(hipStream_t s, size_t shm, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                             int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
