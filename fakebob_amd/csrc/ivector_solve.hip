@@ -171,6 +171,58 @@ __device__ __forceinline__ void fb_sv_accumulate(fb_d4 (&S)[NTR][2], const doubl
   }
 }
 
+// Back substitution L^T x = y, shared by both kernels (round 4: 45 -> ~16 us).  rhs[0 .. R) (LDS) holds y; block by block
+// from the end:  x_p = L_pp^-T t_p  (32 threads, the inverted factor through Di), then RIGHT-looking: every remaining
+// column's t loses block row p's contribution at once, t[col] -= sum_r L[32 p + r][col] x_p[r] -- thread = column, the
+// block ROW is contiguous in the packed triangle (coalesced), and block row p - 1 is requested before block p's update
+// is multiplied, so the serial chain per block is a 32-term triangular product, a 32-term update and three barriers, not
+// a memory round trip.  (Round 3 formed t_p LEFT-looking from the column block of all rows below: strided 8-byte reads
+// and one exposed L2 round trip per block.)
+__device__ __forceinline__ void fb_sv_backsub(const double *__restrict__ Qb, long long aug_off, int R, int npanel,
+                                              const double *__restrict__ Lg, double *__restrict__ rhs, double *__restrict__ Di,
+                                              double *__restrict__ xs, int tid, int nt) {
+  (void)aug_off;
+  auto rowp = [&](int r) -> const double * { return Qb + (((long long)r * (r + 1)) >> 1); };
+  double lv[FB_SV_NB];     // this thread's column of the current block row
+  double dv[2];            // its two elements of the current inverted factor (nt == 512: 1024 / 512)
+  auto fetch = [&](int p) {
+    const int j0 = p * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
+#pragma unroll
+    for (int r = 0; r < FB_SV_NB; ++r) lv[r] = (tid < j0 && r < nb) ? rowp(j0 + r)[tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dv[u] = Lg[(size_t)p * FB_SV_NB * FB_SV_NB + tid + u * nt];
+  };
+  fetch(npanel - 1);
+  for (int p = npanel - 1; p >= 0; --p) {
+    const int j0 = p * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int idx = tid + u * nt; Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = dv[u]; }
+    double cur[FB_SV_NB];
+#pragma unroll
+    for (int r = 0; r < FB_SV_NB; ++r) cur[r] = lv[r];
+    __syncthreads();
+    if (tid < FB_SV_NB) {  // x = L_pp^-T t: x[i] = sum_{q >= i} Linv[q][i] t[q]
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < FB_SV_NB; ++q) {
+        const double t = Di[q * FB_SV_LD + tid] * rhs[min(j0 + q, R - 1)];
+        x += (q >= tid && q < nb) ? t : 0.0;
+      }
+      xs[tid] = tid < nb ? x : 0.0;
+    }
+    if (p > 0) fetch(p - 1);   // in flight during the barrier and the update below
+    __syncthreads();
+    if (tid < FB_SV_NB && tid < nb) rhs[j0 + tid] = xs[tid];
+    if (tid < j0) {
+      double acc = rhs[tid];
+#pragma unroll
+      for (int r = 0; r < FB_SV_NB; ++r) acc = fma(-cur[r], xs[r], acc);
+      rhs[tid] = acc;
+    }
+    __syncthreads();
+  }
+}
+
 template <int NTR>
 __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restrict__ quad, const double *__restrict__ linp,
                                                      int n_kchunks, int B, double *__restrict__ AugAll,
@@ -192,14 +244,12 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
   // from Q, chosen with integer selects -- nothing is masked after a load and the loops have no divergent branches.
   const long long aug_off = (long long)(aug - Q), zero_off = (long long)((AugAll + (size_t)B * R) - Q);
   auto roff = [&](int r) -> long long { return r < R ? (long long)((r * (r + 1)) >> 1) : aug_off; };  // R <= 2^15
-  auto rowp = [&](int r) -> double * { return Q + roff(r); };
   double *Lg = LinvAll + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
   double *rhs = smd;                          // [R]
   double *Dg = rhs + ((R + 1) & ~1);          // [32][33] the diagonal block on its way to wave 0; later scratch
   double *Di = Dg + FB_SV_NB * FB_SV_LD;      // [32][33] its inverse
   double *bc = Di + FB_SV_NB * FB_SV_LD;      // [128] column broadcast of the factorisation
   double *cvt = bc + 128;                     // [8 waves][16][34] accumulator layout -> A-operand layout
-  double *red = cvt + 8 * 16 * FB_SV_LDC;     // [16][33] partial sums of the back substitution
   for (int r = tid; r < R; r += nt) Q[((r * (r + 1)) >> 1) + r] += 1.0;  // A = I + quad
   // rhs = sum of the lin partials: 8 interleaved slices per component, combined in fixed order (thread = component:
   // coalesced, 8 independent loads in flight)
@@ -365,41 +415,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
   //      contiguous bytes at a time (thread = (row group of 16, column))
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
-  for (int pi = npanel - 1; pi >= 0; --pi) {
-    const int j0 = pi * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
-    const int g = tid >> 5, c = tid & 31;
-    double acc = 0.0;
-    if (c < nb) {  // eight rows of this thread's group in flight at a time
-      for (int k = j0 + nb + g; k < R; k += 128) {
-        double lv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) lv[u] = rowp(min(k + 16 * u, R - 1))[j0 + c];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fma(k + 16 * u < R ? lv[u] : 0.0, rhs[min(k + 16 * u, R - 1)], acc);
-      }
-    }
-    red[g * FB_SV_LD + c] = acc;
-    for (int idx = tid; idx < FB_SV_NB * FB_SV_NB; idx += nt)
-      Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = Lg[(size_t)pi * FB_SV_NB * FB_SV_NB + idx];
-    __syncthreads();
-    if (tid < FB_SV_NB) {
-      double s = 0.0;
-#pragma unroll
-      for (int gg = 0; gg < 16; ++gg) s += red[gg * FB_SV_LD + tid];
-      Dg[tid] = tid < nb ? rhs[j0 + tid] - s : 0.0;
-    }
-    __syncthreads();
-    if (tid < FB_SV_NB) {  // x = L11^-T t
-      double x = 0.0;
-#pragma unroll
-      for (int q = 0; q < FB_SV_NB; ++q) {
-        const double t = Di[q * FB_SV_LD + tid] * Dg[q];
-        x += (q >= tid && q < nb) ? t : 0.0;
-      }
-      if (tid < nb) rhs[j0 + tid] = x;
-    }
-    __syncthreads();
-  }
+  fb_sv_backsub(Q, aug_off, R, npanel, Lg, rhs, Di, Dg, tid, nt);
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
 
@@ -465,13 +481,19 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
   double *Lcur = LinvAll + (size_t)(epoch & 1u) * lset + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
   double *Lnxt = LinvAll + (size_t)((epoch + 1u) & 1u) * lset + (size_t)b * npanel * FB_SV_NB * FB_SV_NB;
   unsigned *pg = prog + (size_t)b * (nbr + 1);
-  double *rhs = smd;                          // [R] (back substitution)
-  double *Dg = rhs + ((R + 1) & ~1);          // [32][33] the diagonal block on its way to wave 0; later scratch
-  double *Di = Dg + FB_SV_NB * FB_SV_LD;      // [32][33] an inverted diagonal factor
-  double *bc = Di + FB_SV_NB * FB_SV_LD;      // [128] column broadcast of the factorisation
-  double *Sx = bc + 128;                      // [32][34] the block being formed, row-major (A-operand layout of the solve)
-  double *pr = Sx + FB_SV_NB * FB_SV_LDC;     // [4 sub-tiles][16][17] the second K half's partial sums
-  double *red = pr + 4 * 16 * 17;             // [16][33] partial sums of the back substitution
+  // LDS: the own block row as it is solved (32 rows x 32 npanel columns: the A operand of every later sum is read from
+  // here, never from memory), the block being formed, an inverted diagonal factor, exchange areas.  The back
+  // substitution at the end re-uses the row area.
+  const int ldr = FB_SV_NB * npanel + 2;        // row stride of Lrow (doubles)
+  double *Lrow = smd;                          // [32][ldr]
+  double *Di = Lrow + (size_t)FB_SV_NB * ldr;  // [32][33] an inverted diagonal factor
+  double *bc = Di + FB_SV_NB * FB_SV_LD;       // [128] column broadcast of the factorisation
+  double *Sx = bc + 128;                       // [32][34] the block being formed, row-major (A-operand layout of the solve)
+  double *pr = Sx + FB_SV_NB * FB_SV_LDC;      // [4 sub-tiles][16][17] the second K half's partial sums
+  double *rhs = Lrow;                          // back substitution: [R], then Dg [32], red [16][33]
+  double *Dg = rhs + ((R + 1) & ~1);
+  __shared__ int s_cnt;                        // stores-complete count of the solving waves (off-diagonal flag)
+  if (tid == 0) s_cnt = 0;
   const int st = wv & 3, th = st >> 1, tc = st & 1, kh = wv >> 2;   // wave -> 16 x 16 sub-tile (th, tc), K half kh
 
   auto wait_prog = [&](int row, unsigned need) {  // one thread polls, the barrier releases the workgroup
@@ -489,47 +511,48 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&pg[row], ((epoch & 0xffffffu) << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // acc(sub-tile st) = sum over the panels q = kh, kh + 2, .. < nq of L[rows r0 + 16 th .., q] L[rows c0 + 16 tc .., q]^T
-  auto accumulate = [&](int r0, int c0, int nq) -> fb_d4 {
+  // acc(sub-tile st) = sum over the panels q = kh, kh + 2, .. < nq of Lrow[rows 16 th .., q] L[rows c0 + 16 tc .., q]^T:
+  // the own rows from LDS, the other block row's from memory -- ALL its fragments requested before the first multiply
+  // (one memory round trip, whatever nq: the serial chain of the factorisation waits for this sum once per block row)
+  constexpr int FB_RW_MAXP = 7;                 // panels per K half: R <= 448
+  auto accumulate = [&](int c0, int nq) -> fb_d4 {
     fb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-    const int ra = r0 + 16 * th + l15, rbb = c0 + 16 * tc + l15;
-    const double *pa = Q + (ra <= R ? roff(ra) : zero_off) + 8 * l4;
+    const int rbb = c0 + 16 * tc + l15;
     const double *pb = Q + (rbb < R ? roff(rbb) : zero_off) + 8 * l4;
-    double a0[8], b0[8], a1[8], b1[8];
-    auto load8 = [&](const double *p, double (&f)[8]) {
+    const double *la = Lrow + (size_t)(16 * th + l15) * ldr + 8 * l4;
+    double bf[FB_RW_MAXP][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) f[u] = fb_rw_ld(p + u);
-    };
-    int q = kh;
-    if (q < nq) { load8(pa + FB_SV_NB * q, a0); load8(pb + FB_SV_NB * q, b0); }
-    for (; q < nq; q += 4) {   // two panels of this K half per trip, the next one requested before the multiply
-      const bool h1 = q + 2 < nq, h2 = q + 4 < nq;
-      if (h1) { load8(pa + FB_SV_NB * (q + 2), a1); load8(pb + FB_SV_NB * (q + 2), b1); }
+    for (int j = 0; j < FB_RW_MAXP; ++j) {
+      const int q = kh + 2 * j;
+      if (q < nq) {
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s8], b0[s8], acc, 0, 0, 0);
-      if (h2) { load8(pa + FB_SV_NB * (q + 4), a0); load8(pb + FB_SV_NB * (q + 4), b0); }
-      if (h1) {
+        for (int u = 0; u < 8; ++u) bf[j][u] = fb_rw_ld(pb + FB_SV_NB * q + u);
+      }
+    }
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s8], b1[s8], acc, 0, 0, 0);
+    for (int j = 0; j < FB_RW_MAXP; ++j) {
+      const int q = kh + 2 * j;
+      if (q < nq) {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[FB_SV_NB * q + s8], bf[j][s8], acc, 0, 0, 0);
       }
     }
     return acc;
   };
-  // Sx = A[block] (+ I on the diagonal) - (acc of K half 0 + acc of K half 1), zero where the block has no element
-  auto form_block = [&](int r0, int c0, int nq, bool diag) {
-    const fb_d4 acc = accumulate(r0, c0, nq);
+  // this lane's elements of A[block at (r0, c0)] (+ I on the diagonal), requested ahead of their use
+  auto load_a = [&](int r0, int c0, double (&av)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = r0 + 16 * th + l4 + 4 * i, cc = c0 + 16 * tc + l15;
+      const bool ok = rr <= R && cc < R && cc <= rr;
+      av[i] = fb_rw_ld(Q + (ok ? roff(rr) + cc : zero_off)) + ((ok && rr == cc) ? 1.0 : 0.0);
+    }
+  };
+  // Sx = A block - (acc of K half 0 + acc of K half 1), zero where the block has no element
+  auto finish_block = [&](const fb_d4 &acc, const double (&av)[4], int r0, int c0, bool diag) {
     if (kh == 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pr[(st * 16 + l4 + 4 * i) * 17 + l15] = acc[i];
-    }
-    double av[4];
-    if (kh == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = r0 + 16 * th + l4 + 4 * i, cc = c0 + 16 * tc + l15;
-        const bool ok = rr <= R && cc < R && cc <= rr;
-        av[i] = fb_rw_ld(Q + (ok ? roff(rr) + cc : zero_off)) + ((ok && rr == cc) ? 1.0 : 0.0);   // (A = I + quad; an element is read before its L value replaces it)
-      }
     }
     __syncthreads();
     if (kh == 0) {
@@ -543,7 +566,6 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     }
     __syncthreads();
   };
-
   // the right-hand side (sum of the lin partials) is prepared by the workgroup with the longest wait before its first
   // row, g = G - 1, and announced as prog[nbr]
   if (g == G - 1) {
@@ -564,21 +586,29 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     publish(nbr, 1u);
   }
 
+  int n_pub = 0;   // off-diagonal flags this workgroup has published (the solving waves count their completed stores)
   for (int rb = g; rb < nbr; rb += G) {
     const int r0 = FB_SV_NB * rb;
     const bool has_diag = r0 < R;
     const int nb = has_diag ? min(FB_SV_NB, R - r0) : 0;
+    const int ncol = min(rb, npanel);                    // off-diagonal column blocks of this block row
     if (r0 + FB_SV_NB > R) wait_prog(nbr, 1u);          // this block row holds the right-hand side
     if (has_diag) {  // the other slot set's inverse of this row: sentinel again for the launch after next
       for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(Lnxt + (size_t)rb * FB_SV_NB * FB_SV_NB + i), FB_RW_SENT,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // the diagonal block's sum over the columns already solved is carried along: dsum = sum_{q < c} L[rb,q] L[rb,q]^T is
-    // formed at the end from memory except for the last column, whose block is still in LDS
-    for (int c = 0; c < rb && c < npanel; ++c) {
+    fb_d4 dacc = {0.0, 0.0, 0.0, 0.0};   // this wave's share of sum_q L[rb,q] L[rb,q]^T (sub-tile st, K half kh of every block)
+    double av[4], avd[4] = {0.0, 0.0, 0.0, 0.0};
+    if (kh == 0) {
+      if (has_diag) load_a(r0, r0, avd);
+      if (ncol > 0) load_a(r0, 0, av);
+    }
+    for (int c = 0; c < ncol; ++c) {
       if (c > 0) wait_prog(c, (unsigned)c);              // L[c, 0 .. c-1] in memory
-      form_block(r0, FB_SV_NB * c, c, false);            // Sx = A[rb, c] - sum_{q < c} ...
+      const fb_d4 acc = accumulate(FB_SV_NB * c, c);
+      finish_block(acc, av, r0, FB_SV_NB * c, false);    // Sx = A[rb, c] - sum_{q < c} ...
+      if (kh == 0 && c + 1 < ncol) load_a(r0, FB_SV_NB * (c + 1), av);
       // the inverse of row c's factor, polled as data
       for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt) {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + i);
@@ -589,8 +619,9 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
         Di[(i >> 5) * FB_SV_LD + (i & 31)] = __longlong_as_double((long long)bits);
       }
       __syncthreads();
-      // X = Sx Linv^T on the matrix cores: waves 0 .. 3, sub-tile (th, tc); stored to the matrix and kept in Xl
-      if (kh == 0) {
+      // X = Sx Linv^T on the matrix cores: waves 4 .. 7 (wave 0 never has stores in flight when it starts a
+      // factorisation), sub-tile (th, tc); to the LDS row and -- without waiting -- to memory
+      if (kh == 1) {
         fb_d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
@@ -598,17 +629,35 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
                                                    Di[(16 * tc + l15) * FB_SV_LD + 4 * s8 + l4], x, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int rr = r0 + 16 * th + l4 + 4 * i, cc = FB_SV_NB * c + 16 * tc + l15;
-          if (rr <= R && cc < R) fb_rw_st(Q + roff(rr) + cc, x[i]);
+          const int rl = 16 * th + l4 + 4 * i, rr = r0 + rl, cc = FB_SV_NB * c + 16 * tc + l15;
+          const bool ok = rr <= R && cc < R;
+          if (ok) fb_rw_st(Q + roff(rr) + cc, x[i]);
+          Lrow[(size_t)rl * ldr + cc] = ok ? x[i] : 0.0;
         }
       }
-      // the stores are complete before anybody (this workgroup's next column included) reads them back
-      publish(rb, (unsigned)(c + 1));
+      __syncthreads();
+      // the block's contribution to the diagonal block's sum, while it is hot: K half kh = columns 16 kh .. 16 kh + 15
+      if (has_diag) {
+        const double *la = Lrow + (size_t)(16 * th + l15) * ldr + FB_SV_NB * c + 16 * kh + l4;
+        const double *lb = Lrow + (size_t)(16 * tc + l15) * ldr + FB_SV_NB * c + 16 * kh + l4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[4 * s4], lb[4 * s4], dacc, 0, 0, 0);
+      }
+    }
+    if (has_diag) finish_block(dacc, avd, r0, r0, true);   // Sx = A[rb,rb] + I - sum_{q < rb} L[rb,q] L[rb,q]^T
+    // "off-diagonals done": the solving waves wait for their stores and count; one of them raises the flag -- no workgroup
+    // barrier, wave 0 is factoring meanwhile
+    if (ncol > 0 && kh == 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) atomicAdd(&s_cnt, 1);
+      if (wv == 4 && lane == 0) {
+        n_pub += 1;
+        while (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * n_pub) { }
+        __hip_atomic_store(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (has_diag) {
-      // diagonal block: A + I - sum_{q < rb} L[rb,q] L[rb,q]^T (read back from memory: own stores, complete since the
-      // publish above), then wave 0 factors and inverts it in registers
-      form_block(r0, r0, rb, true);
       if (wv == 0) {
         double X[FB_SV_NB];
         const int rr = lane & 31;
@@ -624,11 +673,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
         }
         const bool bad = fb_sv_chol32(X, bc, lane);
         if (bad && lane == 0) atomicMax(fail, b + 1);
-        if (lane < FB_SV_NB) {
-#pragma unroll
-          for (int cc = 0; cc < FB_SV_NB; ++cc)
-            if (rr < nb && cc <= rr) fb_rw_st(Q + roff(r0 + rr) + r0 + cc, X[cc]);
-        } else {
+        if (lane >= FB_SV_NB) {   // the inverse first: it is what the next block row's owner is polling for
 #pragma unroll
           for (int r = 0; r < FB_SV_NB; ++r) {
             Di[r * FB_SV_LD + rr] = X[r];
@@ -636,11 +681,15 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
             if ((unsigned long long)__double_as_longlong(v) == FB_RW_SENT) v = __longlong_as_double(0x7ff8000000000001ll);
             fb_rw_st(Lcur + ((size_t)rb * FB_SV_NB + r) * FB_SV_NB + rr, v);
           }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < FB_SV_NB; ++cc)
+            if (rr < nb && cc <= rr) fb_rw_st(Q + roff(r0 + rr) + r0 + cc, X[cc]);
         }
       }
       __syncthreads();
       // rows of this block row behind a short diagonal block (only the right-hand side can be there): X = S L^-T
-      if (r0 + nb <= R && r0 + FB_SV_NB > R && kh == 0) {
+      if (r0 + nb <= R && r0 + FB_SV_NB > R && kh == 1) {
         fb_d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
@@ -652,51 +701,16 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
           if (rr <= R && rr >= r0 + nb && cc < r0 + nb) fb_rw_st(Q + roff(rr) + cc, x[i]);
         }
       }
-      publish(rb, (unsigned)(rb + 1));
     }
+    if ((nbr - 1) % G == g && rb + G >= nbr) publish(rb, (unsigned)(ncol + (has_diag ? 1 : 0)));   // the last row of the owner of the back substitution: its stores complete
+    else __syncthreads();
   }
   if ((nbr - 1) % G != g) return;   // the owner of the last block row goes on with the back substitution
   // everything the other workgroups wrote went through to memory before they published; one invalidate and plain loads do
-  wait_prog(nbr - 1, (unsigned)(min(nbr - 1, npanel - 1) + 1));
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  auto rowp = [&](int r) -> double * { return Q + roff(r); };
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
-  for (int pi = npanel - 1; pi >= 0; --pi) {
-    const int j0 = pi * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
-    const int gq = tid >> 5, c = tid & 31;
-    double acc = 0.0;
-    if (c < nb) {  // eight rows of this thread's group in flight at a time
-      for (int k = j0 + nb + gq; k < R; k += 128) {
-        double lv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) lv[u] = rowp(min(k + 16 * u, R - 1))[j0 + c];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fma(k + 16 * u < R ? lv[u] : 0.0, rhs[min(k + 16 * u, R - 1)], acc);
-      }
-    }
-    red[gq * FB_SV_LD + c] = acc;
-    for (int idx = tid; idx < FB_SV_NB * FB_SV_NB; idx += nt)
-      Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = Lcur[(size_t)pi * FB_SV_NB * FB_SV_NB + idx];
-    __syncthreads();
-    if (tid < FB_SV_NB) {
-      double sm = 0.0;
-#pragma unroll
-      for (int gg = 0; gg < 16; ++gg) sm += red[gg * FB_SV_LD + tid];
-      Dg[tid] = tid < nb ? rhs[j0 + tid] - sm : 0.0;
-    }
-    __syncthreads();
-    if (tid < FB_SV_NB) {  // x = L11^-T t
-      double x = 0.0;
-#pragma unroll
-      for (int q = 0; q < FB_SV_NB; ++q) {
-        const double t = Di[q * FB_SV_LD + tid] * Dg[q];
-        x += (q >= tid && q < nb) ? t : 0.0;
-      }
-      if (tid < nb) rhs[j0 + tid] = x;
-    }
-    __syncthreads();
-  }
+  fb_sv_backsub(Q, aug_off, R, npanel, Lcur, rhs, Di, Dg, tid, nt);
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
 
@@ -710,11 +724,14 @@ bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad,
                            double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch) {
   const int R = iv.R;
   if (B * FB_RW_G > 256 || R < 64) return false;
-  const size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17 + 16 * FB_SV_LD);
+  const int npanel = (R + FB_SV_NB - 1) / FB_SV_NB;
+  const size_t rowd = (size_t)FB_SV_NB * (FB_SV_NB * npanel + 2), bsd = ((R + 1) & ~1) + FB_SV_NB + 16 * FB_SV_LD;
+  const size_t shm = sizeof(double) * (std::max(rowd, bsd) + FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17);
+  if (shm > 150 * 1024 || R > 448) return false;
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (fb_device_needs_optin(optin, &bit)) {  // one workgroup per compute unit: more than half of its LDS
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_rw<FB_RW_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_rw<FB_RW_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
       return false;
     optin.fetch_or(bit, std::memory_order_release);
   }

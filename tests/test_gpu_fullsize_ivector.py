@@ -126,3 +126,40 @@ def test_full_size_osi_get_grad_spd200_b201(oracle):
         assert np.all(np.sign(gg[big]) == np.sign(go[big]))
     finally:
         e.close()
+
+
+def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypatch):
+    """k_iv_solve_rw (round 4: the block rows of a posterior system dealt over four workgroups, cross-workgroup exchange
+    through agent-scope stores, progress words and sentinel-polled inverse factors) against k_iv_solve_ll (one workgroup
+    per matrix) and the oracle at the benchmarked size (C = 2048, R = 400), over REPEATED launches (the slot sets
+    alternate with the launch epoch), a batch of 51 and one of 3, and a switch between the kernels on one engine (the slot
+    buffer is plain scratch for k_iv_solve_ll and must be refilled)."""
+    from fakebob_amd.models import synthetic_ivector_system
+    sy = synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=3)
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=_threads())
+    wavs51 = [_wav(u % 7, 30000 + 997 * (u % 5)) for u in range(51)]
+    wavs3 = wavs51[:3]
+    llr_o, ivs_o, tv_o = ctx.score_batch(wavs51)
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        got = {}
+        for mode in ("ll", "rw", "rw", "ll", "rw"):
+            monkeypatch.setenv("FB_IV_SOLVE", mode)
+            for name, wavs in (("b51", wavs51), ("b3", wavs3), ("b51", wavs51)):
+                llr, tv = e.score_raw(wavs)
+                ivs = e.debug_ivectors(len(wavs), sy.R)
+                got.setdefault((mode, name), []).append((llr, ivs))
+        for (mode, name), runs in got.items():
+            n = 51 if name == "b51" else 3
+            for llr, ivs in runs:
+                assert np.abs(ivs - ivs_o[:n]).max() <= 1e-9 * max(1.0, np.abs(ivs_o).max()), (mode, name)
+                assert np.abs(llr - llr_o[:n]).max() <= 1e-7, (mode, name)
+            for llr, ivs in runs[1:]:
+                assert np.array_equal(llr, runs[0][0]) and np.array_equal(ivs, runs[0][1]), (mode, name)   # deterministic
+        d = np.abs(got[("rw", "b51")][0][1] - got[("ll", "b51")][0][1]).max()
+        print("row-wise against one-workgroup solve: max |i-vector difference| %.3g" % d)
+        assert d <= 1e-10
+    finally:
+        monkeypatch.delenv("FB_IV_SOLVE", raising=False)
+        e.close()
