@@ -182,44 +182,66 @@ __device__ __forceinline__ void fb_sv_backsub(const double *__restrict__ Qb, lon
                                               const double *__restrict__ Lg, double *__restrict__ rhs, double *__restrict__ Di,
                                               double *__restrict__ xs, int tid, int nt) {
   (void)aug_off;
+  (void)nt;   // 512 threads: two elements of a 32 x 32 inverse each
   auto rowp = [&](int r) -> const double * { return Qb + (((long long)r * (r + 1)) >> 1); };
-  double lv[FB_SV_NB];     // this thread's column of the current block row
-  double dv[2];            // its two elements of the current inverted factor (nt == 512: 1024 / 512)
-  auto fetch = [&](int p) {
+  struct Buf { double lv[FB_SV_NB]; double dv[2]; };  // a thread's column of a block row + its two elements of the inverse
+  auto fetch = [&](int p, Buf &f) {
     const int j0 = p * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
 #pragma unroll
-    for (int r = 0; r < FB_SV_NB; ++r) lv[r] = (tid < j0 && r < nb) ? rowp(j0 + r)[tid] : 0.0;
+    for (int u = 0; u < 2; ++u) f.dv[u] = Lg[(size_t)p * FB_SV_NB * FB_SV_NB + tid + u * 512];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) dv[u] = Lg[(size_t)p * FB_SV_NB * FB_SV_NB + tid + u * nt];
+    for (int r = 0; r < FB_SV_NB; ++r) f.lv[r] = (tid < j0 && r < nb) ? rowp(j0 + r)[tid] : 0.0;
   };
-  fetch(npanel - 1);
-  for (int p = npanel - 1; p >= 0; --p) {
+  auto step = [&](int p, const Buf &f) {
     const int j0 = p * FB_SV_NB, nb = min(FB_SV_NB, R - j0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const int idx = tid + u * nt; Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = dv[u]; }
-    double cur[FB_SV_NB];
-#pragma unroll
-    for (int r = 0; r < FB_SV_NB; ++r) cur[r] = lv[r];
+    for (int u = 0; u < 2; ++u) { const int idx = tid + u * 512; Di[(idx >> 5) * FB_SV_LD + (idx & 31)] = f.dv[u]; }
     __syncthreads();
-    if (tid < FB_SV_NB) {  // x = L_pp^-T t: x[i] = sum_{q >= i} Linv[q][i] t[q]
+    if (tid < 64) {  // x = L_pp^-T t: x[i] = sum_{q >= i} Linv[q][i] t[q]; wave 0, lane = (half of the q range, i).
+      // Every LDS operand is requested before the first addition (read inside the loop they were 64 dependent LDS round
+      // trips per block: the 3.4 us a step of this substitution took whatever the prefetch depth, r04_rw_stamps_c.txt)
+      const int i = tid & 31, hq = tid >> 5;
+      double dc[16], tq[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int q = 16 * hq + u;
+        dc[u] = Di[q * FB_SV_LD + i];
+        tq[u] = rhs[min(j0 + q, R - 1)];
+      }
       double x = 0.0;
 #pragma unroll
-      for (int q = 0; q < FB_SV_NB; ++q) {
-        const double t = Di[q * FB_SV_LD + tid] * rhs[min(j0 + q, R - 1)];
-        x += (q >= tid && q < nb) ? t : 0.0;
+      for (int u = 0; u < 16; ++u) {
+        const int q = 16 * hq + u;
+        x += (q >= i && q < nb) ? dc[u] * tq[u] : 0.0;
       }
-      xs[tid] = tid < nb ? x : 0.0;
+      x = x + __shfl_xor(x, 32, 64);   // (lower q half + upper q half: the same sum in both lanes)
+      if (tid < FB_SV_NB) xs[tid] = tid < nb ? x : 0.0;
     }
-    if (p > 0) fetch(p - 1);   // in flight during the barrier and the update below
     __syncthreads();
     if (tid < FB_SV_NB && tid < nb) rhs[j0 + tid] = xs[tid];
     if (tid < j0) {
+      double xr[FB_SV_NB];
+#pragma unroll
+      for (int r = 0; r < FB_SV_NB; ++r) xr[r] = xs[r];
       double acc = rhs[tid];
 #pragma unroll
-      for (int r = 0; r < FB_SV_NB; ++r) acc = fma(-cur[r], xs[r], acc);
+      for (int r = 0; r < FB_SV_NB; ++r) acc = fma(-f.lv[r], xr[r], acc);
       rhs[tid] = acc;
     }
     __syncthreads();
+  };
+  // two register sets, TWO block rows in flight: block row p - 2 is requested when block p's update has consumed its set,
+  // a whole step before it is needed
+  Buf A, Bb;
+  fetch(npanel - 1, A);
+  if (npanel >= 2) fetch(npanel - 2, Bb);
+  for (int p = npanel - 1; p >= 0; p -= 2) {
+    step(p, A);
+    if (p - 2 >= 0) fetch(p - 2, A);
+    if (p - 1 >= 0) {
+      step(p - 1, Bb);
+      if (p - 3 >= 0) fetch(p - 3, Bb);
+    }
   }
 }
 
@@ -445,6 +467,15 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
 // for block rows below its own, and a matrix whose G workgroups have all started needs nobody else -- at most one matrix
 // is partly started at any time, so waiting cannot deadlock.
 #define FB_RW_SENT 0x7ff87ff87ff87ff8ull
+#ifdef FB_RW_STAMP  // instrumented build (tools/profile/rw_instrumented.sh): the serial chain of matrix 0, per block row
+__device__ unsigned long long g_rw_stamps[16 * 8 + 8];
+extern "C" int fb_debug_rw_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rw_stamps), sizeof(g_rw_stamps)) == hipSuccess ? 0 : -1;
+}
+#define RW_STAMP(row, k) do { if (b == 0 && tid == 0) g_rw_stamps[(row) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define RW_STAMP(row, k) do { } while (0)
+#endif
 __device__ __forceinline__ double fb_rw_ld(const double *p) {
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
@@ -492,7 +523,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
   double *pr = Sx + FB_SV_NB * FB_SV_LDC;      // [4 sub-tiles][16][17] the second K half's partial sums
   double *rhs = Lrow;                          // back substitution: [R], then Dg [32], red [16][33]
   double *Dg = rhs + ((R + 1) & ~1);
-  __shared__ int s_cnt;                        // stores-complete count of the solving waves (off-diagonal flag)
+  __shared__ int s_cnt, s_ready;               // stores-complete count of the solving waves (off-diagonal flag); complete block rows seen
   if (tid == 0) s_cnt = 0;
   const int st = wv & 3, th = st >> 1, tc = st & 1, kh = wv >> 2;   // wave -> 16 x 16 sub-tile (th, tc), K half kh
 
@@ -509,7 +540,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&pg[row], ((epoch & 0xffffffu) << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_max(&pg[row], ((epoch & 0xffffffu) << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // acc(sub-tile st) = sum over the panels q = kh, kh + 2, .. < nq of Lrow[rows 16 th .., q] L[rows c0 + 16 tc .., q]^T:
   // the own rows from LDS, the other block row's from memory -- ALL its fragments requested before the first multiply
@@ -520,13 +551,22 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     const int rbb = c0 + 16 * tc + l15;
     const double *pb = Q + (rbb < R ? roff(rbb) : zero_off) + 8 * l4;
     const double *la = Lrow + (size_t)(16 * th + l15) * ldr + 8 * l4;
+    // PLAIN (L2-cached) 16-byte loads: this XCD cannot hold a stale line of these blocks -- nobody reads block row c's
+    // off-diagonal part before its flag, the writer's stores went through to memory before the flag, and a line that
+    // straddles into the diagonal block's not yet final part is never read through the cache for that part.  (As
+    // agent-scope loads every block came from memory every time: the catch-up columns of the late block rows took
+    // 5 - 11 us each and the row-wise kernel fell behind its own serial chain, profiles/r04_rw_stamps_a.txt.)
     double bf[FB_RW_MAXP][8];
 #pragma unroll
     for (int j = 0; j < FB_RW_MAXP; ++j) {
       const int q = kh + 2 * j;
       if (q < nq) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bf[j][u] = fb_rw_ld(pb + FB_SV_NB * q + u);
+        for (int h = 0; h < 4; ++h) {
+          const fb_d2u v = *reinterpret_cast<const fb_d2u *>(pb + FB_SV_NB * q + 2 * h);
+          bf[j][2 * h] = v[0];
+          bf[j][2 * h + 1] = v[1];
+        }
       }
     }
 #pragma unroll
@@ -592,6 +632,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     const bool has_diag = r0 < R;
     const int nb = has_diag ? min(FB_SV_NB, R - r0) : 0;
     const int ncol = min(rb, npanel);                    // off-diagonal column blocks of this block row
+    RW_STAMP(rb, 0);
     if (r0 + FB_SV_NB > R) wait_prog(nbr, 1u);          // this block row holds the right-hand side
     if (has_diag) {  // the other slot set's inverse of this row: sentinel again for the launch after next
       for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt)
@@ -604,21 +645,50 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
       if (has_diag) load_a(r0, r0, avd);
       if (ncol > 0) load_a(r0, 0, av);
     }
+    // how many of the block rows below are COMPLETE already: one round trip for all their progress words instead of two
+    // per column (a workgroup that comes back from its previous block row has most columns waiting for it; the polls of
+    // flags that have long been up were most of a catch-up column's 5 us, profiles/r04_rw_stamps_b.txt)
+    if (tid == 0) {
+      unsigned pv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pv[i] = i < ncol ? __hip_atomic_load(&pg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      int ready = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i == ready && i < ncol && (pv[i] >> 8) == (epoch & 0xffffffu) && (pv[i] & 0xffu) >= (unsigned)(i + 1)) ready = i + 1;
+      s_ready = ready;
+    }
+    __syncthreads();
+    const int ready = s_ready;
+    auto ld_inv = [&](int c, unsigned long long (&dst)[2]) {   // this thread's two words of row c's inverted factor
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        dst[u] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + tid + u * 512),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    unsigned long long dvn[2] = {FB_RW_SENT, FB_RW_SENT};
+    if (ncol > 0 && 0 < ready) ld_inv(0, dvn);
     for (int c = 0; c < ncol; ++c) {
-      if (c > 0) wait_prog(c, (unsigned)c);              // L[c, 0 .. c-1] in memory
+      if (c > 0 && c >= ready) wait_prog(c, (unsigned)c);              // L[c, 0 .. c-1] in memory
+      if (c == ncol - 1) RW_STAMP(rb, 1);
+      unsigned long long dvc[2] = {dvn[0], dvn[1]};
+      if (c + 1 < ncol && c + 1 < ready) ld_inv(c + 1, dvn);           // the next column's inverse: in flight during this one
       const fb_d4 acc = accumulate(FB_SV_NB * c, c);
       finish_block(acc, av, r0, FB_SV_NB * c, false);    // Sx = A[rb, c] - sum_{q < c} ...
+      if (c == ncol - 1) RW_STAMP(rb, 2);
       if (kh == 0 && c + 1 < ncol) load_a(r0, FB_SV_NB * (c + 1), av);
-      // the inverse of row c's factor, polled as data
-      for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt) {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + i);
-        unsigned long long bits;
-        do {
-          bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while (bits == FB_RW_SENT);
+      // the inverse of row c's factor: prefetched when row c was known to be complete, else polled as data
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 512;
+        unsigned long long bits = c < ready ? dvc[u] : FB_RW_SENT;
+        while (bits == FB_RW_SENT)
+          bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + i),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         Di[(i >> 5) * FB_SV_LD + (i & 31)] = __longlong_as_double((long long)bits);
       }
       __syncthreads();
+      if (c == ncol - 1) RW_STAMP(rb, 3);
       // X = Sx Linv^T on the matrix cores: waves 4 .. 7 (wave 0 never has stores in flight when it starts a
       // factorisation), sub-tile (th, tc); to the LDS row and -- without waiting -- to memory
       if (kh == 1) {
@@ -645,6 +715,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
       }
     }
     if (has_diag) finish_block(dacc, avd, r0, r0, true);   // Sx = A[rb,rb] + I - sum_{q < rb} L[rb,q] L[rb,q]^T
+    RW_STAMP(rb, 4);
     // "off-diagonals done": the solving waves wait for their stores and count; one of them raises the flag -- no workgroup
     // barrier, wave 0 is factoring meanwhile
     if (ncol > 0 && kh == 1) {
@@ -654,7 +725,8 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
       if (wv == 4 && lane == 0) {
         n_pub += 1;
         while (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * n_pub) { }
-        __hip_atomic_store(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (fetch_max: wave 0's "complete" below may overtake this one; within an epoch the word only grows)
+        __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (has_diag) {
@@ -686,8 +758,15 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
           for (int cc = 0; cc < FB_SV_NB; ++cc)
             if (rr < nb && cc <= rr) fb_rw_st(Q + roff(r0 + rr) + r0 + cc, X[cc]);
         }
+        // "complete": a workgroup that starts a later block row reads this word to know that it need not poll for this
+        // row at all (its inverse can be requested ahead)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+          __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)(rb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
+      RW_STAMP(rb, 5);
       // rows of this block row behind a short diagonal block (only the right-hand side can be there): X = S L^-T
       if (r0 + nb <= R && r0 + FB_SV_NB > R && kh == 1) {
         fb_d4 x = {0.0, 0.0, 0.0, 0.0};
@@ -708,9 +787,11 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
   if ((nbr - 1) % G != g) return;   // the owner of the last block row goes on with the back substitution
   // everything the other workgroups wrote went through to memory before they published; one invalidate and plain loads do
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  RW_STAMP(15, 0);
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
   fb_sv_backsub(Q, aug_off, R, npanel, Lcur, rhs, Di, Dg, tid, nt);
+  RW_STAMP(15, 1);
   for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
 }
 
