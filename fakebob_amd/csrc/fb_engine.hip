@@ -444,6 +444,14 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   e->gmm_delta_rms = 0.0;
   // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
   // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
+  if (G == 1 && M > FB_FXW_MAX_M && (C & 31) == 0) {
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "[fakebob_hip] note: %d models in one variance group: k_gmm_fx2w takes at most %d (LDS), this system is "
+                      "scored by the general kernel k_gmm_fx2 (about twice the time per model)\n", M, FB_FXW_MAX_M);
+    }
+  }
   const bool want_delta = G == 1 && M >= 2 && M <= FB_FXW_MAX_M && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
