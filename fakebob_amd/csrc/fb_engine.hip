@@ -83,7 +83,7 @@ struct fb_engine {
   fb_frontend_cfg cfg;
   FbFrontendDev fe;
   int melw_n = 0;  // packed mel weight count
-  DevBuf fe_tables;
+  DevBuf fe_tables, fe_tables32;
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
@@ -232,7 +232,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->fe_tables32, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
@@ -380,6 +380,14 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   fe.mel_w = (const double *)(base + o_mw); fe.dct = (const double *)(base + o_dct);
   fe.lifter = (const double *)(base + o_lift); fe.dscale = (const double *)(base + o_ds);
   e->melw_n = (int)mel_w.size();
+  fe.f32_tab = nullptr;
+  if (P == 512 && nb <= 31 && nc <= 32 && (L & 1) == 0) {  // k_mfcc_f32's tables (any precision setting: the flag may come later)
+    const std::vector<float> t32 = fb_mfcc_f32_table(L, nb, nc, window.data(), tw_half.data(), tw_full.data(), mel_first.data(),
+                                                     mel_len.data(), mel_off.data(), mel_w.data(), (int)mel_w.size(), dct.data(), lifter.data());
+    FBCHK(e->fe_tables32.ensure(sizeof(float) * t32.size()));
+    HIPCHK(hipMemcpy(e->fe_tables32.p, t32.data(), sizeof(float) * t32.size(), hipMemcpyHostToDevice));
+    fe.f32_tab = e->fe_tables32.as<float>();
+  }
   if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, e->melw_n)) > 150 * 1024)
     return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
   if (c->mfcc_f32 && !fb_mfcc_f32_supported(fe)) {

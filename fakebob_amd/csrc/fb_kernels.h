@@ -25,6 +25,7 @@ struct FbFrontendDev {
   const double *dct;      // [nc][nb] (float32 values widened)
   const double *lifter;   // [nc]
   const double *dscale;   // [(order+1)][2*order*dwin+1] delta kernels (float32 values widened)
+  const float *f32_tab;   // k_mfcc_f32's tables as one float32 blob in its LDS layout (fb_mfcc_f32_table; null: not supported)
   const int *stop;        // nullable device flag: != 0 -> k_mfcc does nothing (attack already stopped)
 };
 
@@ -98,6 +99,11 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
                     int total_frames, float *mfcc);
 // fb_frontend_cfg.mfcc_f32: the float32 kernel (frontend_f32_kernels.hip); false = this configuration is not one it takes
 bool fb_mfcc_f32_supported(const FbFrontendDev &fe);
+// the float32 table blob of k_mfcc_f32 (its LDS image up to the per-wave buffers) from the float64 host tables
+#include <vector>
+std::vector<float> fb_mfcc_f32_table(int L, int nb, int nc, const double *window, const double *tw_half, const double *tw_full,
+                                     const int *mel_first, const int *mel_len, const int *mel_off, const double *mel_w, int melw_n,
+                                     const double *dct, const double *lifter);
 bool fb_launch_mfcc_f32(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav, const int32_t *frame_rec,
                         int total_frames, float *mfcc);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].

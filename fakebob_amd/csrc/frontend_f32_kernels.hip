@@ -170,15 +170,14 @@ __global__ __launch_bounds__(64 * FB_F32_WAVES, 1) void k_mfcc_f32(FbFrontendDev
   };
   int xn[16];
   if (w_glob < n_groups) load_group(w_glob, t_lane, xn);
-  // tables: the float64 host tables rounded to float32 (the window, mel weights, DCT and lifter are float32 values
-  // already: Kaldi stores them as BaseFloat)
-  for (int i = tid; i < Nc; i += NT) { const double2 v = reinterpret_cast<const double2 *>(fe.tw_half)[i]; s_tw[i] = f32x2{(float)v.x, (float)v.y}; }
-  for (int i = tid; i <= Nc; i += NT) { const double2 v = reinterpret_cast<const double2 *>(fe.tw_full)[i]; s_twf[i] = f32x2{(float)v.x, (float)v.y}; }
-  for (int i = tid; i < L; i += NT) s_win[i] = (float)fe.window[i];
-  for (int i = tid; i < melw_n; i += NT) s_melw[i] = (float)fe.mel_w[i];
-  for (int i = tid; i < nc * nb; i += NT) s_dct[i] = (float)fe.dct[i];
-  for (int i = tid; i < nc; i += NT) s_lift[i] = (float)fe.lifter[i];
-  for (int i = tid; i < nb; i += NT) { s_mfirst[i] = fe.mel_first[i]; s_mlen[i] = fe.mel_len[i]; s_moff[i] = fe.mel_off[i]; }
+  // tables: one float32 blob in this kernel's LDS layout, built by fb_set_frontend from the float64 host tables (the
+  // window, mel weights, DCT and lifter are float32 values already: Kaldi stores them as BaseFloat) -- a straight copy,
+  // one 16-byte load per thread
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(fe.f32_tab);
+    float4 *dst = reinterpret_cast<float4 *>(smem32);
+    for (int i = tid; i < lo.wave0 / 4; i += NT) dst[i] = src[i];
+  }
   __syncthreads();
   const float pre = (float)fe.preemph;
 
@@ -301,10 +300,25 @@ __global__ __launch_bounds__(64 * FB_F32_WAVES, 1) void k_mfcc_f32(FbFrontendDev
   }
 }
 
+std::vector<float> fb_mfcc_f32_table(int L, int nb, int nc, const double *window, const double *tw_half, const double *tw_full,
+                                     const int *mel_first, const int *mel_len, const int *mel_off, const double *mel_w, int melw_n,
+                                     const double *dct, const double *lifter) {
+  const MfccF32Lds lo = fb_mfcc_f32_layout(L, nb, nc, melw_n);
+  std::vector<float> t((size_t)lo.wave0 + 4, 0.0f);
+  for (int i = 0; i < 256; ++i) { t[lo.tw + 2 * i] = (float)tw_half[2 * i]; t[lo.tw + 2 * i + 1] = (float)tw_half[2 * i + 1]; }
+  for (int i = 0; i <= 256; ++i) { t[lo.twf + 2 * i] = (float)tw_full[2 * i]; t[lo.twf + 2 * i + 1] = (float)tw_full[2 * i + 1]; }
+  for (int i = 0; i < L; ++i) t[lo.win + i] = (float)window[i];
+  for (int i = 0; i < melw_n; ++i) t[lo.melw + i] = (float)mel_w[i];
+  for (int i = 0; i < nc * nb; ++i) t[lo.dct + i] = (float)dct[i];
+  for (int i = 0; i < nc; ++i) t[lo.lift + i] = (float)lifter[i];
+  int *mi = reinterpret_cast<int *>(&t[lo.melidx]);
+  for (int i = 0; i < nb; ++i) { mi[i] = mel_first[i]; mi[nb + i] = mel_len[i]; mi[2 * nb + i] = mel_off[i]; }
+  return t;
+}
 // true when the configuration is one k_mfcc_f32 takes (the recipe's: P = 512, raw energy, at most 31 mel bins / 32
 // cepstra, even frame length); fb_set_frontend refuses mfcc_f32 = 1 otherwise
 bool fb_mfcc_f32_supported(const FbFrontendDev &fe) {
-  return fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2 && fe.L <= 512 && fe.raw_energy != 0;
+  return fe.P == 512 && fe.nb <= 31 && fe.nc <= 32 && (fe.L & 1) == 0 && fe.L >= 2 && fe.L <= 512 && fe.raw_energy != 0 && fe.f32_tab != nullptr;
 }
 bool fb_launch_mfcc_f32(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav, const int32_t *frame_rec,
                         int total_frames, float *mfcc) {
