@@ -14,22 +14,27 @@ from .engine import Engine
 from .kaldi_io import load_gmm_any
 
 
-# The two file round trips of the reference's pipeline that the engine reproduces on the device:
+# What the reference's pipeline does to the numbers and the engine reproduces on the device when asked:
 #   compress_feats  `copy-feats --compress=true` inside steps/make_mfcc.sh (gmm_ubm_kaldiHelper.py:138-140)
 #   text_scores     the 6-significant-digit score text the helpers parse (gmm_ubm_kaldiHelper.py:236-248)
+#   mfcc_f32        compute-mfcc-feats in Kaldi's own BaseFloat = float32 arithmetic (k_mfcc_f32)
+#                   instead of float64 between Kaldi's float32 storage points
 # Every system class carries its own default in `PIPELINE` -- None for the library classes below (full precision: the
 # engine's flags are left as the caller set them), REFERENCE_PIPELINE for the subclasses the drop-in modules export
 # under the reference's names (fakebob_amd/dropin/).  Nothing process-global is switched by an import.
-REFERENCE_PIPELINE = {"text_scores": True, "compress_feats": True}
+REFERENCE_PIPELINE = {"text_scores": True, "compress_feats": True, "mfcc_f32": True}
+_PIPELINE_ENV = (("text_scores", "FB_TEXT_SCORES"), ("compress_feats", "FB_COMPRESS_FEATS"), ("mfcc_f32", "FB_MFCC_F32"))
 
 
-def _pipeline_options(text_scores, compress_feats, default=None):
-    """Front-end overrides for the two round trips.  Precedence per flag: constructor keyword (True or False), then
-    FB_TEXT_SCORES / FB_COMPRESS_FEATS = 0 | 1, then the class default (`default`, a dict or None).  A flag that none
-    of the three names is NOT returned: constructing a library system on a shared engine leaves whatever the caller
-    set through Engine.set_frontend alone."""
+def _pipeline_options(text_scores, compress_feats, default=None, mfcc_f32=None):
+    """Front-end overrides for the pipeline flags.  Precedence per flag: constructor keyword (True or False), then
+    FB_TEXT_SCORES / FB_COMPRESS_FEATS / FB_MFCC_F32 = 0 | 1, then the class default (`default`, a dict or None).  A flag
+    that none of the three names is NOT returned: constructing a library system on a shared engine leaves whatever
+    the caller set through Engine.set_frontend alone."""
     out = {}
-    for key, kw, env in (("text_scores", text_scores, "FB_TEXT_SCORES"), ("compress_feats", compress_feats, "FB_COMPRESS_FEATS")):
+    kws = {"text_scores": text_scores, "compress_feats": compress_feats, "mfcc_f32": mfcc_f32}
+    for key, env in _PIPELINE_ENV:
+        kw = kws[key]
         if kw is not None:
             out[key] = int(bool(kw))
             continue
@@ -70,7 +75,7 @@ class _GmmSystem(object):
     PIPELINE = None  # class default of the two round trips (see REFERENCE_PIPELINE)
 
     def _setup(self, group_id, models, spk_ids, utt_ids, locations, z_means, z_stds, pre_model_dir, engine,
-               text_scores=None, compress_feats=None):
+               text_scores=None, compress_feats=None, mfcc_f32=None):
         self.pre_model_dir = os.path.abspath(pre_model_dir)
         self.group_id = os.path.abspath(group_id)
         self.spk_ids = spk_ids
@@ -83,7 +88,7 @@ class _GmmSystem(object):
         if os.path.isdir(conf):
             from .config import frontend_from_kaldi_conf
             over = frontend_from_kaldi_conf(self.pre_model_dir)
-        over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE))
+        over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32))
         if over:
             self._engine.set_frontend(**over)
         self._engine.load_gmm(models)
@@ -110,13 +115,13 @@ class gmm_OSI(_GmmSystem):
     task = "OSI"
 
     def __init__(self, group_id, model_list, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None,
-                 text_scores=None, compress_feats=None):
+                 text_scores=None, compress_feats=None, mfcc_f32=None):
         self.threshold = threshold
         locs = [m[2] for m in model_list]
         self.model_list = [ubm] + locs  # UBM first (gmm_ubm_OSI.py:45)
         models = [load_gmm_any(x) for x in self.model_list]
         self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs, None, None,
-                    pre_model_dir, engine, text_scores, compress_feats)
+                    pre_model_dir, engine, text_scores, compress_feats, mfcc_f32)
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
         raw = self._raw(audios, bits_per_sample)
@@ -142,14 +147,14 @@ class gmm_CSI(_GmmSystem):
     task = "CSI"
 
     def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, text_scores=None,
-                 compress_feats=None):
+                 compress_feats=None, mfcc_f32=None):
         locs = [m[2] for m in model_list]
         self.model_list = locs
         self.z_norm_means = np.array([m[3] for m in model_list], np.float64)
         self.z_norm_stds = np.array([m[4] for m in model_list], np.float64)
         models = [load_gmm_any(x) for x in locs]
         self._setup(group_id, models, [m[0] for m in model_list], [m[1] for m in model_list], locs,
-                    self.z_norm_means, self.z_norm_stds, pre_model_dir, engine, text_scores, compress_feats)
+                    self.z_norm_means, self.z_norm_stds, pre_model_dir, engine, text_scores, compress_feats, mfcc_f32)
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
         raw = self._raw(audios, bits_per_sample)
@@ -171,7 +176,7 @@ class gmm_SV(_GmmSystem):
     task = "SV"
 
     def __init__(self, spk_id, model, ubm, pre_model_dir="pre-models", threshold=0.0, engine=None,
-                 text_scores=None, compress_feats=None):
+                 text_scores=None, compress_feats=None, mfcc_f32=None):
         self.threshold = threshold
         self.utt_id = model[1]
         self.identity_location = model[2]
@@ -200,7 +205,7 @@ class _IvSystem(object):
     task = None
     PIPELINE = None
 
-    def _setup(self, group_id, model_list, pre_model_dir, engine, system, text_scores=None, compress_feats=None):
+    def _setup(self, group_id, model_list, pre_model_dir, engine, system, text_scores=None, compress_feats=None, mfcc_f32=None):
         from .models import IvectorSystem
         self.pre_model_dir = os.path.abspath(pre_model_dir)
         self.group_id = os.path.abspath(group_id)
@@ -231,13 +236,13 @@ class _IvSystem(object):
             if os.path.isdir(conf):
                 from .config import frontend_from_kaldi_conf
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
-            over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE))
+            over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32))
             if over:
                 self._engine.set_frontend(**over)
             d = load_ivector_pre_models(self.pre_model_dir)
             system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
         else:
-            over = _pipeline_options(text_scores, compress_feats, self.PIPELINE)
+            over = _pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32)
             if over:
                 self._engine.set_frontend(**over)
             system = system.with_enrolled(enrolled, zm, zs)
@@ -263,9 +268,9 @@ class iv_OSI(_IvSystem):
     task = "OSI"
 
     def __init__(self, group_id, model_list, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None,
-                 text_scores=None, compress_feats=None):
+                 text_scores=None, compress_feats=None, mfcc_f32=None):
         self.threshold = threshold
-        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats)
+        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats, mfcc_f32)
 
     def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
         s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds   # :119
@@ -293,8 +298,8 @@ class iv_CSI(_IvSystem):
     task = "CSI"
 
     def __init__(self, group_id, model_list, pre_model_dir="pre-models", engine=None, system=None, text_scores=None,
-                 compress_feats=None):
-        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats)
+                 compress_feats=None, mfcc_f32=None):
+        self._setup(group_id, model_list, pre_model_dir, engine, system, text_scores, compress_feats, mfcc_f32)
 
     def score(self, audio_list, fs=16000, bits_per_sample=16, n_jobs=10, debug=False):
         s = (self._llr(audio_list, bits_per_sample) - self.z_norm_means) / self.z_norm_stds
@@ -317,9 +322,9 @@ class iv_SV(_IvSystem):
     task = "SV"
 
     def __init__(self, spk_id, model, pre_model_dir="pre-models", threshold=0.0, engine=None, system=None,
-                 text_scores=None, compress_feats=None):
+                 text_scores=None, compress_feats=None, mfcc_f32=None):
         self.threshold = threshold
-        self._setup(spk_id, [model], pre_model_dir, engine, system, text_scores, compress_feats)
+        self._setup(spk_id, [model], pre_model_dir, engine, system, text_scores, compress_feats, mfcc_f32)
         self.spk_id = self.group_id
         self.utt_id = model[1]
         self.identity_location = model[2]

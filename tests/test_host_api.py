@@ -442,19 +442,20 @@ def test_pipeline_option_precedence_and_dropin_defaults(monkeypatch):
     import subprocess
     import sys
     from fakebob_amd import systems
-    for k in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS"):
+    for k in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS", "FB_MFCC_F32"):
         monkeypatch.delenv(k, raising=False)
     ref = systems.REFERENCE_PIPELINE
     assert systems._pipeline_options(None, None) == {}                        # nobody said anything: engine flags stay
     assert systems._pipeline_options(True, None) == {"text_scores": 1}
     assert systems._pipeline_options(None, False) == {"compress_feats": 0}   # an explicit False clears a shared engine's flag
-    assert systems._pipeline_options(None, None, ref) == {"text_scores": 1, "compress_feats": 1}
+    assert systems._pipeline_options(None, None, ref) == {"text_scores": 1, "compress_feats": 1, "mfcc_f32": 1}
+    assert systems._pipeline_options(None, None, None, mfcc_f32=True) == {"mfcc_f32": 1}
     monkeypatch.setenv("FB_TEXT_SCORES", "1")
     monkeypatch.setenv("FB_COMPRESS_FEATS", "1")
     assert systems._pipeline_options(None, None) == {"text_scores": 1, "compress_feats": 1}
     assert systems._pipeline_options(False, False) == {"text_scores": 0, "compress_feats": 0}   # keyword wins, both ways
     monkeypatch.setenv("FB_TEXT_SCORES", "0")
-    assert systems._pipeline_options(None, None, ref) == {"text_scores": 0, "compress_feats": 1}     # env wins over the class default
+    assert systems._pipeline_options(None, None, ref) == {"text_scores": 0, "compress_feats": 1, "mfcc_f32": 1}     # env wins over the class default
     sub = systems.reference_pipeline(systems.gmm_OSI)
     assert issubclass(sub, systems.gmm_OSI) and sub.__name__ == "gmm_OSI" and sub.PIPELINE == ref
     assert systems.gmm_OSI.PIPELINE is None and systems.iv_SV.PIPELINE is None
@@ -467,11 +468,11 @@ def test_pipeline_option_precedence_and_dropin_defaults(monkeypatch):
             "                  (ivector_PLDA_OSI, 'iv_OSI'), (ivector_PLDA_CSI, 'iv_CSI'), (ivector_PLDA_SV, 'iv_SV')):\n"
             "    cls = getattr(mod, name)\n"
             "    assert issubclass(cls, getattr(systems, name)) and cls is not getattr(systems, name)\n"
-            "    assert cls.PIPELINE == {'text_scores': True, 'compress_feats': True}\n"
+            "    assert cls.PIPELINE == {'text_scores': True, 'compress_feats': True, 'mfcc_f32': True}\n"
             "    assert getattr(systems, name).PIPELINE is None\n"
             "assert systems._pipeline_options(None, None) == {}\n"
             "from fakebob_amd.attack import FakeBob\n"
             "assert FAKEBOB.FakeBob is FakeBob\n"
             % (os.path.join(root, "fakebob_amd", "dropin"), root))
-    env = {k: v for k, v in os.environ.items() if k not in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS")}
+    env = {k: v for k, v in os.environ.items() if k not in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS", "FB_MFCC_F32")}
     subprocess.run([sys.executable, "-c", code], check=True, env=env)
