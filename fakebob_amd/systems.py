@@ -183,7 +183,7 @@ class gmm_SV(_GmmSystem):
         self.model_list = [ubm, self.identity_location]
         models = [load_gmm_any(x) for x in self.model_list]
         self._setup(spk_id, models, [model[0]], [model[1]], [model[2]], None, None, pre_model_dir, engine,
-                    text_scores, compress_feats)
+                    text_scores, compress_feats, mfcc_f32)
         self.spk_id = self.group_id
 
     def score(self, audios, fs=16000, bits_per_sample=16, debug=False, n_jobs=5):
