@@ -606,7 +606,16 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         }
         return w;
       };
-      const double budget2 = 6.0e-6 * 6.0e-6, ce1 = 0.14 * 0.14, ce2 = 0.07 * 0.07;
+      // FB_GMM_DELTA_BUDGET: the error budget of the rule (default 6e-6: float32-equivalent scores).  north_star asks
+      // for 1e-4 against the reference; a caller who wants only that can say so (e.g. 5e-5) and gets two products where
+      // the default insists on three -- measured and reported separately by bench.py, never the headline
+      double budget = 6.0e-6;
+      if (const char *be = getenv("FB_GMM_DELTA_BUDGET")) {
+        const double v = atof(be);
+        if (!(v >= 1e-7 && v <= 1e-4)) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_BUDGET must be in [1e-7, 1e-4] (got '%s')", be);
+        budget = v;
+      }
+      const double budget2 = budget * budget, ce1 = 0.14 * 0.14, ce2 = 0.07 * 0.07;
       int t2 = n_tiles, t3 = n_tiles;  // tiles [0, t3): P = 3, [t3, t2): P = 2, [t2, n_tiles): P = 1
       while (t2 > 0 && ce1 * worst_sum(t2 - 1, n_tiles) <= 0.75 * budget2) --t2;  // (the P = 1 tail may use 3/4 of the budget)
       t3 = t2;
