@@ -987,8 +987,8 @@ static int time_end(fb_engine *e, int what = 1) {
 }
 
 static bool fb_fuse_on(const fb_engine *e);
-// k_iv_solve_rw (four workgroups per matrix) is the LATENCY form of the posterior solve: it finishes a batch of 51 systems
-// sooner, on 204 compute units instead of 51 -- right for one attack per GPU, wrong when several attacks share the chip
+// k_iv_solve_rw (five workgroups per matrix) is the LATENCY form of the posterior solve: it finishes a batch of 51 systems
+// sooner, on 255 compute units instead of 51 -- right for one attack per GPU, wrong when several attacks share the chip
 // and the idle units are what their kernels run on.  fb_set_fused_chain(e, 1) -- what the drivers choose for one or two
 // attacks in flight -- selects it; FB_IV_SOLVE=rw | ll forces either.
 static bool fb_iv_use_rw(const fb_engine *e) {
@@ -1170,7 +1170,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FB_DBG_SYNC(e, "contract");
     FBCHK(time_begin(e, 2));
     // FB_IV_SOLVE=ll keeps the one-workgroup-per-matrix kernel (A/B); otherwise the row-wise kernel whenever its grid of
-    // 4 workgroups per matrix is resident at once, which is when the chip has idle units to give it
+    // 5 workgroups per matrix is resident at once, which is when the chip has idle units to give it
     if (fb_iv_use_rw(e) &&
         fb_launch_iv_solve_rw(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B, e->iv_A.as<double>(),
                               e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>(), e->iv_prog.as<unsigned>(),

@@ -258,8 +258,8 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // R + 64 zeros behind them
 void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                            int B, double *Aall, double *LinvAll, double *ivec, int *fail);
-// k_iv_solve_rw: the same system with the block rows of a matrix dealt over four workgroups (up-looking Cholesky); false
-// = B x 4 workgroups are more than the chip holds at once (the caller runs fb_launch_iv_solve_ll).  LinvAll: TWO slot
+// k_iv_solve_rw: the same system with the block rows of a matrix dealt over five workgroups (up-looking Cholesky); false
+// = B x 5 workgroups are more than the chip holds at once (the caller runs fb_launch_iv_solve_ll).  LinvAll: TWO slot
 // sets (fb_iv_solve_rw_linv_doubles), every 64-bit word 0x7ff87ff87ff87ff8 before the first launch and whenever `epoch`
 // restarts; prog: fb_iv_solve_rw_prog_words() unsigned, zero then; ticket: one int, zero
 size_t fb_iv_solve_rw_linv_doubles(const FbIvDev &iv, int B);

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_iv_solve_rw (round 4): the same factorisation ROW-WISE over G workgroups per matrix.  One workgroup per matrix has a
+// k_iv_solve_rw (round 4): the same factorisation ROW-WISE over G (= FB_RW_G = 5) workgroups per matrix.  One workgroup per matrix has a
 // floor of ~200 us -- 13 serial 32 x 32 block factorisations of 7 us with seven waves idle, and at samples_per_draw = 50
 // only 51 of 256 compute units have a matrix at all.  Here block row rb (32 rows: tile rows 2 rb, 2 rb + 1; the right-hand
 // side rides along as row R) belongs to workgroup rb % G, which does everything for it, column by column ("up-looking"
@@ -798,7 +798,10 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
 // LinvAll: TWO slot sets of B x npanel x 32 x 32 doubles, every word FB_RW_SENT before the first launch / after an epoch
 // restart; prog: B x (block rows + 1) unsigned, zero then; ticket: one int, zero.  Returns false when the grid of B x G
 // workgroups would not be resident at once (the caller then runs k_iv_solve_ll).
-#define FB_RW_G 4
+// 5 workgroups per matrix: 255 of the 256 compute units at samples_per_draw = 50 (51 systems).  With 4 the late block rows'
+// catch-up (all the columns that became available while the workgroup finished its previous row, ~5 us each) fell behind
+// the serial chain from row 7 on: 208 us against 194 (profiles/r04_rw_stamps_d.txt, _e.txt)
+#define FB_RW_G 5
 size_t fb_iv_solve_rw_linv_doubles(const FbIvDev &iv, int B) { return (size_t)2 * B * ((iv.R + 31) / 32) * 1024; }
 size_t fb_iv_solve_rw_prog_words(const FbIvDev &iv, int B) { return (size_t)B * ((iv.R + 1 + 31) / 32 + 1); }
 bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks, int B,

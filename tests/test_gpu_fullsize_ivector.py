@@ -129,7 +129,7 @@ def test_full_size_osi_get_grad_spd200_b201(oracle):
 
 
 def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypatch):
-    """k_iv_solve_rw (round 4: the block rows of a posterior system dealt over four workgroups, cross-workgroup exchange
+    """k_iv_solve_rw (round 4: the block rows of a posterior system dealt over five workgroups, cross-workgroup exchange
     through agent-scope stores, progress words and sentinel-polled inverse factors) against k_iv_solve_ll (one workgroup
     per matrix) and the oracle at the benchmarked size (C = 2048, R = 400), over REPEATED launches (the slot sets
     alternate with the launch epoch), a batch of 51 and one of 3, and a switch between the kernels on one engine (the slot
