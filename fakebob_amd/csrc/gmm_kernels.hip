@@ -450,14 +450,29 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
     } else {
       fb_fx_step<NK, false>(cur, lane, bx1, bx2, hq, pv);
       if constexpr (DUMP) {
-        if (row < n_rows) {
-          const int tile = tile0 + it / g.n_items;
-          float *dst = part_m + (size_t)row * (g.n_tiles * 32) + tile * 32 + 4 * h;
+        // The wave's 32 frames x 32 components go out as WHOLE 128-byte rows: through a per-wave LDS tile (row stride 36
+        // floats) into the order "eight consecutive lanes = one frame's row", four store instructions of eight full
+        // lines each.  Straight from the accumulator layout a lane held four separate 16-byte pieces of its frame's
+        // row and every store instruction touched 32 lines with 32 bytes each: the PMC pass counted 234 MB written for
+        // 125 MB of values (profiles/r04_traffic.json).
+        const int tile = tile0 + it / g.n_items;
+        float *tb = lds + 2 * IMG4 * 4 + 2 * g.M * 256 + w * (32 * 36);
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<float4 *>(dst + 8 * rr) = make_float4(pv[4 * rr] * unscale, pv[4 * rr + 1] * unscale,
-                                                                    pv[4 * rr + 2] * unscale, pv[4 * rr + 3] * unscale);
+        for (int rr = 0; rr < 4; ++rr)
+          *reinterpret_cast<float4 *>(tb + j * 36 + 8 * rr + 4 * h) = make_float4(pv[4 * rr] * unscale, pv[4 * rr + 1] * unscale,
+                                                                              pv[4 * rr + 2] * unscale, pv[4 * rr + 3] * unscale);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int fr = 8 * i + (lane >> 3), piece = lane & 7, rg = strip0 + w * 32 + fr;
+          const float4 v = *reinterpret_cast<const float4 *>(tb + fr * 36 + 4 * piece);
+          if (rg < n_rows) *reinterpret_cast<float4 *>(part_m + (size_t)rg * (g.n_tiles * 32) + tile * 32 + 4 * piece) = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the tile is read before the next item overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else {
         if (it >= pad_it0) {  // last tile of a model whose C is not a multiple of 32: the padding components' gconst
                               // (-60000 2^-kl, the most an f16 image can hold) must not compete with far-off frames
@@ -501,7 +516,8 @@ static void launch_gmm_fx_t(hipStream_t s, const FbGmmDev &g, const float *feats
     grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
     xcd_map = n_chunks;
   }
-  const size_t ldsb = (size_t)2 * 2 * NK * 64 * 16 + (size_t)2 * g.M * 256 * sizeof(float);
+  const size_t ldsb = (size_t)2 * 2 * NK * 64 * 16 + (size_t)2 * g.M * 256 * sizeof(float) +
+                      (DUMP ? (size_t)4 * 32 * 36 * sizeof(float) : 0);   // + the dump's per-wave transposition tiles
   hipLaunchKernelGGL((k_gmm_fx2<NK, DUMP>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, rows_cap,
                      part_m, part_s, xcd_map);
 }
