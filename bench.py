@@ -389,7 +389,7 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"
     `peak` = the dense peak of the pipe the kernel issues its MFMAs on (f16 / bf16: 2.5 PF), so `frac` is a true
     fraction.  `executed_*`: the products the kernel really issues per (frame, component), K padded to 16*nk:
     k_gmm_fx2w -- the shared quadratic item and the base model with 3 partial products each, every other model as a
-    delta item with the products of its component tile (tiles = (#P=1, #P=2, #P=3)); k_gmm_fx2 / k_gmm_bx3 -- quadratic
+    delta item with the products of its component tile (tiles = (#P=1, #P=2, #P=3, #F6)); k_gmm_fx2 / k_gmm_bx3 -- quadratic
     item + one item per model, 3 / 6 partial products each."""
     per_s = 1.0 / (gmm_ms_avg * 1e-3) / 1e12 if gmm_ms_avg > 0 else 0.0
     achieved = flops_launch * per_s
@@ -398,15 +398,18 @@ def _gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant="fx2w/3"
         nk = (D_FEAT + 1 + 15) // 16
         pipe, peak = "f16 MFMA (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
         if variant.startswith("fx2w/"):
-            n1, n2, n3 = tiles if tiles and sum(tiles) else (0, 0, 1)
-            p_avg = (n1 + 2.0 * n2 + 3.0 * n3) / (n1 + n2 + n3)
+            n1, n2, n3, n6 = (tuple(tiles) + (0,))[:4] if tiles and sum(tiles) else (0, 0, 1, 0)
+            # (an F6 item issues its five f16 MFMAs and four scaled fp6 / fp4 MFMAs per half, each of the latter in the
+            #  time of one f16 MFMA: counted as 9 / 5 products' worth of f16 issue slots)
+            p_avg = (n1 + 2.0 * n2 + 3.0 * n3 + 1.8 * n6) / (n1 + n2 + n3 + n6)
             ex = flops_launch * (3 + 3 + (M - 1) * p_avg) * 2.0 * 16 * nk / alg_per_fc
             name = ("k_gmm_fx2w<5,%d> (diag-GMM log-likelihood + logsumexp; f32 operands as a two-term f16 split, "
                     "f32 accumulate on v_mfma_f32_32x32x16_f16: shared quadratic item and the base model with 3 partial "
                     "products, the other %d models as deltas from the base model's accumulator with 1 / 2 / 3 products "
-                    "per component tile (%d / %d / %d tiles, components sorted by adaptation distance); accumulators in "
+                    "per component tile or one product + the corrections on v_mfma_scale_f32_32x32x64_f8f6f4 (F6) "
+                    "(%d / %d / %d / %d tiles, components sorted by adaptation distance); accumulators in "
                     "log2 units relative to a per-frame reference: one v_exp_f32 + one v_add_f32 per value; one wave per "
-                    "SIMD, 64 frames per wave, software-pipelined)" % (M, M - 1, n1, n2, n3))
+                    "SIMD, 64 frames per wave, software-pipelined)" % (M, M - 1, n1, n2, n3, n6))
         else:
             ex = flops_launch * (1 + M) * 3 * 2.0 * 16 * nk / alg_per_fc
             name = "k_gmm_fx2<5,false> (two-term f16 split, 3 partial products per item, quadratic item shared)"
@@ -569,7 +572,7 @@ def main():
         prms.append(nes_params(gmm_task, attack_type, seed=42, stream=utt, **kw))
     audio = auds[0]
     n_models = len(models)
-    variant, tiles = engs[0].gmm_kernel_variant, engs[0].gmm_delta_tiles
+    variant, tiles = engs[0].gmm_kernel_variant, engs[0].gmm_delta_tiles + (engs[0].gmm_delta_tiles_f6,)
     if not variant.startswith("fx2w/") and GMM_MODE == "fx2":
         print("bench.py: WARNING: this system is scored by the general kernel %s, not k_gmm_fx2w (more than %d models, "
               "several variance groups or partial tiles)" % (variant, 10), file=sys.stderr)
@@ -634,9 +637,11 @@ def main():
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "gmm_kernel": variant,
                        "gmm_delta_p": {"tiles_p1": tiles[0], "tiles_p2": tiles[1], "tiles_p3": tiles[2],
-                                       "shift_rms": engs[0].gmm_shift_rms,
-                                       "note": "component tiles (32 components) by the partial products their delta items run; "
-                                               "chosen by fb_load_gmm from the models (DESIGN.md section 5)"},
+                                       "tiles_f6": engs[0].gmm_delta_tiles_f6, "shift_rms": engs[0].gmm_shift_rms,
+                                       "note": "component tiles (32 components) by the class of their delta items: 1 .. 3 f16 "
+                                               "partial products, or F6 = one f16 product + the two corrections as "
+                                               "block-scaled fp6 / fp4 products; chosen by fb_load_gmm from the models "
+                                               "(DESIGN.md section 5)"},
                        "seeds": {"audio": 1234, "ubm": 2001, "speakers": 2100, "philox": 42}},
             "roofline": dict(_gmm_roofline(flops_launch, gmm_ms_avg, solo_ms, solo_rows, variant, tiles, n_models),
                              gmm_share_of_stream_time=ms_gmm / ms_dev if ms_dev > 0 else None,
@@ -673,7 +678,7 @@ def main():
 
         def gmm_case(name, note, n_mod):
             r = quick_measure(torch, aset, n2, 10, chain_fused=fused)
-            r["gmm_kernel"], r["gmm_delta_tiles"] = engs[0].gmm_kernel_variant, list(engs[0].gmm_delta_tiles)
+            r["gmm_kernel"], r["gmm_delta_tiles"] = engs[0].gmm_kernel_variant, list(engs[0].gmm_delta_tiles) + [engs[0].gmm_delta_tiles_f6]
             fl = n_mod * C_GAUSS * 4 * D_FEAT * r["voiced_rows_per_iter"]
             r["kernel_solo_frac"] = fl / (r["kernel_solo_launch_ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
             r["note"] = note
@@ -685,14 +690,20 @@ def main():
             wc = gmm_case("forced_three_products", "the headline workload with three partial products forced in every tile "
                           "(FB_GMM_DELTA_P=3): what k_gmm_fx2w costs for speaker models adapted arbitrarily far", n_models)
             out["roofline"]["worst_case"] = {
-                "kernel_variant": wc["gmm_kernel"], "tiles_p1_p2_p3": wc["gmm_delta_tiles"], "value": wc["value"],
+                "kernel_variant": wc["gmm_kernel"], "tiles_p1_p2_p3_f6": wc["gmm_delta_tiles"], "value": wc["value"],
                 "single_attack": wc["single_attack"]["value"], "avg_launch_ms": wc["kernel_avg_launch_ms"],
                 "solo_launch_ms": wc["kernel_solo_launch_ms"], "solo_frac": wc["kernel_solo_frac"], "steps": n2,
-                "note": "same run, same workload, P = 3 in every component tile: the bracket of `value` for real speaker models"}
+                "note": "same run, same workload, P = 3 in every component tile: what speaker models unrelated to model 0 cost "
+                        "(the lower bracket of `value`; models adapted from model 0, however far, run the F6 class: "
+                        "secondary.forced_f6)"}
+            reload(models, "OSI", (None, None), kw, "targeted", env={"FB_GMM_DELTA_P": "6"})
+            gmm_case("forced_f6", "the headline workload with the F6 class forced in every tile (FB_GMM_DELTA_P=6: one f16 "
+                     "product + the two corrections as block-scaled fp6 / fp4 products, float32-equivalent scores): what "
+                     "k_gmm_fx2w costs for speakers enrolled on any amount of data", n_models)
             ubm_r, spk_r = synthetic_gmm_system(S_SPK, C_GAUSS, D_FEAT, **ENROL_REALISTIC)
             reload([ubm_r] + spk_r, "OSI", (None, None), kw, "targeted")
             gmm_case("realistic_enrolment", "speakers enrolled on 20 000 frames (models.ENROL_REALISTIC: alpha ~ 0.2-0.4 where "
-                     "the enrolment data fell), products per tile chosen by fb_load_gmm", n_models)
+                     "the enrolment data fell), the class of every tile chosen by fb_load_gmm", n_models)
             reload([ubm_r] + spk_r, "OSI", (None, None), kw, "targeted", env={"FB_GMM_DELTA_BUDGET": "5e-5"})
             gmm_case("realistic_enrolment_budget_5e-5", "the same speakers with the delta-product rule's error budget relaxed "
                      "from 6e-6 (float32-equivalent scores, the default) to 5e-5 (inside north_star's 1e-4 against the "

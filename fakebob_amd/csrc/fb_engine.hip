@@ -448,7 +448,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // f16x2 images (k_gmm_fx2): two-term f16 split (residual scaled by 2^12), gconst at K position D.
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
-  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0, delta_t3 = 0, delta_t2 = 0;
+  int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0, delta_t3 = 0, delta_t2 = 0, delta_t6 = 0;
   e->gmm_delta_rms = 0.0;
   // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
   // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
@@ -615,19 +615,37 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         if (!(v >= 1e-7 && v <= 1e-4)) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_BUDGET must be in [1e-7, 1e-4] (got '%s')", be);
         budget = v;
       }
-      const double budget2 = budget * budget, ce1 = 0.14 * 0.14, ce2 = 0.07 * 0.07;
-      int t2 = n_tiles, t3 = n_tiles;  // tiles [0, t3): P = 3, [t3, t2): P = 2, [t2, n_tiles): P = 1
+      // The F6 class (round 4): the two products P = 1 leaves out -- delta's second term against the frames' leading
+      // term, delta's leading term against the frames' second -- taken in block-scaled fp6 / fp4 by four
+      // v_mfma_scale_f32_32x32x64_f8f6f4 per 32-frame half (K = 64 each at the price of one K = 16 f16 product: ~20 ns,
+      // tools/probes/f6_mfma_probe.hip) instead of ten f16 products; operands and their layout: the F6 item below.
+      // What an utterance average keeps of their rounding, measured on the realistic enrolment with the class in every
+      // tile: max |err| 7.1e-6 against 3.2e-4 for P = 1, 6.8e-5 for P = 2 and 3.3e-6 for P = 3 (the float32 accumulation
+      // error every variant carries) -- c = 0.003 in the model above, cheaper AND closer than P = 2, which the rule
+      // therefore no longer chooses (FB_GMM_DELTA_F6=0 brings the earlier rule back: P = 2 in the middle, no F6 tiles).
+      const double budget2 = budget * budget, ce1 = 0.14 * 0.14, ce2 = 0.07 * 0.07, ce6 = 0.003 * 0.003;
+      bool use_f6 = true;
+      if (const char *fe6 = getenv("FB_GMM_DELTA_F6")) use_f6 = !(fe6[0] == '0' && fe6[1] == 0);
+      // tiles [0, t3): P = 3, [t3, t6): F6, [t6, t2): P = 2, [t2, n_tiles): P = 1
+      int t2 = n_tiles, t3 = n_tiles, t6 = n_tiles;
       while (t2 > 0 && ce1 * worst_sum(t2 - 1, n_tiles) <= 0.75 * budget2) --t2;  // (the P = 1 tail may use 3/4 of the budget)
-      t3 = t2;
+      t3 = t6 = t2;
       {
         const double left = budget2 - ce1 * worst_sum(t2, n_tiles);
-        while (t3 > 0 && ce2 * worst_sum(t3 - 1, t2) <= left) --t3;
+        if (use_f6) {
+          while (t3 > 0 && ce6 * worst_sum(t3 - 1, t2) <= left) --t3;
+          t6 = t2;
+        } else {
+          while (t3 > 0 && ce2 * worst_sum(t3 - 1, t2) <= left) --t3;
+          t6 = t3;
+        }
       }
-      const char *pe = getenv("FB_GMM_DELTA_P");  // tests / worst-case benchmark: the same number of products in every tile
+      const char *pe = getenv("FB_GMM_DELTA_P");  // tests / worst-case benchmark: the same class in every tile (6 = F6)
       if (pe && *pe) {
         const int v = atoi(pe);
-        if (v < 1 || v > 3) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_P must be 1, 2 or 3 (got '%s')", pe);
+        if (!(v >= 1 && v <= 3) && v != 6) return fb_fail(FB_E_ARG, "FB_GMM_DELTA_P must be 1, 2, 3 or 6 (got '%s')", pe);
         t3 = v == 3 ? n_tiles : 0;
+        t6 = v == 6 ? n_tiles : t3;
         t2 = v >= 2 ? n_tiles : 0;
       }
       {  // (reported by fb_gmm_kernel_variant: the equal-weight statistic of round 3)
@@ -635,8 +653,15 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         for (double v : b2) sumsq += v;
         e->gmm_delta_rms = sqrt(sumsq / ((double)(M - 1) * C));
       }
-      const int want_p = (n_tiles - t2 >= t2 - t3 && n_tiles - t2 >= t3) ? 1 : (t2 - t3 >= t3 ? 2 : 3);  // what most tiles run
-      auto tile_p = [&](int t) { return t < t3 ? 3 : (t < t2 ? 2 : 1); };
+      auto tile_p = [&](int t) { return t < t3 ? 3 : (t < t6 ? 6 : (t < t2 ? 2 : 1)); };
+      int want_p = 1;  // what most tiles run
+      {
+        const int cnt[4] = {n_tiles - t2, t2 - t6, t3, t6 - t3}, cls[4] = {1, 2, 3, 6};
+        int best = 0;
+        for (int i = 1; i < 4; ++i)
+          if (cnt[i] > cnt[best]) best = i;
+        want_p = cls[best];
+      }
 
       // The images are in LOG2 units: every parameter is multiplied by log2 e in float64 and then split into its f16
       // terms -- the accumulators of k_gmm_fx2w then hold the exponent of 2 directly and its logsumexp update needs
@@ -687,6 +712,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
               const int c = perm[t * 32 + cc];
               double cst = m == 0 ? L2E * (double)gconsts[c]
                                   : (m > 0 ? L2E * (double)(gconsts[(size_t)m * C + c] - gconsts[c]) : 0.0);
+              double vv[96] = {0.0}, aa[96] = {0.0};  // the linear parameters and their leading f16 terms (F6 items)
               for (int k = 0; k < D; ++k) {
                 double v;
                 if (m < 0) v = ldexp(L2E * (double)(-0.5f * iv[(size_t)c * D + k]), -kq[k]);
@@ -694,9 +720,129 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
                 else v = ldexp(L2E * (double)(miv[((size_t)m * C + c) * D + k] - miv[(size_t)c * D + k]), -kd[k]);
                 const double a = f16r(v);
                 put16(a, at(0, k, cc));
+                vv[k] = v;
+                aa[k] = a;
+                if (m > 0 && tile_p(t) == 6) continue;  // (the second half of the item holds the fp6 operands: below)
                 put16(v - a, at(1, k, cc));
                 if (m > 0 && tile_p(t) == 1)  // the dropped second term at the component's mean (mu' = mu 2^kd)
                   cst += (v - a) * ldexp((double)miv[(size_t)c * D + k] / (double)iv[(size_t)c * D + k], kd[k]);
+              }
+              if (m > 0 && tile_p(t) == 6) {
+                // F6 item: [0, 5 KB) the leading f16 term as above; then, per lane (kh, cc) -- the lane that holds the
+                // component's K places 8 kh .. 8 kh + 7 of every chunk, as in the f16 fragments -- blocks of 32 codes with
+                // one power-of-two scale each (value u in bits [6u, 6u + 6) resp. [4u, 4u + 4) of the lane's operand):
+                //   block 0 (e2m3): u = 8 c + i, c < 4: delta's SECOND term d2 at dimension 16 c + 8 kh + i  (against x_1)
+                //   block L (e2m1): the same places: what block 0's codes leave of d2                     (against x_1)
+                //   block 1 (e2m3): the same places: delta's LEADING term times 2^-12                (against x_2 2^12)
+                //   block 2 (e2m3, lanes kh = 0 only -- the frames' side is zero for kh = 1 --): u < 8: d2 at dimension
+                //            64 + u; 8 <= u < 16: leading term 2^-12 at 64 + u - 8; 16 <= u < 24: what the first eight
+                //            codes leave of d2; zero where the dimension is past D and for u >= 24
+                // The parameters are the same for every frame, so what their rounding leaves does not average out over
+                // an utterance the way the frames' does: d2 in ONE e2m3 term left 1.45e-5 of an utterance average in the
+                // float64 model of this class (tools/probes/f6_corr_emul.py, scratch of round 4: the frames' 4 bits and
+                // the leading term's cost ~1e-6 each), the second term brings that to 3.8e-6.  (The 2^-12 / 2^12 pair
+                // keeps block 2's kinds of values inside one scale's range on both sides.)
+                // Bytes: 5120 block 0 bits 0 .. 127 [64] x 16, 6144 its bits 128 .. 191 [64] x 8, 6656 / 7680 block 1
+                // likewise, 8192 block L [64] x 16, 9216 / 9728 block 2 [32] x 16 / [32] x 8, 9984 [64] x 4: the scale
+                // bytes (e8m0: 2^(byte - 127)) of blocks 0, 1, L, 2.
+                uint8_t *ib = reinterpret_cast<uint8_t *>(im);
+                const int DC = 64;  // dimensions of the chunks 0 .. 3
+                auto scale_for = [](const double *val, int n, double top) {  // smallest e with max |val| 2^-e <= top
+                  double mx = 0.0;
+                  for (int u = 0; u < n; ++u) mx = std::max(mx, fabs(val[u]));
+                  int ex = -126;
+                  if (mx > 0.0) {
+                    ex = (int)ceil(log2(mx / top));
+                    while (ldexp(mx, -ex) > top) ++ex;
+                    while (ldexp(mx, -(ex - 1)) <= top) --ex;
+                    ex = std::min(127, std::max(-126, ex));
+                  }
+                  return ex;
+                };
+                auto code_e2m3 = [](double v, int ex, double *got) {  // nearest code (ties to even), |v| 2^-ex <= 7.5
+                  const double q = fabs(ldexp(v, -ex));
+                  const double step = q < 2.0 ? 0.125 : (q < 4.0 ? 0.25 : 0.5), base = q < 2.0 ? 0.0 : (q < 4.0 ? 2.0 : 4.0);
+                  int code = std::min((q < 2.0 ? 0 : (q < 4.0 ? 16 : 24)) + (int)nearbyint((q - base) / step), 31);
+                  const double dq = code < 16 ? code * 0.125 : (code < 24 ? 2.0 + (code - 16) * 0.25 : 4.0 + (code - 24) * 0.5);
+                  *got = (v < 0.0 ? -1.0 : 1.0) * ldexp(dq, ex);
+                  return code | (v < 0.0 ? 32 : 0);
+                };
+                auto code_e2m1 = [](double v, int ex, double *got) {  // 0, .5, 1, 1.5, 2, 3, 4, 6
+                  const double q = fabs(ldexp(v, -ex));
+                  const double step = q < 2.0 ? 0.5 : (q < 4.0 ? 1.0 : 2.0), base = q < 2.0 ? 0.0 : (q < 4.0 ? 2.0 : 4.0);
+                  int code = std::min((q < 2.0 ? 0 : (q < 4.0 ? 4 : 6)) + (int)nearbyint((q - base) / step), 7);
+                  const double dq = code < 4 ? code * 0.5 : (code < 6 ? 2.0 + (code - 4) * 1.0 : 4.0 + (code - 6) * 2.0);
+                  *got = (v < 0.0 ? -1.0 : 1.0) * ldexp(dq, ex);
+                  return code | (v < 0.0 ? 8 : 0);
+                };
+                auto put6 = [](uint64_t (&bits)[3], int u, int code) {
+                  const int bit = 6 * u;
+                  bits[bit >> 6] |= (uint64_t)code << (bit & 63);
+                  if ((bit & 63) > 58) bits[(bit >> 6) + 1] |= (uint64_t)code >> (64 - (bit & 63));
+                };
+                auto mean_at = [&](int k) { return ldexp((double)miv[(size_t)c * D + k] / (double)iv[(size_t)c * D + k], kd[k]); };
+                for (int kh = 0; kh < 2; ++kh) {
+                  const int lane = kh * 32 + cc;
+                  uint32_t scales = 0;
+                  int dim[32];
+                  double v2[32], v1[32], left[32], got;
+                  for (int u = 0; u < 32; ++u) {
+                    const int k = 16 * (u / 8) + 8 * kh + (u % 8);
+                    dim[u] = k < D && k < DC ? k : -1;
+                    v2[u] = dim[u] < 0 ? 0.0 : vv[k] - aa[k];
+                    v1[u] = dim[u] < 0 ? 0.0 : ldexp(aa[k], -12);
+                  }
+                  {  // block 0 and block L
+                    const int ex = scale_for(v2, 32, 7.5);
+                    uint64_t bits[3] = {0, 0, 0};
+                    for (int u = 0; u < 32; ++u) {
+                      put6(bits, u, code_e2m3(v2[u], ex, &got));
+                      left[u] = v2[u] - got;
+                    }
+                    memcpy(ib + 5120 + (size_t)lane * 16, &bits[0], 16);
+                    memcpy(ib + 6144 + (size_t)lane * 8, &bits[2], 8);
+                    scales |= (uint32_t)(ex + 127);
+                    const int exl = scale_for(left, 32, 6.0);
+                    uint64_t lb[2] = {0, 0};
+                    for (int u = 0; u < 32; ++u) {
+                      lb[(4 * u) >> 6] |= (uint64_t)code_e2m1(left[u], exl, &got) << ((4 * u) & 63);
+                      if (dim[u] >= 0) cst += (left[u] - got) * mean_at(dim[u]);  // what both terms leave, at the component's mean
+                    }
+                    memcpy(ib + 8192 + (size_t)lane * 16, lb, 16);
+                    scales |= (uint32_t)(exl + 127) << 16;
+                  }
+                  {  // block 1
+                    const int ex = scale_for(v1, 32, 7.5);
+                    uint64_t bits[3] = {0, 0, 0};
+                    for (int u = 0; u < 32; ++u) put6(bits, u, code_e2m3(v1[u], ex, &got));
+                    memcpy(ib + 6656 + (size_t)lane * 16, &bits[0], 16);
+                    memcpy(ib + 7680 + (size_t)lane * 8, &bits[2], 8);
+                    scales |= (uint32_t)(ex + 127) << 8;
+                  }
+                  if (kh == 0) {  // block 2: the dimensions of chunk 4
+                    double val[32] = {0.0};
+                    for (int u = 0; u < 8; ++u) {
+                      const int k = DC + u;
+                      if (k < D) { val[u] = vv[k] - aa[k]; val[8 + u] = ldexp(aa[k], -12); }
+                    }
+                    const int ex = scale_for(val, 16, 7.5);
+                    uint64_t bits[3] = {0, 0, 0};
+                    for (int u = 0; u < 16; ++u) {
+                      put6(bits, u, code_e2m3(val[u], ex, &got));
+                      if (u < 8) val[16 + u] = val[u] - got;
+                    }
+                    for (int u = 16; u < 24; ++u) {
+                      put6(bits, u, code_e2m3(val[u], ex, &got));
+                      if (DC + u - 16 < D) cst += (val[u] - got) * mean_at(DC + u - 16);
+                    }
+                    memcpy(ib + 9216 + (size_t)cc * 16, &bits[0], 16);
+                    memcpy(ib + 9728 + (size_t)cc * 8, &bits[2], 8);
+                    scales |= (uint32_t)(ex + 127) << 24;
+                  } else {
+                    scales |= 127u << 24;
+                  }
+                  memcpy(ib + 9984 + (size_t)lane * 4, &scales, 4);
+                }
               }
               if (m < 0) {  // the frames' reference stands in their x^2 operand as -(R mod 2048), -(R div 2048) (gmm_wide_kernel.hip)
                 put16(1.0, at(0, D + 3, cc));
@@ -771,7 +917,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         }
         FBCHK(e->gmm_anchor.ensure(sizeof(float) * an.size()));
         HIPCHK(hipMemcpy(e->gmm_anchor.p, an.data(), sizeof(float) * an.size(), hipMemcpyHostToDevice));
-        if (fits) { delta_p = want_p; delta_t3 = t3; delta_t2 = t2; }
+        if (fits) { delta_p = want_p; delta_t3 = t3; delta_t2 = t2; delta_t6 = t6; }
       }
     }
   }
@@ -832,6 +978,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.delta_p = mode == FB_GMM_MODE_FX2 ? delta_p : 0;
   g.delta_t3 = g.delta_p ? delta_t3 : 0;
   g.delta_t2 = g.delta_p ? delta_t2 : 0;
+  g.delta_t6 = g.delta_p ? delta_t6 : 0;
   g.images_fd = g.delta_p ? reinterpret_cast<decltype(g.images_fd)>(e->gmm_images_fd.p) : nullptr;
   g.anchor = g.delta_p ? e->gmm_anchor.as<float>() : nullptr;
   g.item_model = e->gmm_items.as<int>();
@@ -2156,9 +2303,16 @@ extern "C" int fb_gmm_delta_tiles(fb_engine *e, int *tiles_p1, int *tiles_p2, in
   if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
   const bool wide = e->kind == 0 && fb_gmm_use_wide(e->gmm);
   if (tiles_p3) *tiles_p3 = wide ? e->gmm.delta_t3 : 0;
-  if (tiles_p2) *tiles_p2 = wide ? e->gmm.delta_t2 - e->gmm.delta_t3 : 0;
+  if (tiles_p2) *tiles_p2 = wide ? e->gmm.delta_t2 - e->gmm.delta_t6 : 0;
   if (tiles_p1) *tiles_p1 = wide ? e->gmm.n_tiles - e->gmm.delta_t2 : 0;
   return wide ? 1 : 0;
+}
+
+extern "C" int fb_gmm_delta_tiles_f6(fb_engine *e) {
+  if (!e) return fb_fail(FB_E_ARG, "null engine");
+  if (!e->have_gmm) return fb_fail(FB_E_STATE, "no GMM loaded");
+  const bool wide = e->kind == 0 && fb_gmm_use_wide(e->gmm);
+  return wide ? e->gmm.delta_t6 - e->gmm.delta_t3 : 0;
 }
 
 extern "C" int fb_debug_mfcc(fb_engine *e, const int16_t *wav, int64_t n, float *mfcc, int *T_out) {

@@ -161,12 +161,13 @@ struct FbGmmDev {
   // common power-of-two factor: every dimension is balanced by exact powers of two of its own, 2^kd / 2^kq, applied to
   // the frames in the kernel and inversely to the parameters here.  The COMPONENTS are stored sorted by how far the
   // other models moved them from the base model (the order is free under logsumexp), so that the partial products per K
-  // chunk a delta item needs fall from tile to tile: tiles [0, delta_t3) are evaluated with 3, [delta_t3, delta_t2)
-  // with 2, the rest with 1.  delta_p = the count most tiles use (1 .. 3; 0: no delta images); anchor = the frames'
+  // chunk a delta item needs fall from tile to tile: tiles [0, delta_t3) are evaluated with 3, [delta_t6, delta_t2)
+  // with 2, the rest with 1.  delta_p = the class most tiles use (1 .. 3, 6 = F6; 0: no delta images); anchor = the frames'
   // balancing factors and the components whose log2-likelihoods start the kernel's per-frame reference (layout:
   // fb_load_gmm)
   const unsigned int __attribute__((ext_vector_type(4))) * images_fd;
   int delta_p, delta_t3, delta_t2;
+  int delta_t6;  // tiles [delta_t3, delta_t6): the F6 class (delta_t3 <= delta_t6 <= delta_t2; fb_load_gmm, gmm_wide_kernel.hip)
   const float *anchor;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output

@@ -310,6 +310,116 @@ __device__ __forceinline__ void fb_fxw_step(const u32x4 *__restrict__ cur4, cons
   out1 = x1;
 }
 
+
+// The F6 form of a delta step (round 4): the leading f16 product (2 NK MFMAs, as NP = 1) and then the two products NP = 1
+// leaves out -- delta_2 . x_1 and delta_1 . x_2 -- as four v_mfma_scale_f32_32x32x64_f8f6f4 per half on block-scaled
+// fp6 / fp4 operands: K = 64 each at the price of one K = 16 f16 MFMA (tools/probes/f6_mfma_probe.hip,
+// f4f6_mfma_probe.hip: ~20 against 22.5 ns), 18 MFMAs per step against NP = 3's 30.  The frames' side is e2m3 (4
+// significant bits: its rounding differs from frame to frame and averages out over an utterance); delta_2, whose
+// rounding is the same for every frame, gets TWO terms (e2m3 + e2m1 of what that leaves), delta_1 -- against the
+// zero-mean x_2 -- one.  Operands (fb_load_gmm's F6 item layout): a lane holds the K places 8 h .. 8 h + 7 of every chunk,
+// as in the f16 fragments, so the frames' side is made from the f16 fragments the lane already has (the kernel's
+// prologue, v_cvt_scalef32_pk32_fp6_f16) and the parameters' side comes from the item's second half in LDS.  MFMAs of a
+// half: block 0 (delta_2 hi) x fq[0] (x_1), block L (delta_2 lo, fp4) x fq[0], block 1 (delta_1 2^-12) x fq[1] (x_2 2^12),
+// block 2 (the dimensions of chunk 4: lanes h = 0, the frames' operand is zero in the others) x fq[2].  The update slices
+// of the pending set are dealt over the 18 gaps as in fb_fxw_step.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int NK, bool UPD>
+__device__ __forceinline__ void fb_fxw_step6(const u32x4 *__restrict__ cur4, const u32x4 *__restrict__ nxt4, const bool pf0,
+                                             int lane, u32x4 &z1, const u32x4 (&b1)[2][NK], const i32x8 (&fq)[2][3],
+                                             const int (&fsc)[2][3], const f32x16 &init0, const f32x16 &init1,
+                                             f32x16 &out0, f32x16 &out1, const f32x16 &p0, const f32x16 &p1,
+                                             float *__restrict__ ps, FbFxwUpd &u, const u32x4 *__restrict__ dsrc, unsigned ddst,
+                                             const int dq0, const int dn) {
+  static_assert(NK == 5, "F6 item layout");
+  constexpr int NM = 2 * NK, NG = NM + 8;  // f16 MFMAs / MFMAs per step
+  constexpr int NS = 20, PD = 2;
+  f32x16 x0 = init0, x1 = init1;
+  u32x4 s1[PD + 1];
+  i32x8 pa[4];  // blocks 0, L, 1, 2 in the order of their MFMAs
+  int psc = 0;
+  float se0 = 0.f, se1 = 0.f, sd0 = 0.f, sd1 = 0.f;
+  float ea0 = 0.f, ea1 = 0.f, eb0 = 0.f, eb1 = 0.f;
+  const unsigned char *ib = reinterpret_cast<const unsigned char *>(cur4);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g < NM) {
+      const int c = g / 2, kk = g % 2;
+      if (kk == 0) {
+#pragma unroll
+        for (int cn = (c == 0 ? 1 : c + PD); cn <= c + PD && cn < NK; ++cn) s1[cn % (PD + 1)] = cur4[cn * 64 + lane];
+        if (c == 0) {
+          const u32x4 lo = *reinterpret_cast<const u32x4 *>(ib + 5120 + lane * 16);
+          const uint2 hi = *reinterpret_cast<const uint2 *>(ib + 6144 + lane * 8);
+          pa[0] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi.x, (int)hi.y, 0, 0};
+          psc = *reinterpret_cast<const int *>(ib + 9984 + lane * 4);
+        } else if (c == 1) {
+          const u32x4 lo = *reinterpret_cast<const u32x4 *>(ib + 8192 + lane * 16);
+          pa[1] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], 0, 0, 0, 0};
+        } else if (c == 2) {
+          const u32x4 lo = *reinterpret_cast<const u32x4 *>(ib + 6656 + lane * 16);
+          const uint2 hi = *reinterpret_cast<const uint2 *>(ib + 7680 + lane * 8);
+          pa[2] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi.x, (int)hi.y, 0, 0};
+        } else if (c == 3) {  // (lanes h = 1 read their component's h = 0 operand: it meets zeros)
+          const u32x4 lo = *reinterpret_cast<const u32x4 *>(ib + 9216 + (lane & 31) * 16);
+          const uint2 hi = *reinterpret_cast<const uint2 *>(ib + 9728 + (lane & 31) * 8);
+          pa[3] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi.x, (int)hi.y, 0, 0};
+        }
+      }
+      const u32x4 &a1 = c == 0 ? z1 : s1[c % (PD + 1)];
+      if (kk == 0) FB_FX_MFMA(a1, b1[0][c], x0);
+      else FB_FX_MFMA(a1, b1[1][c], x1);
+      if (pf0 && g == 3) z1 = nxt4[lane];  // chunk 0's register is free: the next item's chunk 0 (an F6 item again)
+      if (kk == 1 && c < dn) fb_glds16(dsrc + (dq0 + c) * 64, ddst + (unsigned)(dq0 + c) * 1024u);
+    } else {
+      const int blk = (g - NM) / 2, hf = (g - NM) % 2;  // 0: block 0, 1: block L, 2: block 1, 3: block 2
+      const int fb = blk == 0 || blk == 1 ? 0 : blk - 1;  // the frames' operand it meets
+      const int sa = blk == 0 ? psc : (psc >> (blk == 1 ? 16 : (blk == 2 ? 8 : 24)));  // (the instruction takes byte 0)
+      if (blk == 1) {
+        if (hf == 0) x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[1], fq[0][fb], x0, 4, 2, 0, sa, 0, fsc[0][fb]);
+        else x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[1], fq[1][fb], x1, 4, 2, 0, sa, 0, fsc[1][fb]);
+      } else {
+        if (hf == 0) x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[blk], fq[0][fb], x0, 2, 2, 0, sa, 0, fsc[0][fb]);
+        else x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[blk], fq[1][fb], x1, 2, 2, 0, sa, 0, fsc[1][fb]);
+      }
+    }
+    if constexpr (UPD) {  // the slices of fb_fxw_step, four or five instructions per gap
+      const int m0 = (g * 4 * NS) / NG, m1 = ((g + 1) * 4 * NS) / NG;
+#pragma unroll
+      for (int mm = m0; mm < m1; ++mm) {
+        const int sl = mm >> 2, part = mm & 3;
+        const int r = sl - 1, ra = sl - 3;
+        if (part == 0) {
+          if (ra == 0) se0 = ea0;
+          else if (ra == 1) sd0 = ea0;
+          else if (ra >= 2 && ra <= 15 && !(ra & 1)) se0 = fb_v_add(se0, ea0);
+          else if (ra >= 2 && ra <= 15) sd0 = fb_v_add(sd0, ea0);
+        } else if (part == 1) {
+          if (ra == 0) se1 = ea1;
+          else if (ra == 1) sd1 = ea1;
+          else if (ra >= 2 && ra <= 15 && !(ra & 1)) se1 = fb_v_add(se1, ea1);
+          else if (ra >= 2 && ra <= 15) sd1 = fb_v_add(sd1, ea1);
+          ea0 = eb0; ea1 = eb1;
+        } else if (part == 2) {
+          if (sl == 0) { u.so0 = ps[0]; u.so1 = ps[256]; }
+          if (r >= 0 && r <= 15) eb0 = fb_v_exp(p0[r]);
+        } else {
+          if (r >= 0 && r <= 15) eb1 = fb_v_exp(p1[r]);
+          if (sl == NS - 1) {
+            u.sn0 = fb_v_add(fb_v_add(se0, sd0), u.so0);
+            u.sn1 = fb_v_add(fb_v_add(se1, sd1), u.so1);
+            ps[0] = u.sn0; ps[256] = u.sn1;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("" : "+v"(x0), "+v"(x1));
+  out0 = x0;
+  out1 = x1;
+}
+
 template <int NK, int M>
 __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__restrict__ feats,
                                                      const int *__restrict__ n_rows_ptr, int n_chunks,
@@ -524,6 +634,66 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
 #pragma unroll
   for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = rc[m & 1]; st_s[m * 256 + tid] = 0.0f; }
 
+  // ---- the frames' fp6 operands of the F6 tiles (fb_fxw_step6; block layout: fb_load_gmm), from the f16 fragments:
+  //      block 0 = x_1 of the chunks 0 .. 3, block 1 = x_2 of the same places times 2^12 (by the scale alone), block 2 =
+  //      {x_1 of chunk 4, x_2 of chunk 4 times 2^12 (exact: |x_2| <= 8 below the range shift), x_1 of chunk 4 again (for
+  //      delta_2's second term), 8 zeros} in the lanes h = 0, zero in the others.  One scale per
+  //      lane and block: the smallest power of two that brings the block's largest magnitude to <= 7.5.
+  i32x8 fq[2][3];
+  int fsc[2][3];
+  const bool has_f6 = g.delta_t6 > g.delta_t3;
+  if (has_f6) {
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+    typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto convert = [&](const u32x16 &wv, const int extra, i32x8 &out, int &sc) {
+      u16x2 mx = {0, 0};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned av = wv[i] & 0x7fff7fffu;  // |f16| patterns order like unsigned integers
+        mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, av));
+      }
+      const unsigned short top = mx[0] > mx[1] ? mx[0] : mx[1];
+      const float mf = (float)__builtin_bit_cast(_Float16, top);
+      // smallest e with mf 2^-e <= 7.5 (one more where mf / 7.5 is an exact power of two): exponent(mf / 7.5) + 1
+      int byte = (int)((__float_as_uint(__fmul_rn(mf, 0.13333334f)) >> 23) & 0xffu) + 1;
+      byte = byte > 240 ? 240 : byte;  // (inf / NaN frames: their scores are NaN anyway)
+      const auto q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, wv), __uint_as_float((unsigned)byte << 23));
+      out = i32x8{(int)q[0], (int)q[1], (int)q[2], (int)q[3], (int)q[4], (int)q[5], 0, 0};
+      sc = byte + extra;
+    };
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      u32x16 w0, w1, w2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w0[4 * c + u] = bx1[hf][c][u]; w1[4 * c + u] = bx2[hf][c][u]; }
+      const f16x2 k4096 = {(_Float16)4096.0f, (_Float16)4096.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // (lanes h = 1 hold the constants' places there: no dimensions, zeros)
+        const unsigned xu = bx2[hf][NK - 1][u];
+        const f16x2 up2 = __builtin_bit_cast(f16x2, xu) * k4096;
+        w2[u] = h ? 0u : bx1[hf][NK - 1][u];
+        w2[4 + u] = h ? 0u : __builtin_bit_cast(unsigned, up2);
+        w2[8 + u] = w2[u];
+        w2[12 + u] = 0u;
+      }
+      convert(w0, 0, fq[hf][0], fsc[hf][0]);
+      convert(w1, 12, fq[hf][1], fsc[hf][1]);
+      convert(w2, 0, fq[hf][2], fsc[hf][2]);
+    }
+  } else {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { fq[hf][b] = i32x8{0, 0, 0, 0, 0, 0, 0, 0}; fsc[hf][b] = 127; }
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) asm volatile("" : "+a"(fq[hf][b]));  // parked beside the other frame operands
+
   // Component tiles of this chunk: chunk_i, chunk_i + n_chunks, ... (strided, so that every chunk gets the same mix of
   // the tile classes below).  fb_load_gmm stores the components SORTED by how far the other models moved them from
   // the base model (the order is free under logsumexp), so the products per K chunk a delta item needs (P, above
@@ -533,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     const int c = bound > chunk_i ? (bound - chunk_i + n_chunks - 1) / n_chunks : 0;
     return c < n_t ? c : n_t;
   };
-  const int n_p3 = tiles_below(g.delta_t3), n_p32 = tiles_below(g.delta_t2);
+  const int n_p3 = tiles_below(g.delta_t3), n_p36 = tiles_below(g.delta_t6), n_p32 = tiles_below(g.delta_t2);
   const u32x4 *gimg = g.images_fd;
   auto tile_of = [&](int t) { return chunk_i + (t < n_t - 1 ? t : n_t - 1) * n_chunks; };  // (clamped: see srcA below)
 
@@ -666,16 +836,27 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
         settle(acc[(M - 1) & 1][0], acc[(M - 1) & 1][1], pm, ps, rp, uu);
       } else if (jj == 2) {
         float *pm = st_m + tid, *ps = st_s + tid;
-        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], ps, 1.f, 1.f, uu,
-                                 dsrc, ddst, dq0, dn);
+        if constexpr (P == 6)
+          fb_fxw_step6<NK, true>(cur4, nxt4, pf0, lane, z1, bx1, fq, fsc, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], ps, uu, dsrc, ddst, dq0, dn);
+        else
+          fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[1][0], acc[1][1], hq[0], hq[1], ps, 1.f, 1.f, uu,
+                                   dsrc, ddst, dq0, dn);
         settle(hq[0], hq[1], pm, ps, rc, uu);
       } else if (DEFER && jj == NI - 1) {
-        fb_fxw_step<NK, P, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                  zero, zero, st_s, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
+        if constexpr (P == 6)
+          fb_fxw_step6<NK, false>(cur4, nxt4, pf0, lane, z1, bx1, fq, fsc, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                                  zero, zero, st_s, uu, dsrc, ddst, dq0, dn);
+        else
+          fb_fxw_step<NK, P, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                                    zero, zero, st_s, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
       } else {
         float *pm = st_m + (2 * (jj - 2)) * 256 + tid, *ps = st_s + (2 * (jj - 2)) * 256 + tid;
-        fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
-                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], ps, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
+        if constexpr (P == 6)
+          fb_fxw_step6<NK, true>(cur4, nxt4, pf0, lane, z1, bx1, fq, fsc, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                                 acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], ps, uu, dsrc, ddst, dq0, dn);
+        else
+          fb_fxw_step<NK, P, true>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[0], hq[1], acc[(jj - 1) & 1][0], acc[(jj - 1) & 1][1],
+                                   acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], ps, 1.f, 1.f, uu, dsrc, ddst, dq0, dn);
         settle(acc[(jj - 2) & 1][0], acc[(jj - 2) & 1][1], pm, ps, rc, uu);
       }
       if (jj == GA - 1 || jj == NI - 1) publish();
@@ -684,6 +865,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   {
     int t = 0;
     for (; t < n_p3; ++t) tile(std::integral_constant<int, 3>{}, t);
+    for (; t < n_p36; ++t) tile(std::integral_constant<int, 6>{}, t);
     for (; t < n_p32; ++t) tile(std::integral_constant<int, 2>{}, t);
     for (; t < n_t; ++t) tile(std::integral_constant<int, 1>{}, t);
   }

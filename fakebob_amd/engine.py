@@ -151,6 +151,14 @@ class Engine(object):
         return (a.value, b.value, c.value)
 
     @property
+    def gmm_delta_tiles_f6(self):
+        """Tiles of the F6 class (corrections as block-scaled fp6 products, fb_gmm_delta_tiles_f6)."""
+        rc = self._L.fb_gmm_delta_tiles_f6(self._h)
+        if rc < 0:
+            N.check(rc)
+        return rc
+
+    @property
     def gmm_shift_rms(self):
         """fb_load_gmm's measure of how far the models were adapted from model 0 (what P is chosen from)."""
         v = C.c_double()

@@ -32,7 +32,7 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
 int fb_gmm_kernel_mode(fb_engine *e);
 /* The kernel fb_score_* / the NES loop launch for the loaded GMM system: 1 = k_gmm_bx3, 2 = k_gmm_fx2 (any number of
  * variance groups, partial tiles, more than 10 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 10 models: the
- * speaker models are scored as deltas from model 0 with 1 .. 3 partial products per K chunk, chosen by fb_load_gmm PER
+ * speaker models are scored as deltas from model 0 with 1 .. 3 partial products per K chunk (or class 6, below), chosen by fb_load_gmm PER
  * 32-COMPONENT TILE from how far the tile's components were adapted; P = the count most tiles run, *shift_rms
  * (nullable) returns the rms adaptation statistic; FB_GMM_DELTA_P forces one count for every tile; FB_GMM_NARROW=1
  * selects k_gmm_fx2 instead).  Negative FB_E_* without a model. */
@@ -40,6 +40,10 @@ int fb_gmm_kernel_variant(fb_engine *e, double *shift_rms);
 /* k_gmm_fx2w's tile classes for the loaded model: how many component tiles run 1 / 2 / 3 partial products per K chunk
  * in their delta items (all zero, return value 0, when another kernel scores the model; 1 otherwise). */
 int fb_gmm_delta_tiles(fb_engine *e, int *tiles_p1, int *tiles_p2, int *tiles_p3);
+/* ... and how many run the F6 class: the leading f16 product plus the two correction products in block-scaled fp6
+ * (fb_gmm_kernel_variant returns 16 when most tiles do; FB_GMM_DELTA_P=6 forces it for every tile, FB_GMM_DELTA_F6=0
+ * keeps the rule from choosing it).  tiles_p1 + tiles_p2 + tiles_p3 + this = the model's component tiles. */
+int fb_gmm_delta_tiles_f6(fb_engine *e);
 
 /* the GMM kernel the engine scores with, on T rows of D features handed in as they are (no front-end): per-frame
  * log-likelihoods out[m * T + t] of every model (gmm-global-get-frame-likes without --average).  Lets the tests reach

@@ -300,11 +300,12 @@ def test_wide_scoring_kernel_single_tile_chunks(oracle, monkeypatch, n_speakers,
     assert np.abs(raw_g - raw_o).max() <= 2e-5
 
 
-@pytest.mark.parametrize("delta_p", [1, 2, 3])
+@pytest.mark.parametrize("delta_p", [1, 2, 3, 6])
 @pytest.mark.parametrize("n_speakers", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_wide_scoring_kernel_every_model_count(oracle, monkeypatch, n_speakers, delta_p):
     """k_gmm_fx2w is instantiated per model count M = 2 .. 10 (SV: UBM + 1; OSI: UBM + up to 9 speakers) and per number of
-    partial products of the delta items: each instantiation has its own LDS slot split, LDS-DMA piece schedule,
+    partial products of the delta items (6: the F6 class, the corrections as block-scaled fp6 / fp4 products): each
+    instantiation has its own LDS slot split, LDS-DMA piece schedule,
     accumulator rotation and update-slice schedule.  Several component chunks per strip (C = 1024 -> tiles streamed
     through both slots many times), a ragged last strip, against the oracle and against the general kernel on the
     same inputs."""
@@ -409,7 +410,7 @@ def test_wide_kernel_reference_rescue_and_range_paths(monkeypatch):
     huge = rng.standard_normal((130, D)) * np.logspace(3, 4, 130)[:, None]  # |x| sd^-1 > 181: the range shift
     rows = np.concatenate([near, far, np.zeros((7, D)), onefar, huge, near[:50]]).astype(np.float32)
     want = _frame_lls(models, rows)
-    for P in ("1", "2", "3"):
+    for P in ("1", "2", "3", "6"):
         monkeypatch.setenv("FB_GMM_DELTA_P", P)
         e = Engine(0)
         try:

@@ -29,7 +29,7 @@ def _pair(oracle, full_system, over):
     return e, ctx
 
 
-@pytest.mark.parametrize("delta_p", ["", "3"])
+@pytest.mark.parametrize("delta_p", ["", "3", "6"])
 def test_config1_get_grad_and_attack_at_full_size(oracle, full_system, monkeypatch, delta_p):
     """What can and cannot be promised at N = 48 000, spd = 50.  Scores, losses and the gradient estimate agree with
     the float64-accumulating oracle to ~3e-6 / 1e-3 (gradient rms 0.22).  The update is sign(momentum gradient)
