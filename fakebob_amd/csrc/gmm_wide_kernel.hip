@@ -337,7 +337,7 @@ __device__ __forceinline__ void fb_fxw_step6(const u32x4 *__restrict__ cur4, con
   f32x16 x0 = init0, x1 = init1;
   u32x4 s1[PD + 1];
   i32x8 pa[4];  // blocks 0, L, 1, 2 in the order of their MFMAs
-  int psc = 0;
+  int psc = 0, psh[4] = {0, 0, 0, 0};  // the lane's four scale bytes; each one in byte 0 (what the instruction takes)
   float se0 = 0.f, se1 = 0.f, sd0 = 0.f, sd1 = 0.f;
   float ea0 = 0.f, ea1 = 0.f, eb0 = 0.f, eb1 = 0.f;
   const unsigned char *ib = reinterpret_cast<const unsigned char *>(cur4);
@@ -364,6 +364,8 @@ __device__ __forceinline__ void fb_fxw_step6(const u32x4 *__restrict__ cur4, con
           const u32x4 lo = *reinterpret_cast<const u32x4 *>(ib + 9216 + (lane & 31) * 16);
           const uint2 hi = *reinterpret_cast<const uint2 *>(ib + 9728 + (lane & 31) * 8);
           pa[3] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi.x, (int)hi.y, 0, 0};
+        } else {  // (well ahead of the MFMAs that read them: no hazard wait states)
+          psh[0] = psc; psh[1] = psc >> 16; psh[2] = psc >> 8; psh[3] = psc >> 24;
         }
       }
       const u32x4 &a1 = c == 0 ? z1 : s1[c % (PD + 1)];
@@ -374,7 +376,7 @@ __device__ __forceinline__ void fb_fxw_step6(const u32x4 *__restrict__ cur4, con
     } else {
       const int blk = (g - NM) / 2, hf = (g - NM) % 2;  // 0: block 0, 1: block L, 2: block 1, 3: block 2
       const int fb = blk == 0 || blk == 1 ? 0 : blk - 1;  // the frames' operand it meets
-      const int sa = blk == 0 ? psc : (psc >> (blk == 1 ? 16 : (blk == 2 ? 8 : 24)));  // (the instruction takes byte 0)
+      const int sa = psh[blk];
       if (blk == 1) {
         if (hf == 0) x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[1], fq[0][fb], x0, 4, 2, 0, sa, 0, fsc[0][fb]);
         else x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa[1], fq[1][fb], x1, 4, 2, 0, sa, 0, fsc[1][fb]);

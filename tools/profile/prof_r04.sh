@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 profile set on the GPU box: rocprofv3 kernel-trace stats of the bench commands (GMM headline with 1 / 3
-# attacks in flight, three products forced, realistic enrolment, the reference-pipeline mode, GMM CSI, i-vector SV
+# attacks in flight, three products / the F6 class forced, realistic enrolment, the reference-pipeline mode, GMM CSI, i-vector SV
 # spd=50 and OSI spd=200), the HBM-traffic PMC passes (separate runs, --kernel-trace only, one counter group per pass)
 # and the default bench lines.  traffic.json records the hash of the kernel sources it was taken on: bench.py reports
 # roofline.traffic only while that hash is the build's (bench.kernel_source_hash()).
@@ -16,6 +16,7 @@ prof() {  # name, bench args...
 prof gmm_1attack --steps 100 --warmup 10 --streams 1
 prof gmm_3attacks --steps 100 --warmup 10
 FB_GMM_DELTA_P=3 prof gmm_p3_1attack --steps 100 --warmup 10 --streams 1
+FB_GMM_DELTA_P=6 prof gmm_f6_1attack --steps 100 --warmup 10 --streams 1
 prof gmm_realistic_1attack --steps 100 --warmup 10 --streams 1 --enrol realistic
 prof gmm_faithful_1attack --steps 100 --warmup 10 --streams 1 --faithful
 prof gmm_csi_1attack --steps 100 --warmup 10 --streams 1 --task CSI
