@@ -56,6 +56,36 @@ def test_frontend_and_scores_for_other_configs(oracle, over):
         e.close()
 
 
+@pytest.mark.parametrize("over", FRONTENDS[-2:] + [dict()])
+def test_f6_class_with_other_feature_dimensions(oracle, monkeypatch, over):
+    """The F6 items' block 2 holds the dimensions 64 .. D - 1 (eight of them at D = 72, four at 68, none at 64): heavily
+    enrolled speakers (the corrections matter: one product alone is an order of magnitude off) with the class forced
+    in every tile, against the oracle and against three f16 products."""
+    from fakebob_amd.models import ENROL_REALISTIC
+    cfg = oracle.default_cfg(**over)
+    err = {}
+    for p in ("6", "3", "1"):
+        monkeypatch.setenv("FB_GMM_DELTA_P", p)
+        e = Engine(0)
+        try:
+            e.set_frontend(**over)
+            D = e.feat_dim
+            ubm, spk = synthetic_gmm_system(n_speakers=3, C=256, D=D, **ENROL_REALISTIC)
+            e.load_gmm([ubm] + spk)
+            assert e.gmm_kernel_variant == "fx2w/" + p
+            wavs = [_wav(0, 24000), _wav(1, 9000), _wav(2, 40000), _wav(3, 48000)]
+            raw_g, tv_g = e.score_raw(wavs)
+        finally:
+            e.close()
+        gc, miv, iv = stack_models([ubm] + spk)
+        raw_o, tv_o = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=4)
+        assert np.array_equal(tv_g, tv_o)
+        err[p] = float(np.abs(raw_g - raw_o).max())
+    print("D = %d: max |err| F6 %.3g, three products %.3g, one product %.3g" % (D, err["6"], err["3"], err["1"]))
+    assert D == {0: 72, 1: 72}.get(len(over), 68 if over.get("num_ceps") == 17 else 64)
+    assert err["3"] <= SCORE_TOL and err["6"] <= 1e-5 + err["3"] and err["1"] > 3.0 * err["6"]
+
+
 @pytest.mark.parametrize("mode,env", [("bx3", {"FB_GMM_MODE": "bx3"}), ("fx2", {"FB_GMM_NARROW": "1"})])
 def test_other_gmm_kernels_still_match(oracle, monkeypatch, mode, env):
     """The default scoring kernel is k_gmm_fx2w; the general two-term kernel (k_gmm_fx2: any number of variance
