@@ -804,24 +804,45 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
 #define FB_RW_G 5
 size_t fb_iv_solve_rw_linv_doubles(const FbIvDev &iv, int B) { return (size_t)2 * B * ((iv.R + 31) / 32) * 1024; }
 size_t fb_iv_solve_rw_prog_words(const FbIvDev &iv, int B) { return (size_t)B * ((iv.R + 1 + 31) / 32 + 1); }
+template <int G>
+static bool launch_solve_rw(hipStream_t s, size_t shm, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
+                            int B, double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket,
+                            unsigned epoch) {
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (fb_device_needs_optin(optin, &bit)) {  // one workgroup per compute unit: more than half of its LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_rw<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+      return false;
+    optin.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(k_iv_solve_rw<G>, dim3(B * G), dim3(512), std::max(shm, (size_t)82 * 1024), s, iv,
+                     const_cast<double *>(quad), linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+  return true;
+}
+// workgroups per matrix: FB_RW_G, fewer when B x FB_RW_G workgroups would not be resident at once (FB_IV_RW_G = 2 | 3 | 5
+// chooses for A/B runs)
+int fb_iv_solve_rw_groups(int B) {
+  int g = FB_RW_G;
+  if (const char *ev = getenv("FB_IV_RW_G")) {
+    const int v = atoi(ev);
+    if (v == 2 || v == 3 || v == 5) g = v;
+  }
+  while (g > 2 && B * g > 256) g = g == 5 ? 3 : 2;
+  return g;
+}
 bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks, int B,
                            double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch) {
-  const int R = iv.R;
-  if (B * FB_RW_G > 256 || R < 64) return false;
+  const int R = iv.R, G = fb_iv_solve_rw_groups(B);
+  if (B * G > 256 || R < 64) return false;
   const int npanel = (R + FB_SV_NB - 1) / FB_SV_NB;
   const size_t rowd = (size_t)FB_SV_NB * (FB_SV_NB * npanel + 2), bsd = ((R + 1) & ~1) + FB_SV_NB + 16 * FB_SV_LD;
   const size_t shm = sizeof(double) * (std::max(rowd, bsd) + FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17);
   if (shm > 150 * 1024 || R > 448) return false;
-  static std::atomic<unsigned long long> optin{0};
-  unsigned long long bit = 0;
-  if (fb_device_needs_optin(optin, &bit)) {  // one workgroup per compute unit: more than half of its LDS
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iv_solve_rw<FB_RW_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-      return false;
-    optin.fetch_or(bit, std::memory_order_release);
+  switch (G) {
+    case 2: return launch_solve_rw<2>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+    case 3: return launch_solve_rw<3>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+    default: return launch_solve_rw<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
   }
-  hipLaunchKernelGGL(k_iv_solve_rw<FB_RW_G>, dim3(B * FB_RW_G), dim3(512), std::max(shm, (size_t)82 * 1024), s, iv,
-                     const_cast<double *>(quad), linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
-  return true;
 }
 
 template <int NTR>

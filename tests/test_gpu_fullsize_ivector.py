@@ -128,8 +128,10 @@ def test_full_size_osi_get_grad_spd200_b201(oracle):
         e.close()
 
 
-def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypatch):
-    """k_iv_solve_rw (round 4: the block rows of a posterior system dealt over five workgroups, cross-workgroup exchange
+@pytest.mark.parametrize("groups", ["5", "3", "2"])
+def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypatch, groups):
+    """k_iv_solve_rw (round 4: the block rows of a posterior system dealt over five workgroups -- three or two when a
+    larger batch would not leave all of them resident, forced here through FB_IV_RW_G --, cross-workgroup exchange
     through agent-scope stores, progress words and sentinel-polled inverse factors) against k_iv_solve_ll (one workgroup
     per matrix) and the oracle at the benchmarked size (C = 2048, R = 400), over REPEATED launches (the slot sets
     alternate with the launch epoch), a batch of 51 and one of 3, and a switch between the kernels on one engine (the slot
@@ -140,6 +142,7 @@ def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypat
     wavs51 = [_wav(u % 7, 30000 + 997 * (u % 5)) for u in range(51)]
     wavs3 = wavs51[:3]
     llr_o, ivs_o, tv_o = ctx.score_batch(wavs51)
+    monkeypatch.setenv("FB_IV_RW_G", groups)
     e = Engine(0)
     try:
         e.load_ivector(sy, "OSI")
@@ -162,4 +165,5 @@ def test_row_wise_solve_kernel_equals_the_one_workgroup_kernel(oracle, monkeypat
         assert d <= 1e-10
     finally:
         monkeypatch.delenv("FB_IV_SOLVE", raising=False)
+        monkeypatch.delenv("FB_IV_RW_G", raising=False)
         e.close()
