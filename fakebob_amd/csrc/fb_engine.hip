@@ -94,7 +94,7 @@ struct fb_engine {
   int kind = 0;   // 0 = GMM-UBM, 1 = i-vector/PLDA
   int n_out = 0;  // columns of `raw`: models (GMM) or enrolled speakers (i-vector)
   FbIvDev iv;
-  DevBuf iv_fg, iv_fg64, iv_tri, iv_sim, iv_u, iv_backend;
+  DevBuf iv_fg, iv_fg64, iv_fgL, iv_tri, iv_sim, iv_u, iv_backend;
   DevBuf iv_ll, iv_sel, iv_post, iv_gamma, iv_X, iv_linp, iv_quad, iv_A, iv_linv, iv_ivec, iv_fail, iv_active, iv_bws, iv_pairs, iv_llf;
   int iv_kchunks = 96;
   int iv_Bpad = 0;  // padding of the transposed statistics currently zero-initialised
@@ -235,7 +235,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   DevBuf *bufs[] = {&e->fe_tables, &e->fe_tables32, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
-                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_tri,
+                    &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
                     &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
@@ -1567,6 +1567,91 @@ extern "C" int fb_load_ivector(fb_engine *e, const fb_ivector_system *sy, int ta
       FBCHK(e->iv_fg64.ensure(sizeof(double) * f64.size()));
       HIPCHK(hipMemcpy(e->iv_fg64.p, f64.data(), sizeof(double) * f64.size(), hipMemcpyHostToDevice));
       e->iv.fg64 = e->iv_fg64.as<double>();
+    }
+    e->iv.fgL = nullptr;
+    if (D == 72) {
+      // Cholesky image of the same function for k_iv_fullcov_mfma (ivector_kernels.hip): with P = L L' and any mu,
+      //   gconst + mic . x - 1/2 x'Px = [gconst + 1/2 mu'P mu] + (mic - P mu) . x - 1/2 |L'(x - mu)|^2;
+      // mu = P^-1 mic refined in long double until the residual's term is far below the float64 rounding of the
+      // rest (it is then dropped); L from a long double factorisation of the float32 parameters as they are, rounded
+      // once.  A component whose residual cannot be brought down keeps the whole batch on the triangle-form kernel.
+      const int NFR = 50, REC = NFR * 64 + 72 + 2;
+      std::vector<double> rec((size_t)C * REC, 0.0);
+      std::vector<long double> Pm((size_t)D * D), Lm((size_t)D * D), mu(D), rs(D), dx(D);
+      bool ok = true;
+      for (int c = 0; c < C && ok; ++c) {
+        const float *P = sy->fg_inv_covars + (size_t)c * triD;
+        const float *mic = sy->fg_means_invcovars + (size_t)c * D;
+        for (int r = 0, idx = 0; r < D; ++r)
+          for (int cc = 0; cc <= r; ++cc, ++idx) Pm[(size_t)r * D + cc] = Pm[(size_t)cc * D + r] = (long double)P[idx];
+        std::fill(Lm.begin(), Lm.end(), 0.0L);
+        for (int j = 0; j < D && ok; ++j) {
+          long double d = Pm[(size_t)j * D + j];
+          for (int q = 0; q < j; ++q) d -= Lm[(size_t)j * D + q] * Lm[(size_t)j * D + q];
+          if (!(d > 0.0L)) { ok = false; break; }
+          const long double lj = sqrtl(d);
+          Lm[(size_t)j * D + j] = lj;
+          for (int i = j + 1; i < D; ++i) {
+            long double v = Pm[(size_t)i * D + j];
+            for (int q = 0; q < j; ++q) v -= Lm[(size_t)i * D + q] * Lm[(size_t)j * D + q];
+            Lm[(size_t)i * D + j] = v / lj;
+          }
+        }
+        if (!ok) break;
+        auto solve = [&](std::vector<long double> &b) {  // b <- P^-1 b through L
+          for (int i = 0; i < D; ++i) {
+            long double v = b[i];
+            for (int q = 0; q < i; ++q) v -= Lm[(size_t)i * D + q] * b[q];
+            b[i] = v / Lm[(size_t)i * D + i];
+          }
+          for (int i = D - 1; i >= 0; --i) {
+            long double v = b[i];
+            for (int q = i + 1; q < D; ++q) v -= Lm[(size_t)q * D + i] * b[q];
+            b[i] = v / Lm[(size_t)i * D + i];
+          }
+        };
+        for (int d = 0; d < D; ++d) mu[d] = (long double)mic[d];
+        solve(mu);
+        double *o = &rec[(size_t)c * REC];
+        long double res_term = 0.0L;
+        for (int it = 0; it < 4; ++it) {
+          // the kernel uses mu rounded to float64: refine THAT vector's residual
+          long double mx = 0.0L, sc = 0.0L;
+          for (int i = 0; i < D; ++i) {
+            long double v = (long double)mic[i];
+            for (int q = 0; q < D; ++q) v -= Pm[(size_t)i * D + q] * (long double)(double)mu[q];
+            rs[i] = v;
+            mx = std::max(mx, fabsl(v));
+            sc = std::max(sc, fabsl((long double)mic[i]));
+          }
+          res_term = mx / (sc > 0.0L ? sc : 1.0L);
+          if (it == 3) break;
+          dx = rs;
+          solve(dx);
+          for (int i = 0; i < D; ++i) mu[i] = (long double)(double)mu[i] + dx[i];
+        }
+        // (mic - P mu) . x relative to mic . x: float64 rounding of mu leaves ~1e-16 kappa; the term is dropped, so it has
+        // to be invisible next to the 1e-13 the float64 sums themselves carry
+        if (!(res_term < 1.0e-11L)) { ok = false; break; }
+        long double q2 = 0.0L;
+        for (int i = 0; i < D; ++i)
+          for (int q = 0; q < D; ++q) q2 += (long double)(double)mu[i] * Pm[(size_t)i * D + q] * (long double)(double)mu[q];
+        int f = 0;
+        for (int jt = 0; jt < 5; ++jt)
+          for (int s2 = 4 * jt; s2 < D / 4; ++s2, ++f)
+            for (int l = 0; l < 64; ++l) {
+              const int q = l >> 4;  // the kernel's K order: a lane's four places of a 16-row block are consecutive rows
+              const int row = s2 < 16 ? 16 * (s2 / 4) + 4 * q + (s2 % 4) : 64 + 2 * q + (s2 - 16), col = 16 * jt + (l & 15);
+              o[(size_t)f * 64 + l] = (col <= row && col < D) ? (double)Lm[(size_t)row * D + col] : 0.0;
+            }
+        for (int d = 0; d < D; ++d) o[(size_t)NFR * 64 + d] = (double)mu[d];
+        o[(size_t)NFR * 64 + D] = (double)((long double)fg_gc[c] + 0.5L * q2);
+      }
+      if (ok) {
+        FBCHK(e->iv_fgL.ensure(sizeof(double) * rec.size()));
+        HIPCHK(hipMemcpy(e->iv_fgL.p, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+        e->iv.fgL = e->iv_fgL.as<double>();
+      }
     }
     e->iv.tri_r = e->iv_tri.as<unsigned char>(); e->iv.tri_c = e->iv.tri_r + triD;
   }

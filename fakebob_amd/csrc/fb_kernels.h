@@ -232,6 +232,7 @@ struct FbIvDev {
   const float *fg_P;            // [C][triD] inv_covars, packed lower-triangular
   const double *fg64;           // [C][triD + D + 1] float64 image for k_iv_fullcov_t: P with the diagonal halved,
                                 //   then means_invcovars, then gconst
+  const double *fgL;            // [C][FB_FCM_REC] (D = 72; else null): Cholesky image for k_iv_fullcov_mfma (ivector_kernels.hip)
   const unsigned char *tri_r, *tri_c;  // [triD] row / column of packed element e
   const double *sim;            // [C*D][R] Sigma^-1 M
   const double *u;              // [C][triR]

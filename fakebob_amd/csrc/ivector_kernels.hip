@@ -427,6 +427,131 @@ __global__ __launch_bounds__(FB_IV_CH) void k_iv_fullcov_lds(FbIvDev iv, const f
   if (ok) llf[pr] = (float)(sP[TRI + D] + (lin - half_quad));
 }
 
+// The same log-likelihoods on the float64 matrix cores (round 4).  With P = L L' (Cholesky, fb_load_ivector) and
+// mu = P^-1 means_invcovars the record's function gconst + means_invcovars . x - 1/2 x'Px is
+//     gc'' - 1/2 |L'(x - mu)|^2,        gc'' = gconst + 1/2 mu'P mu
+// (an identity for any mu up to the term (means_invcovars - P mu) . x, which the host drives below 1e-18 by refining
+// mu in long double), so a bucket's pairs are ONE product Y = (X - 1 mu') L with the lower-triangular L, followed by
+// row sums of squares: v_mfma_f64_16x16x4_f64 tiles of 16 pairs x 16 columns, K = 4 rows of L per instruction, and
+// only the K steps at or below the tile's diagonal -- 18 + 14 + 10 + 6 + 2 = 50 instructions per 16 pairs (102 kflop
+// against the 2 700 fma = 5.4 kflop per pair of the triangle form: 1.2 x the arithmetic, none of its 1 300 LDS broadcasts
+// per wave).  Workgroup = (component, chunk of 256 pairs) as before, wave = 64 pairs = four row tiles that share every
+// fragment of L (read once per wave from the record staged in LDS); a lane holds element (pair l & 15, K place l >> 4)
+// of its tiles' A operands -- its pair's features minus mu, 18 values per tile, gathered straight from the feature rows
+// -- and 4 results per tile, squared and added as the column tiles finish; the 16 lanes of a K place are summed at the
+// end.  Record (fgL, per component): 50 fragments x 64 lanes (fragment (jt, s), s >= 4 jt: lane -> L[row(s, l >> 4)][16 jt +
+// (l & 15)] with the kernel's K order row(s, q) = 16 (s / 4) + 4 q + s % 4 (64 + 2 q + s - 16 for s >= 16), zero above the
+// diagonal and past D), then mu[72], then gc''.
+#define FB_FCM_NFRAG 50
+#define FB_FCM_REC (FB_FCM_NFRAG * 64 + 72 + 2)
+// A wave takes NRT row tiles of 16 pairs (the workgroup's FB_IV_CH pairs over FB_IV_CH / (16 NRT) waves): NRT = 1 keeps
+// the wave under 128 registers -- four or more waves per SIMD, which is what hides the record's copy, the pair -> feature
+// row round trips and the matrix pipe's latency behind one another (four tiles per wave, 340 registers, one wave per
+// SIMD: 116 us against the triangle form's 95; two tiles: 69; one: 60.5 -- measured).
+__device__ __forceinline__ int fb_wave_lower_bound(const int *__restrict__ a, int lo, int hi, int key, int lane);
+template <int NRT>
+__global__ __launch_bounds__(FB_IV_CH * 4 / NRT) __attribute__((amdgpu_waves_per_eu(NRT == 1 ? 8 : 3, 8))) void k_iv_fullcov_mfma(FbIvDev iv, const float *__restrict__ feats,
+                                                                       const int *__restrict__ bstart,
+                                                                       const int *__restrict__ wstart,
+                                                                       const int *__restrict__ pairs, float *__restrict__ llf) {
+  constexpr int D = 72, NS = D / 4, NT = FB_IV_CH * 4 / NRT;
+  __shared__ __attribute__((aligned(16))) double sL[FB_FCM_REC];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = blockIdx.x;
+  if (wi >= wstart[iv.C]) return;
+  // the component of this work item: the last k with wstart[k] <= wi (two rounds of 64 probes; empty buckets repeat
+  // their successor's start and are skipped by "last")
+  const int k = __builtin_amdgcn_readfirstlane(fb_wave_lower_bound(wstart, 0, iv.C + 1, wi + 1, lane)) - 1;
+  const int b0 = __builtin_amdgcn_readfirstlane(bstart[k]), b1 = __builtin_amdgcn_readfirstlane(bstart[k + 1]);
+  const int c0 = b0 + (wi - __builtin_amdgcn_readfirstlane(wstart[k])) * FB_IV_CH;  // the chunk's first pair
+  const int e0 = c0 + 16 * NRT * w, e1 = min(b1, c0 + FB_IV_CH);
+  const bool any = e0 < e1;  // (a scalar)
+  // the pairs' feature values first (two dependent global round trips), the record's copy behind them
+  const int li = lane & 15, kq = lane >> 4;
+  int pr[NRT];
+  float xf[NRT][NS];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int p = e0 + 16 * rt + li;
+    pr[rt] = any ? pairs[p < e1 ? p : e0] : 0;
+  }
+  // K place (step s2, l >> 4) = dimension 16 (s2 / 4) + 4 (l >> 4) + s2 % 4 (64 + 2 (l >> 4) + s2 - 16 for the last two steps):
+  // the order within a 16-row block of L is free, and this one makes a lane's values of a block ONE 16-byte piece of its
+  // pair's feature row (five loads per tile instead of eighteen, whole 64-byte sectors per row)
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const float *fr = feats + (size_t)(pr[rt] / iv.nsel) * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 v = any ? *reinterpret_cast<const float4 *>(fr + 16 * b + 4 * kq) : float4{0.f, 0.f, 0.f, 0.f};
+      xf[rt][4 * b] = v.x; xf[rt][4 * b + 1] = v.y; xf[rt][4 * b + 2] = v.z; xf[rt][4 * b + 3] = v.w;
+    }
+    const float2 v2 = any ? *reinterpret_cast<const float2 *>(fr + 64 + 2 * kq) : float2{0.f, 0.f};
+    xf[rt][16] = v2.x; xf[rt][17] = v2.y;
+  }
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(iv.fgL + (size_t)k * FB_FCM_REC);
+    double2 *dst = reinterpret_cast<double2 *>(sL);
+    constexpr int NCP = (FB_FCM_REC / 2 + NT - 1) / NT;  // every load of the copy in flight before the first store
+    double2 tmp[NCP];
+#pragma unroll
+    for (int j = 0; j < NCP; ++j) {
+      const int i = (int)threadIdx.x + j * NT;
+      tmp[j] = src[i < FB_FCM_REC / 2 ? i : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NCP; ++j) {
+      const int i = (int)threadIdx.x + j * NT;
+      if (i < FB_FCM_REC / 2) dst[i] = tmp[j];
+    }
+  }
+  __syncthreads();
+  if (!any) return;
+  const double *mu = sL + FB_FCM_NFRAG * 64;
+  double a[NRT][NS];
+#pragma unroll
+  for (int s2 = 0; s2 < NS; ++s2) {
+    const double m = mu[s2 < 16 ? 16 * (s2 / 4) + 4 * kq + (s2 % 4) : 64 + 2 * kq + (s2 - 16)];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) a[rt][s2] = (double)xf[rt][s2] - m;
+  }
+  double acc[NRT][4];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[rt][r] = 0.0;
+  int f = 0;
+#pragma unroll
+  for (int jt = 0; jt < 5; ++jt) {
+    fb_d4 c[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) c[rt] = fb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 4 * jt; s2 < NS; ++s2, ++f) {
+      const double b = sL[f * 64 + lane];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) c[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt][s2], b, c[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rt][r] = fma(c[rt][r], c[rt][r], acc[rt][r]);
+  }
+  const double gc2 = sL[FB_FCM_NFRAG * 64 + D];
+  // a result register holds (pair (l >> 4) + 4 r of the tile, column l & 15): sum the 16 columns of a K-place group
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = acc[rt][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int i = kq + 4 * r;                       // the pair of the tile this lane group's register r belongs to
+      const int pri = __shfl(pr[rt], i, 64);          // (lane i, K place 0, holds that pair's index)
+      if (li == 0 && e0 + 16 * rt + i < e1) llf[pri] = (float)(gc2 - 0.5 * v);
+    }
+}
+
 // softmax over the nsel full-covariance log-likelihoods of a frame + min-post pruning: lane = slot
 __global__ __launch_bounds__(256) void k_iv_post(FbIvDev iv, const int *__restrict__ n_rows_ptr,
                                                  const int *__restrict__ sel, const float *__restrict__ llf,
@@ -494,7 +619,11 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   hipLaunchKernelGGL(k_iv_bucket_fill, dim3(n_blk), dim3(64), lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
   const int n_pairs_cap = rows_cap * iv.nsel;
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
-  if (iv.D == 72)
+  const char *fc_env = getenv("FB_IV_FULLCOV");  // "lds": the triangle-form kernel (A/B runs, tests); read per launch
+  const bool fc_lds = fc_env && strcmp(fc_env, "lds") == 0;
+  if (iv.D == 72 && iv.fgL && !fc_lds)
+    hipLaunchKernelGGL(k_iv_fullcov_mfma<1>, dim3(work_cap), dim3(FB_IV_CH * 4), 0, s, iv, feats, bstart, wstart, pairs, llf);
+  else if (iv.D == 72)
     hipLaunchKernelGGL((k_iv_fullcov_lds<72>), dim3(work_cap), dim3(FB_IV_CH), 0, s, iv, feats, bstart, wstart, pairs, llf);
   else if (iv.triD <= 42 * 64)
     hipLaunchKernelGGL((k_iv_fullcov<42>), dim3(work_cap), dim3(256), 0, s, iv, feats, bstart, wstart, pairs, llf);

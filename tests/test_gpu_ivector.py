@@ -46,6 +46,38 @@ def test_ivector_larger_system(engine, oracle):
     assert np.abs(llr_g - llr_o).max() <= SCORE_TOL
 
 
+def test_full_covariance_kernels_agree(engine, oracle, monkeypatch):
+    """k_iv_fullcov_mfma (round 4: a bucket's pairs as ONE product with the Cholesky factor of the precision matrix on the
+    float64 matrix cores, then row sums of squares) against k_iv_fullcov_lds (the triangle form, thread = pair,
+    FB_IV_FULLCOV=lds) and the oracle: the same posteriors up to float64 rounding, so the same i-vectors to 1e-9 --
+    with buckets of every fill (C = 256 components over 4 utterances of different lengths: empty ones, tails of a few
+    pairs, full 128-pair chunks)."""
+    sy = synthetic_ivector_system(C=256, D=72, R=100, L=50, n_speakers=2, seed=5)
+    engine.load_ivector(sy, "CSI")
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=8)
+    wavs = [_wav(0), _wav(1, 9000), _wav(2, 30000), _wav(3, 1700)]
+    llr_o, ivs_o, tv_o = ctx.score_batch(wavs)
+    out = {}
+    for name in ("mfma", "lds", "mfma"):
+        if name == "lds":
+            monkeypatch.setenv("FB_IV_FULLCOV", "lds")
+        else:
+            monkeypatch.delenv("FB_IV_FULLCOV", raising=False)
+        llr, tv = engine.score_raw(wavs)
+        out.setdefault(name, []).append((llr, engine.debug_ivectors(len(wavs), sy.R)))
+        assert np.array_equal(tv, tv_o)
+    monkeypatch.delenv("FB_IV_FULLCOV", raising=False)
+    scale = max(1.0, np.abs(ivs_o).max())
+    for name, runs in out.items():
+        for llr, ivs in runs:
+            assert np.abs(ivs - ivs_o).max() <= 1e-9 * scale, name
+            assert np.abs(llr - llr_o).max() <= 1e-7, name
+    assert np.array_equal(out["mfma"][0][1], out["mfma"][1][1])          # deterministic
+    d = np.abs(out["mfma"][0][1] - out["lds"][0][1]).max()
+    print("matrix-core against triangle-form full-covariance kernel: max |i-vector difference| %.3g" % d)
+    assert d <= 1e-9 * scale
+
+
 @pytest.mark.parametrize("task,attack,kw", [
     ("OSI", "targeted", dict(target=1, threshold=0.5)),
     ("SV", "targeted", dict(threshold=0.1)),
