@@ -87,7 +87,7 @@ struct fb_engine {
   // gmm
   bool have_gmm = false;
   FbGmmDev gmm;
-  DevBuf gmm_items, gmm_images_bx, gmm_images_fx, gmm_images_fd, gmm_anchor;
+  DevBuf gmm_items, gmm_images_bx, gmm_images_fx, gmm_images_fd, gmm_images_fd2, gmm_images_fd3, gmm_anchor;  // (fd, fd2, fd3: the delta images of k_gmm_fx2w's passes)
   double gmm_delta_rms = 0.0;  // fb_load_gmm's shift statistic behind gmm.delta_p
   int n_groups = 0;
   // i-vector system (kind == 1): the diagonalised UBM lives in `gmm` (M = 1)
@@ -232,7 +232,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   if (!e) return FB_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->fe_tables, &e->fe_tables32, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
+  DevBuf *bufs[] = {&e->fe_tables, &e->fe_tables32, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_images_fd2, &e->gmm_images_fd3, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
                     &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
@@ -449,18 +449,24 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   // Needs every parameter inside f16's range; a model that does not fit runs on the bf16x3 kernel.
   const int NKF = (D + 1 + 15) / 16 < 2 ? 2 : (D + 1 + 15) / 16;  // instantiated for 2..6
   int kx = 0, kx2 = 0, kacc = 0, kl = 0, kq = 0, delta_p = 0, delta_t3 = 0, delta_t2 = 0, delta_t6 = 0;
+  int n_pass = 0, pass_lo[FB_FXW_MAX_PASS + 1] = {1, 1, 1, 1};
   e->gmm_delta_rms = 0.0;
   // k_gmm_fx2w scores the models of ONE variance group as deltas from model 0 (the UBM for OSI / SV, the first
   // speaker for CSI): delta images are built when the kernel's shape conditions hold (fb_gmm_use_wide)
-  if (G == 1 && M > FB_FXW_MAX_M && (C & 31) == 0) {
+  // More than FB_FXW_MAX_M models (the LDS holds a tile of 1 + M items and the state of M models) run as SEVERAL
+  // PASSES of the kernel: pass p scores the base model again and its share of the others (FB_FXW_MAX_PASS passes of up
+  // to FB_FXW_MAX_M - 1 delta models each); beyond that the general kernel takes over
+  const int max_wide_models = 1 + (FB_FXW_MAX_M - 1) * FB_FXW_MAX_PASS;
+  if (G == 1 && M > max_wide_models && (C & 31) == 0) {
     static bool warned = false;
     if (!warned) {
       warned = true;
-      fprintf(stderr, "[fakebob_hip] note: %d models in one variance group: k_gmm_fx2w takes at most %d (LDS), this system is "
-                      "scored by the general kernel k_gmm_fx2 (about twice the time per model)\n", M, FB_FXW_MAX_M);
+      fprintf(stderr, "[fakebob_hip] note: %d models in one variance group: k_gmm_fx2w takes at most %d (in %d passes), this "
+                      "system is scored by the general kernel k_gmm_fx2 (about twice the time per model)\n", M, max_wide_models,
+              FB_FXW_MAX_PASS);
     }
   }
-  const bool want_delta = G == 1 && M >= 2 && M <= FB_FXW_MAX_M && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
+  const bool want_delta = G == 1 && M >= 2 && M <= max_wide_models && (C & 31) == 0 && NKF == 5 && D + 5 <= 16 * NKF && (D & 3) == 0;  // (K places for the constants' three terms and the frames' reference)
   if (mode == FB_GMM_MODE_FX2) {
     const float lim = 32768.0f;
     float max_q = 0.0f, max_l = 0.0f, max_g = 0.0f;
@@ -698,12 +704,17 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
         fits = fits && ldexp(L2E * pl, -kd[k]) < 60000.0 && ldexp(L2E * pq, -kq[k]) < 60000.0;
       }
       for (int c = 0; c < M * C; ++c) fits = fits && L2E * fabs((double)gconsts[c]) < 60000.0;
-      if (fits) {  // (k_gmm_fx2 scores a model that does not)
-        std::vector<uint16_t> fd((size_t)n_tiles * n_items * per_item, 0);
+      // passes: the M - 1 delta models dealt evenly over ceil((M - 1) / (FB_FXW_MAX_M - 1)) launches
+      n_pass = (M - 1 + FB_FXW_MAX_M - 2) / (FB_FXW_MAX_M - 1);
+      for (int p = 0; p <= n_pass; ++p) pass_lo[p] = 1 + (int)(((long long)(M - 1) * p) / n_pass);
+      DevBuf *pass_buf[FB_FXW_MAX_PASS] = {&e->gmm_images_fd, &e->gmm_images_fd2, &e->gmm_images_fd3};
+      for (int pass = 0; fits && pass < n_pass; ++pass) {  // (k_gmm_fx2 scores a model that does not fit)
+        const int n_items_p = 2 + pass_lo[pass + 1] - pass_lo[pass];  // Q, base, the pass's deltas
+        std::vector<uint16_t> fd((size_t)n_tiles * n_items_p * per_item, 0);
         for (int t = 0; t < n_tiles; ++t)
-          for (int it = 0; it < n_items; ++it) {
-            uint16_t *im = &fd[((size_t)t * n_items + it) * per_item];
-            const int m = it - 1;  // -1: the quadratic item
+          for (int it = 0; it < n_items_p; ++it) {
+            uint16_t *im = &fd[((size_t)t * n_items_p + it) * per_item];
+            const int m = it < 2 ? it - 1 : pass_lo[pass] + it - 2;  // -1: the quadratic item, 0: the base model
             auto at = [&](int term, int k, int cc) -> uint16_t * {
               const int ch = k / 16, hh = (k % 16) / 8, i = k % 8, lane = hh * 32 + cc;
               return &im[(((size_t)term * NKF + ch) * 64 + lane) * 8 + i];
@@ -856,8 +867,10 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
               }
             }
           }
-        FBCHK(e->gmm_images_fd.ensure(sizeof(uint16_t) * fd.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
-        HIPCHK(hipMemcpy(e->gmm_images_fd.p, fd.data(), sizeof(uint16_t) * fd.size(), hipMemcpyHostToDevice));
+        FBCHK(pass_buf[pass]->ensure(sizeof(uint16_t) * fd.size() + 4096));  // k_gmm_fx2w fetches whole 1 KB pieces: up to 3 past the end
+        HIPCHK(hipMemcpy(pass_buf[pass]->p, fd.data(), sizeof(uint16_t) * fd.size(), hipMemcpyHostToDevice));
+      }
+      if (fits) {
         // The anchors of k_gmm_fx2w's reference: the base model's FB_FXW_ANCHORS widest components.  The log2-likelihood
         // of a frame under one of them is a lower bound of the base model's log2 sum; every other model's sum is at least
         // that minus |dgconst| + |dlinear|_2 |x|_2 (Cauchy-Schwarz on the delta line above, in the frames' balanced units),
@@ -980,6 +993,16 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.delta_t2 = g.delta_p ? delta_t2 : 0;
   g.delta_t6 = g.delta_p ? delta_t6 : 0;
   g.images_fd = g.delta_p ? reinterpret_cast<decltype(g.images_fd)>(e->gmm_images_fd.p) : nullptr;
+  g.n_pass = g.delta_p ? n_pass : 0;
+  g.pass_first = 1;
+  {
+    DevBuf *pb[FB_FXW_MAX_PASS] = {&e->gmm_images_fd, &e->gmm_images_fd2, &e->gmm_images_fd3};
+    for (int p = 0; p < FB_FXW_MAX_PASS; ++p) {
+      g.pass_images[p] = (g.delta_p && p < n_pass) ? reinterpret_cast<decltype(g.images_fd)>(pb[p]->p) : nullptr;
+      g.pass_lo[p] = pass_lo[p];
+    }
+    g.pass_lo[FB_FXW_MAX_PASS] = pass_lo[FB_FXW_MAX_PASS];
+  }
   g.anchor = g.delta_p ? e->gmm_anchor.as<float>() : nullptr;
   g.item_model = e->gmm_items.as<int>();
   g.item_model_host_q_first = (G == 1) ? 1 : 0;  // one group: the list built above is {Q, 0, 1, ..., M-1}

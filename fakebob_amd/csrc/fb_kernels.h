@@ -168,11 +168,19 @@ struct FbGmmDev {
   const unsigned int __attribute__((ext_vector_type(4))) * images_fd;
   int delta_p, delta_t3, delta_t2;
   int delta_t6;  // tiles [delta_t3, delta_t6): the F6 class (delta_t3 <= delta_t6 <= delta_t2; fb_load_gmm, gmm_wide_kernel.hip)
+  // passes of k_gmm_fx2w (more than FB_FXW_MAX_M models): pass p scores the base model and the models pass_lo[p] ..
+  // pass_lo[p + 1] - 1 from its own image buffer {Q, base, its deltas}; the launcher hands the kernel a copy of this
+  // struct with images_fd = pass_images[p] and pass_first = pass_lo[p] (local model m >= 1 is model pass_first + m - 1 of
+  // the M the partial sums are laid out for)
+  int n_pass, pass_first;
+  const unsigned int __attribute__((ext_vector_type(4))) * pass_images[3];
+  int pass_lo[4];
   const float *anchor;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
-#define FB_FXW_MAX_M 10   // models k_gmm_fx2w takes: (1 + M) 10 KB items + the state of 2 M x 256 frames = 156 KB of LDS at M = 10
+#define FB_FXW_MAX_PASS 3 // launches of k_gmm_fx2w per batch: 1 + 9 x 3 = 28 models (fb_load_gmm)
+#define FB_FXW_MAX_M 10   // models ONE launch of k_gmm_fx2w takes: (1 + M) 10 KB items + the state of 2 M x 256 frames = 156 KB of LDS at M = 10
 #define FB_FXW_ANCHORS 2  // anchor components of k_gmm_fx2w's per-frame reference (FbGmmDev::anchor)
 #define FB_GMM_MODE_BX3 1
 #define FB_GMM_MODE_FX2 2

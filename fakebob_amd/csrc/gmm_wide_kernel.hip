@@ -913,7 +913,8 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
       const float mx = fmaxf(mm, m2);
       const float sx = ss * __expf(mm - mx) + s2 * __expf(m2 - mx);
       if (h == 0 && rows[hf] < n_rows) {
-        const size_t o = ((size_t)chunk_i * M + m) * rows_cap + rows[hf];
+        const int mg = m == 0 ? 0 : g.pass_first + m - 1;  // this pass's model m among the g.M the partials are laid out for
+        const size_t o = ((size_t)chunk_i * g.M + mg) * rows_cap + rows[hf];
         part_m[o] = mx;
         part_s[o] = sx;
       }
@@ -945,26 +946,34 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
                      xcd_map);
 }
 // k_gmm_fx2w is instantiated for the shapes the reference's systems have with the recipe's 72-dimensional features
-// (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models (SV: UBM + 1; OSI: UBM + up
-// to 9 speakers; CSI: up to 10 speakers).  Everything else runs on k_gmm_fx2.
+// (NKF = 5): one variance group, every component tile full, 2 <= M <= FB_FXW_MAX_M models per launch (SV: UBM + 1; OSI: UBM +
+// up to 9 speakers; CSI: up to 10 speakers; larger sites in up to FB_FXW_MAX_PASS passes).  Everything else runs on k_gmm_fx2.
 bool fb_gmm_use_wide(const FbGmmDev &g) {
   const bool off = getenv("FB_GMM_NARROW") != nullptr;  // read per call: the tests switch it inside one process
   return g.mode == FB_GMM_MODE_FX2 && !off && g.NKF == 5 && (g.D & 3) == 0 && g.n_items == g.M + 1 && (g.C & 31) == 0 && g.M >= 2 &&
-         g.M <= FB_FXW_MAX_M && g.item_model_host_q_first && g.delta_p >= 1 && g.images_fd != nullptr && g.anchor != nullptr;
+         g.n_pass >= 1 && g.item_model_host_q_first && g.delta_p >= 1 && g.images_fd != nullptr && g.anchor != nullptr;
 }
 void fb_launch_gmm_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap,
                         int n_chunks, float *part_m, float *part_s) {
-  switch (g.M) {
-    case 2: launch_gmm_fxw_t<5, 2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 3: launch_gmm_fxw_t<5, 3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 4: launch_gmm_fxw_t<5, 4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 5: launch_gmm_fxw_t<5, 5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 6: launch_gmm_fxw_t<5, 6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 7: launch_gmm_fxw_t<5, 7>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 8: launch_gmm_fxw_t<5, 8>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 9: launch_gmm_fxw_t<5, 9>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    case 10: launch_gmm_fxw_t<5, 10>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
-    default: break;  // fb_gmm_use_wide() admits only the cases above
+  // one launch per pass (fb_load_gmm: more than FB_FXW_MAX_M models are dealt over up to FB_FXW_MAX_PASS launches, each
+  // with the base model and its own delta images; the base model's partials are written by every pass with the same
+  // values)
+  for (int p = 0; p < g.n_pass; ++p) {
+    FbGmmDev gp = g;
+    gp.images_fd = g.pass_images[p];
+    gp.pass_first = g.pass_lo[p];
+    switch (1 + g.pass_lo[p + 1] - g.pass_lo[p]) {
+      case 2: launch_gmm_fxw_t<5, 2>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 3: launch_gmm_fxw_t<5, 3>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 4: launch_gmm_fxw_t<5, 4>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 5: launch_gmm_fxw_t<5, 5>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 6: launch_gmm_fxw_t<5, 6>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 7: launch_gmm_fxw_t<5, 7>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 8: launch_gmm_fxw_t<5, 8>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 9: launch_gmm_fxw_t<5, 9>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      case 10: launch_gmm_fxw_t<5, 10>(s, gp, feats, n_rows_ptr, rows_cap, n_chunks, part_m, part_s); break;
+      default: break;  // fb_load_gmm deals at most FB_FXW_MAX_M - 1 delta models to a pass
+    }
   }
 }
 

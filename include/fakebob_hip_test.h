@@ -31,7 +31,8 @@ int fb_debug_feats(fb_engine *e, const int16_t *wav, int64_t n, float *feats,
  * (No reference counterpart: the reference runs Kaldi's float32 CPU code, gmm_ubm_kaldiHelper.py:202-221.) */
 int fb_gmm_kernel_mode(fb_engine *e);
 /* The kernel fb_score_* / the NES loop launch for the loaded GMM system: 1 = k_gmm_bx3, 2 = k_gmm_fx2 (any number of
- * variance groups, partial tiles, more than 10 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 10 models: the
+ * variance groups, partial tiles, more than 28 models), 10 + P = k_gmm_fx2w (one variance group, 2 .. 28 models -- more than
+ * 10 in two or three launches --: the
  * speaker models are scored as deltas from model 0 with 1 .. 3 partial products per K chunk (or class 6, below), chosen by fb_load_gmm PER
  * 32-COMPONENT TILE from how far the tile's components were adapted; P = the count most tiles run, *shift_rms
  * (nullable) returns the rms adaptation statistic; FB_GMM_DELTA_P forces one count for every tile; FB_GMM_NARROW=1

@@ -388,23 +388,45 @@ def test_wide_scoring_kernel_csi_base_is_the_first_speaker(oracle, monkeypatch):
     assert np.abs(raw_g - raw_o).max() <= 2e-5
 
 
-def test_more_than_ten_models_run_on_the_general_kernel(oracle, monkeypatch):
-    """Beyond 10 models the LDS of one CU no longer holds a tile of every model plus the logsumexp state: the general
-    kernel takes over (documented cliff: DESIGN.md section 5), with the same results."""
+@pytest.mark.parametrize("n_speakers,delta_p", [(10, ""), (10, "6"), (12, ""), (18, "3"), (19, "6"), (27, ""), (28, "")])
+def test_more_than_ten_models_run_in_several_passes(oracle, monkeypatch, n_speakers, delta_p):
+    """One launch of k_gmm_fx2w holds a tile of 1 + M items and the logsumexp state of M models in the LDS of a CU: M <= 10.
+    Larger sites -- UBM + 10 speakers is already one too many -- are scored in up to three PASSES of the same kernel, each
+    with the base model and its share of the others (round 4; before, they fell to the general kernel at about twice
+    the time per model); beyond 1 + 9 x 3 = 28 models the general kernel takes over.  Same results either way."""
     for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
         monkeypatch.delenv(k, raising=False)
-    ubm, spk = synthetic_gmm_system(n_speakers=10, C=256, D=72)
-    wavs = [_wav(u, 16000) for u in range(3)]
+    if delta_p:
+        monkeypatch.setenv("FB_GMM_DELTA_P", delta_p)
+    ubm, spk = synthetic_gmm_system(n_speakers=n_speakers, C=256, D=72, enrol_frames=2000.0)
+    wavs = [_wav(u, 16000 + 777 * u) for u in range(4)]
     gc, miv, iv = stack_models([ubm] + spk)
-    raw_o, _ = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=8)
+    raw_o, tv_o = oracle.gmm_score_batch(oracle.default_cfg(), wavs, gc, miv, iv, nthreads=8)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        if n_speakers + 1 <= 28:
+            assert e.gmm_kernel_variant.startswith("fx2w/"), e.gmm_kernel_variant
+            if delta_p:
+                assert e.gmm_kernel_variant == "fx2w/" + delta_p
+        else:
+            assert e.gmm_kernel_variant == "fx2"
+        raw_g, tv_g = e.score_raw(wavs)
+        raw_g2, _ = e.score_raw(wavs[::-1])
+    finally:
+        e.close()
+    assert np.array_equal(tv_g, tv_o)
+    assert np.abs(raw_g - raw_o).max() <= 2e-5, np.abs(raw_g - raw_o).max()
+    assert np.array_equal(raw_g2[::-1], raw_g)            # every model's column, whichever pass wrote it
+    monkeypatch.setenv("FB_GMM_NARROW", "1")
     e = Engine(0)
     try:
         e.load_gmm([ubm] + spk)
         assert e.gmm_kernel_variant == "fx2"
-        raw_g, _ = e.score_raw(wavs)
+        raw_n, _ = e.score_raw(wavs)
     finally:
         e.close()
-    assert np.abs(raw_g - raw_o).max() <= 2e-5
+    assert np.abs(raw_g - raw_n).max() <= 2e-5
 
 
 def _frame_lls(models, x):
