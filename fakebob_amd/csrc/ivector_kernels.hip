@@ -660,7 +660,10 @@ __device__ __forceinline__ int fb_wave_lower_bound(const int *__restrict__ a, in
   const unsigned long long ge = __ballot(v >= key);
   return ge ? lo + (int)__builtin_ctzll(ge) : hi;
 }
-#define FB_IV_SG 16  // feature rows in flight per wave (two register buffers of this size)
+#define FB_IV_SG 8  // feature rows in flight per wave (two register buffers of this size).  Round 4: 16 -> 8 -- the kernel is a
+                    // chain of dependent round trips per (bucket, utterance) run, hidden by OTHER waves: 50 registers and eight waves
+                    // per SIMD (the whole grid resident) beat the deeper prefetch at 100 registers, 84 -> 61 us (spd 200: 354 -> 267);
+                    // 4 measures the same, 32 spills
 #define FB_IV_SSPLIT 16 // workgroups per component (utterances dealt round-robin): spreads the few very popular
                         // components, whose buckets hold thousands of pairs, over several CUs
 __global__ __launch_bounds__(256) void k_iv_stats(FbIvDev iv, const float *__restrict__ feats,
