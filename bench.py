@@ -281,15 +281,15 @@ def bench_ivector(args, torch):
         flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * R + tri)   # 64-row MFMA tiles
         con_ms = ms_con / args.steps
         gbps = bytes_alg / (con_ms * 1e-3) / 1e9
-        contraction = {"kernel": "k_iv_contract_dma<lin> + <quad> (T-matrix contraction: LDS-DMA ring, float64 MFMA "
+        contraction = {"kernel": "k_iv_contract_both = k_iv_contract_dma<lin> + <quad> in one launch (T-matrix contraction: LDS-DMA ring, float64 MFMA "
                                  "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
                        "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                        "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
                        "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
                        "all_components_bytes": bytes_all,
                        "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
-                               "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the two "
-                               "contraction kernels, HIP events on the attack's stream (with several attacks in flight "
+                               "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the "
+                               "contraction launch, HIP events on the attack's stream (with several attacks in flight "
                                "it includes time shared with other attacks' kernels)",
                        "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
                                     "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,

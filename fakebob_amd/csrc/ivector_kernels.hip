@@ -931,25 +931,27 @@ __device__ __forceinline__ void fb_iv_glds16(const void *gsrc, unsigned lds_dst)
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+typedef double fb_cd_sa_t[FB_CD_S][(FB_CD_KC / 2) * FB_CD_LDP];
+typedef double fb_cd_sb_t[FB_CD_S][FB_CD_KC * FB_CG_LDB];
+// (the body of one workgroup; bx / by / bz = its tile, K chunk and utterance group: a launch index of its own kernel or
+// decoded from the joint launch's, k_iv_contract_both)
 template <bool IS_LIN>
-__global__ __launch_bounds__(256) void k_iv_contract_dma(FbIvDev iv, const double *__restrict__ AT, int ldA, size_t zero_row,
-                                                         const int *__restrict__ active,
-                                                         const int *__restrict__ n_active, int B, int n_kchunks,
-                                                         double *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) double sA[FB_CD_S][(FB_CD_KC / 2) * FB_CD_LDP];
-  __shared__ __attribute__((aligned(16))) double sB[FB_CD_S][FB_CD_KC * FB_CG_LDB];
+__device__ __forceinline__ void fb_contract_dma_body(const FbIvDev &iv, const double *__restrict__ AT, int ldA, size_t zero_row,
+                                                     const int *__restrict__ active, const int *__restrict__ n_active, int B,
+                                                     int n_kchunks, double *__restrict__ out, const int bx, const int by,
+                                                     const int bz, fb_cd_sa_t &sA, fb_cd_sb_t &sB) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = IS_LIN ? iv.R : iv.triR;
   const int DK = IS_LIN ? iv.D : 1;
   const double *P = IS_LIN ? iv.sim : iv.u;
-  const int n0 = blockIdx.x * FB_CG_NT;
-  const int b0 = blockIdx.z * 64;
+  const int n0 = bx * FB_CG_NT;
+  const int b0 = bz * 64;
   const int na = *n_active;
   int a0 = 0, a1 = na;
   if (IS_LIN) {
     const int per = (na + n_kchunks - 1) / n_kchunks;
-    a0 = blockIdx.y * per;
+    a0 = by * per;
     a1 = min(na, a0 + per);
   }
   const int nq = max(0, a1 - a0) * DK;
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_iv_contract_dma(FbIvDev iv, const doubl
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  double *o = IS_LIN ? out + (size_t)blockIdx.y * B * N : out;
+  double *o = IS_LIN ? out + (size_t)by * B * N : out;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int col = n0 + 32 * w + 16 * c + (lane & 15);
@@ -1027,6 +1029,37 @@ __global__ __launch_bounds__(256) void k_iv_contract_dma(FbIvDev iv, const doubl
   }
 }
 
+template <bool IS_LIN>
+__global__ __launch_bounds__(256) void k_iv_contract_dma(FbIvDev iv, const double *__restrict__ AT, int ldA, size_t zero_row,
+                                                         const int *__restrict__ active,
+                                                         const int *__restrict__ n_active, int B, int n_kchunks,
+                                                         double *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) fb_cd_sa_t sA;
+  __shared__ __attribute__((aligned(16))) fb_cd_sb_t sB;
+  fb_contract_dma_body<IS_LIN>(iv, AT, ldA, zero_row, active, n_active, B, n_kchunks, out, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
+}
+// Both contractions in ONE launch (round 4): the linear one (Sigma^-1 M: few flops, bound by the latency of its short K
+// chunks) first in launch order, the quadratic one (U: bound by the float64 matrix pipe) behind it -- the workgroups of
+// the second fill the compute units beside those of the first instead of waiting for its launch to drain.
+__global__ __launch_bounds__(256) void k_iv_contract_both(FbIvDev iv, const double *__restrict__ XT,
+                                                          const double *__restrict__ gammaT, int ldA,
+                                                          const int *__restrict__ active, const int *__restrict__ n_active,
+                                                          int B, int n_kchunks, double *__restrict__ linp,
+                                                          double *__restrict__ quad, int n_lin_x, int n_quad_x) {
+  __shared__ __attribute__((aligned(16))) fb_cd_sa_t sA;
+  __shared__ __attribute__((aligned(16))) fb_cd_sb_t sB;
+  const int n_lin = n_lin_x * n_kchunks * (int)gridDim.y;
+  int idx = blockIdx.x;
+  if (idx < n_lin_x * n_kchunks) {
+    fb_contract_dma_body<true>(iv, XT, ldA, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp, idx % n_lin_x, idx / n_lin_x,
+                               blockIdx.y, sA, sB);
+  } else {
+    idx -= n_lin_x * n_kchunks;
+    fb_contract_dma_body<false>(iv, gammaT, ldA, (size_t)iv.C, active, n_active, B, 1, quad, idx, 0, blockIdx.y, sA, sB);
+  }
+  (void)n_lin; (void)n_quad_x;
+}
+
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
                            double *quad) {
@@ -1034,6 +1067,13 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
   const int bgroups = (B + 63) / 64;
   // LDS-DMA form: needs 16-byte aligned row segments; odd R / odd R(R+1)/2 take the register-staged kernel
   const bool dma = (iv.R % 2 == 0) && (iv.triR % 2 == 0) && iv.R >= 2;
+  static const bool split = getenv("FB_IV_CONTRACT_SPLIT") != nullptr;  // A/B: the two launches
+  if (dma && !split) {
+    const int n_lin_x = (iv.R + FB_CG_NT - 1) / FB_CG_NT, n_quad_x = (iv.triR + FB_CG_NT - 1) / FB_CG_NT;
+    hipLaunchKernelGGL(k_iv_contract_both, dim3(n_lin_x * n_kchunks + n_quad_x, bgroups), dim3(256), 0, s, iv, XT, gammaT, Bpad,
+                       active, n_active, B, n_kchunks, linp, quad, n_lin_x, n_quad_x);
+    return;
+  }
   if (dma) {
     hipLaunchKernelGGL((k_iv_contract_dma<true>), dim3((iv.R + FB_CG_NT - 1) / FB_CG_NT, n_kchunks, bgroups), dim3(256), 0, s,
                        iv, XT, Bpad, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp);
@@ -1061,8 +1101,9 @@ __device__ __forceinline__ double fb_block_sum(double v, double *red) {
 }
 // One workgroup of 1024 threads per utterance.  The two mat-vecs (LDA: L x R, PLDA transform: L x L) are split four
 // ways along the contraction index -- thread (g, t) sums a quarter of the products of output t, the quarters are added
-// in fixed order -- so that a lane's dependent chain is R/4 loads long instead of R (the kernel is a latency chain:
-// 77 us with 256 threads and whole dot products per thread).
+// in fixed order -- so that a lane's dependent chain is R/4 loads long instead of R, with 20 - 25 of them in flight (the
+// kernel is a latency chain: 77 us with 256 threads and whole dot products per thread, 35 with 8 loads in flight, 30 with
+// 20; five shares over 1000 threads measured the same as four).
 __global__ __launch_bounds__(1024) void k_iv_backend(FbIvDev iv, const double *__restrict__ ivec,
                                                      double *__restrict__ llr) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
@@ -1076,7 +1117,7 @@ __global__ __launch_bounds__(1024) void k_iv_backend(FbIvDev iv, const double *_
     const int r0 = (int)((long long)R * g / 4), r1 = (int)((long long)R * (g + 1) / 4);
     for (int l = t; l < L; l += 256) {
       double acc = (g == 0 && iv.lda_cols == R + 1) ? iv.ldaT[(size_t)R * L + l] : 0.0;
-#pragma unroll 8
+#pragma unroll 20
       for (int r = r0; r < r1; ++r) acc = fma(iv.ldaT[(size_t)r * L + l], x[r], acc);
       part[g * L + l] = acc;
     }
@@ -1098,7 +1139,7 @@ __global__ __launch_bounds__(1024) void k_iv_backend(FbIvDev iv, const double *_
     const int m0 = (int)((long long)L * g / 4), m1 = (int)((long long)L * (g + 1) / 4);
     for (int l = t; l < L; l += 256) {
       double acc = 0.0;
-#pragma unroll 8
+#pragma unroll 25
       for (int m = m0; m < m1; ++m) acc = fma(iv.pldaT[(size_t)m * L + l], z[m], acc);
       part[g * L + l] = acc;
     }
