@@ -1319,7 +1319,6 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(e->iv_ivec.ensure(sizeof(double) * (size_t)B * iv.R));
     FBCHK(e->iv_fail.ensure(sizeof(int)));
     FBCHK(e->iv_active.ensure(sizeof(int) * (size_t)(iv.C + 1)));
-    HIPCHK(hipMemsetAsync(e->iv_fail.p, 0, sizeof(int), s));
     FB_DBG_SYNC(e, "front-end");
     fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                        e->iv_ll.as<float>());
@@ -1335,7 +1334,8 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(time_begin(e));
     fb_launch_iv_contract(s, iv, e->iv_gamma.as<double>(), e->iv_X.as<double>(), B, Bpad, e->iv_kchunks,
                           e->iv_bws.as<int>() + 3 * (size_t)iv.C + 2, e->iv_active.as<int>(),
-                          e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(), e->iv_quad.as<double>());
+                          e->iv_active.as<int>() + iv.C, e->iv_linp.as<double>(), e->iv_quad.as<double>(),
+                          e->iv_fail.as<int>());
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
     FBCHK(time_begin(e, 2));

@@ -263,7 +263,7 @@ void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, co
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
-                           double *quad);
+                           double *quad, int *fail);
 // ivector_solve.hip (k_iv_solve_ll): quad is consumed (factored in place); Aall = B x R right-hand sides + a row of
 // R + 64 zeros behind them
 void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,

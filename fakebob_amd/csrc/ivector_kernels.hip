@@ -765,7 +765,7 @@ void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, co
 // few hundred of the C Gaussians are touched by a 3-s utterance, and the 51 utterances of an NES batch
 // are noisy copies of one utterance, so the contraction streams only the active rows of Sigma^-1 M / U.
 __global__ __launch_bounds__(1024) void k_iv_active(int C, int *__restrict__ flags, int *__restrict__ active,
-                                                    int *__restrict__ n_active) {
+                                                    int *__restrict__ n_active, int *__restrict__ fail) {
   __shared__ int s_cnt[17];
   __shared__ int s_base;
   if (threadIdx.x == 0) s_base = 0;
@@ -785,7 +785,8 @@ __global__ __launch_bounds__(1024) void k_iv_active(int C, int *__restrict__ fla
     if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += s_cnt[i]; s_base += t; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_active = s_base;
+  if (threadIdx.x == 0) { *n_active = s_base; *fail = 0; }  // (the solve's not-positive-definite flag: clean for this batch -- a
+                                                            // hipMemsetAsync per batch was 5 us of the stream's time)
 }
 
 // The two contractions as one LDS-tiled GEMM on the float64 matrix cores (v_mfma_f64_16x16x4_f64):
@@ -1062,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_iv_contract_both(FbIvDev iv, const doub
 
 void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gammaT, const double *XT, int B,
                            int Bpad, int n_kchunks, int *flags, int *active, int *n_active, double *linp,
-                           double *quad) {
-  hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active);
+                           double *quad, int *fail) {
+  hipLaunchKernelGGL(k_iv_active, dim3(1), dim3(1024), 0, s, iv.C, flags, active, n_active, fail);
   const int bgroups = (B + 63) / 64;
   // LDS-DMA form: needs 16-byte aligned row segments; odd R / odd R(R+1)/2 take the register-staged kernel
   const bool dma = (iv.R % 2 == 0) && (iv.triR % 2 == 0) && iv.R >= 2;
