@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { v1[i] = 0x08208208 + lane * (i + 1); v2[i] = 0x04104104 + 3 * lane * (i + 2); }
   if (MODE == 1 || MODE == 3) { v1[6] = v1[7] = v2[6] = v2[7] = 0; }
+  i32x8 v3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v3[i] = i < 6 ? 0x0c30c30c + 5 * lane * (i + 1) : 0;
   const int s1 = 120 + (lane & 7), s2 = 125 - (lane & 3);
+  float e0 = 0.f, e1 = 0.f, u0 = 0.f, u1 = 0.f, t0 = -0.01f * lane, t1 = -0.02f * lane;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -43,6 +47,32 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters) {
       } else if (MODE == 3) {  // one f16 then one fp6 alternating: the mix a correction class would issue (5 : 3)
         a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, h2, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, v1, a1, 2, 2, 0, s2, 0, s1);
+      } else if (MODE == 5) {  // fp6 with the B operand read from accumulation registers (k_gmm_fx2w's frames' side)
+        asm volatile("" : "+a"(v2), "+a"(v1));
+        a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v2, a0, 2, 2, 0, s1, 0, s2);
+        a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v1, a1, 2, 2, 0, s2, 0, s1);
+      } else if (MODE == 6) {  // the F6 step's mix: 20 f16 MFMAs then 12 scaled ones, B from accumulation registers
+        asm volatile("" : "+a"(v2), "+a"(v1));
+        if (q < 10) {
+          if (q & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, h1, a1, 0, 0, 0);
+          else a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, h2, a0, 0, 0, 0);
+          if (q & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, h1, a1, 0, 0, 0);
+          else a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, h2, a0, 0, 0, 0);
+        } else {
+          a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v2, a0, 2, 2, 0, s1, 0, s2);
+          a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v1, a1, 2, 2, 0, s2, 0, s1);
+        }
+      } else if (MODE == 7 || MODE == 8) {  // two exponentials + two additions behind every MFMA: f16 (7) / scaled fp6 (8)
+        if (MODE == 7) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, h2, a0, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v2, a0, 2, 2, 0, s1, 0, s2);
+        asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=v"(e0), "=v"(e1) : "v"(t0), "v"(t1));
+        asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(u0), "+v"(u1) : "v"(t0), "v"(t1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 7) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, h1, a1, 0, 0, 0);
+        else a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v3, v1, a1, 2, 2, 0, s2, 0, s1);
+        asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=v"(e0), "=v"(e1) : "v"(t0), "v"(t1));
+        asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(u0), "+v"(u1) : "v"(t0), "v"(t1));
+        __builtin_amdgcn_sched_barrier(0);
       } else {                 // fp4
         a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, v2, a0, 4, 4, 0, s1, 0, s2);
         a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v2, v1, a1, 4, 4, 0, s2, 0, s1);
@@ -52,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters) {
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
-  out[blockIdx.x * 256 + threadIdx.x] = s + pad[0] * 0.f;
+  out[blockIdx.x * 256 + threadIdx.x] = s + pad[0] * 0.f + e0 + e1 + u0 + u1;
 }
 
 __global__ void check(const int *A, const int *B, const int *SA, const int *SB, float *C) {
@@ -94,6 +124,10 @@ int main() {
   run<2>("v_mfma_scale_f32_32x32x64_f8f6f4 fp8 e4m3", 64);
   run<4>("v_mfma_scale_f32_32x32x64_f8f6f4 fp4", 64);
   run<3>("alternating f16 K=16 / fp6 K=64 (per pair /2)", 40);
+  run<5>("fp6 e2m3, B from accumulation registers", 64);
+  run<6>("F6 step mix (20 f16 + 12 scaled per 32), B from AGPRs", 40);
+  run<7>("f16 K=16 + 2 v_exp + 2 v_add behind each", 16);
+  run<8>("fp6 K=64 + 2 v_exp + 2 v_add behind each", 64);
   // layout check
   static int ca[32][64], cb[64][32], sa[32][2], sb[32][2];
   srand(7);
