@@ -137,6 +137,43 @@ def test_attack_is_independent_of_the_queue_depth(monkeypatch, batch):
     assert np.array_equal(got[3], ref[3])            # trace rows (bit-identical)
 
 
+def test_attack_on_a_site_with_more_than_ten_models_equals_the_oracle(oracle, monkeypatch):
+    """UBM + 12 speakers: k_gmm_fx2w scores them in two passes (round 4).  The whole NES loop on top of that -- get_grad,
+    the loss over 12 scores, early stop, trace -- against the oracle on the 1 s / spd = 10 attack the bit-identical
+    trajectories of tests/test_gpu_parity.py use."""
+    for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P"):
+        monkeypatch.delenv(k, raising=False)
+    from fakebob_amd.models import stack_models
+    ubm, spk = synthetic_gmm_system(n_speakers=12, C=256, D=72)
+    models = [ubm] + spk
+    gc, miv, iv = stack_models(models)
+    e = Engine(0)
+    try:
+        e.load_gmm(models)
+        e.set_system("OSI")
+        assert e.gmm_kernel_variant.startswith("fx2w/")
+        ctx = oracle.GmmSystemCtx(oracle.default_cfg(), "OSI", gc, miv, iv, nthreads=8)
+        audio = synthetic_audio(6, 16000)
+        kw = dict(samples_per_draw=10, max_iter=6, target=7, threshold=-1.0, epsilon=0.002)
+        pg = nes_params("OSI", "targeted", seed=11, stream=0, **kw)
+        po = oracle.nes_params("OSI", "targeted", ctx.S, **kw)
+        flg, gg, alg, scg = e.get_grad(pg, audio, it=0)
+        flo, go, alo, sco = oracle.get_grad(po, ctx.fn, ctx.ctx, audio, seed=11, it=0, stream=0)
+        assert scg[:ctx.S].shape == sco.shape == (12,)
+        assert np.abs(scg[:ctx.S] - sco).max() <= 2e-5 and abs(flg - flo) <= 2e-5 and abs(alg - alo) <= 2e-5
+        adv_g, flag_g, advf_g, tr_g = e.attack(pg, audio)
+        adv_o, flag_o, advf_o, tr_o = oracle.attack(po, ctx.fn, ctx.ctx, audio, seed=11, stream=0)
+        assert flag_g == flag_o and tr_g.shape == tr_o.shape
+        # the first iteration to score tolerance; afterwards the gradient entries within float32 noise of zero step
+        # their samples in opposite directions and the iteration amplifies it (tests/test_gpu_fullsize_gmm.py)
+        rows = np.abs(tr_g - tr_o).max(axis=1)
+        assert rows[0] <= 1e-4 and rows.max() <= 1e-2, rows
+        assert np.array_equal(tr_g[:, 2], tr_o[:, 2])                         # same learning-rate schedule
+        assert np.abs(advf_g - audio).max() <= pg.epsilon + 1e-12
+    finally:
+        e.close()
+
+
 def test_text_scores_option_matches_the_oracle_and_quantises(oracle):
     """fb_frontend_cfg.text_scores: raw scores go through Kaldi's 6-significant-digit text output, as the
     reference's helpers read them; the device rounding is bit-identical to the oracle's."""
