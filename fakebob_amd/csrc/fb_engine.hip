@@ -118,7 +118,8 @@ struct fb_engine {
   int pre_ndp = 0;
   bool defer_finalize = false;  // run_scoring leaves the GMM finalisation to the fused finalize + loss launch
   int vad_part_B = -1, vad_part_dim = -1;  // slot layout the sentinel-filled exchange buffer of k_vad_delta_cmvn_p was prepared for
-  unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernel on vad_pub (its published counts carry the epoch)
+  unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernels on vad_pub (its published counts carry the epoch)
+  unsigned vad_p_launches = 0;  // launches of k_vad_delta_cmvn_p on vad_part since its sentinel fill (its slot sets alternate with them)
   FbCtlDev *h_ctl = nullptr;  // pinned
   hipEvent_t evg_ring[2 * 16] = {};
   int evg_n = 0;
@@ -361,9 +362,22 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   memcpy(&host[o_dct], dct.data(), sizeof(double) * dct.size());
   memcpy(&host[o_lift], lifter.data(), sizeof(double) * lifter.size());
   memcpy(&host[o_ds], dscale.data(), sizeof(double) * dscale.size());
+  // every check that can refuse the configuration runs on locals: a refused call leaves e->fe, e->cfg and the device
+  // tables exactly as they were
+  if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, (int)mel_w.size())) > 150 * 1024)
+    return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
+  const bool f32_shape = P == 512 && nb <= 31 && nc <= 32 && (L & 1) == 0;  // k_mfcc_f32's tables exist for these
+  if (c->mfcc_f32 && !(f32_shape && c->raw_energy != 0))
+    return fb_fail(FB_E_ARG, "mfcc_f32 needs padded_length 512, raw_energy, <= 31 mel bins, <= 32 cepstra and an even frame length");
+  std::vector<float> t32;
+  if (f32_shape)  // (any precision setting: the flag may come later)
+    t32 = fb_mfcc_f32_table(L, nb, nc, window.data(), tw_half.data(), tw_full.data(), mel_first.data(), mel_len.data(),
+                            mel_off.data(), mel_w.data(), (int)mel_w.size(), dct.data(), lifter.data());
   FBCHK(sync_stream(e));
   FBCHK(e->fe_tables.ensure(off));
+  if (f32_shape) FBCHK(e->fe_tables32.ensure(sizeof(float) * t32.size()));
   HIPCHK(hipMemcpy(e->fe_tables.p, host.data(), off, hipMemcpyHostToDevice));
+  if (f32_shape) HIPCHK(hipMemcpy(e->fe_tables32.p, t32.data(), sizeof(float) * t32.size(), hipMemcpyHostToDevice));
   char *base = e->fe_tables.as<char>();
   FbFrontendDev &fe = e->fe;
   fe.L = L; fe.P = P; fe.shift = c->frame_shift; fe.nb = nb; fe.nc = nc; fe.dim = dim; fe.order = order;
@@ -380,20 +394,7 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   fe.mel_w = (const double *)(base + o_mw); fe.dct = (const double *)(base + o_dct);
   fe.lifter = (const double *)(base + o_lift); fe.dscale = (const double *)(base + o_ds);
   e->melw_n = (int)mel_w.size();
-  fe.f32_tab = nullptr;
-  if (P == 512 && nb <= 31 && nc <= 32 && (L & 1) == 0) {  // k_mfcc_f32's tables (any precision setting: the flag may come later)
-    const std::vector<float> t32 = fb_mfcc_f32_table(L, nb, nc, window.data(), tw_half.data(), tw_full.data(), mel_first.data(),
-                                                     mel_len.data(), mel_off.data(), mel_w.data(), (int)mel_w.size(), dct.data(), lifter.data());
-    FBCHK(e->fe_tables32.ensure(sizeof(float) * t32.size()));
-    HIPCHK(hipMemcpy(e->fe_tables32.p, t32.data(), sizeof(float) * t32.size(), hipMemcpyHostToDevice));
-    fe.f32_tab = e->fe_tables32.as<float>();
-  }
-  if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, e->melw_n)) > 150 * 1024)
-    return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
-  if (c->mfcc_f32 && !fb_mfcc_f32_supported(fe)) {
-    fe.mfcc_f32 = e->cfg.mfcc_f32 ? 1 : 0;
-    return fb_fail(FB_E_ARG, "mfcc_f32 needs padded_length 512, raw_energy, <= 31 mel bins, <= 32 cepstra and an even frame length");
-  }
+  fe.f32_tab = f32_shape ? e->fe_tables32.as<float>() : nullptr;
   e->cfg = *c;
   e->gmm.text_scores = c->text_scores;
   e->iv.text_scores = c->text_scores;
@@ -1197,6 +1198,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
       HIPCHK(hipMemsetAsync(e->vad_pub.p, 0, e->vad_pub.cap, s));
       HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->vad_part.p), (int)FB_VAD_SENTINEL32, e->vad_part.cap / 4, s));
       e->vad_epoch = 0;
+      e->vad_p_launches = 0;
       e->vad_part_B = B;
       e->vad_part_dim = fe.dim;
     }
@@ -1205,8 +1207,9 @@ static int run_post_mfcc(fb_engine *e, int B) {
     if (fb_fuse_on(e) && !cm_fused && getenv("FB_VAD_WHOLE") == nullptr &&
         fb_launch_vad_delta_cmvn_p(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                    e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
-                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>())) {
+                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>(), e->vad_p_launches)) {
       e->vad_epoch += 1;
+      e->vad_p_launches += 1;
       return FB_OK;
     }
     if (fb_fuse_on(e) && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
@@ -1885,6 +1888,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     // mis-assign utterances / skip its loss body.  A new attack starts them clean.
     if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
     if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+    e->vad_part_B = -1;  // ... and k_vad_delta_cmvn_p's exchange slots are refilled with sentinels (run_post_mfcc)
     FbCtlDev h;
     memset(&h, 0, sizeof(h));
     h.lr = p->max_lr; h.min_lr = p->min_lr; h.plateau_drop = p->plateau_drop;

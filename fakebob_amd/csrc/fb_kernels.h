@@ -123,14 +123,14 @@ bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const floa
                               int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
                               float *feats, float *cm_out);
 // the same with every utterance split over FB_CMVN_PARTS (4) workgroups (no CompressedMatrix phase): part_sum = exchange
-// slots, fb_vad_parts_doubles() 64-bit words, every 32-bit half FB_VAD_SENTINEL32 before the first launch and whenever
-// the epoch counter restarts
+// slots, fb_vad_parts_doubles() 64-bit words, every 32-bit half FB_VAD_SENTINEL32 before the first launch; slot_set =
+// launches of this kernel on the buffer since then (its two slot sets alternate with it)
 #define FB_VAD_SENTINEL32 0x7ff87ff8u
 #define FB_VAD_SENTINEL 0x7ff87ff87ff87ff8ull
 size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B);
 bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                                 int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                                float *feats, double *part_sum);
+                                float *feats, double *part_sum, unsigned slot_set);
 bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
                           const int *vrank, const int *row_off, int B, int t_max, float *feats);
 // add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk

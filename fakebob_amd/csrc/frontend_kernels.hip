@@ -1352,8 +1352,16 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
                                                           unsigned epoch, int *__restrict__ ticket,
                                                           unsigned long long *__restrict__ pub, int *__restrict__ tv,
                                                           int *__restrict__ row_off, float *__restrict__ feats,
-                                                          double *__restrict__ part_sum) {
-  if (fe.stop && *fe.stop) return;
+                                                          double *__restrict__ part_sum, unsigned slot_set) {
+  if (fe.stop && *fe.stop) {
+    // A launch queued behind the stopping iteration computes nothing, but it still owes the NEXT launch its sentinels:
+    // the host counts this launch, so the next one polls the slot set the last REAL launch filled.  Workgroup i puts the
+    // sentinel back into the i-th (utterance, part) slot of that set (any bijection does).
+    unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((slot_set + 1u) & 1u) * B * FB_CMVN_PARTS * fe.dim;
+    for (int d = threadIdx.x; d < fe.dim; d += 256)
+      __hip_atomic_store(&nxt[(size_t)blockIdx.x * fe.dim + d], FB_VAD_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   __shared__ int s_tk, s_run, s_wtot[4], s_rbase;
   __shared__ float s_thr;
@@ -1473,14 +1481,15 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   // ---- this part's block of the CMVN column sums (frame by frame from zero), exchanged with the other parts.
   //      No flags and no fences: a block sum is ONE 64-bit word, stored and polled with relaxed agent-scope atomics; a
   //      slot that still holds the sentinel (a NaN no sum can be: a NaN sum is stored as another NaN) has not been
-  //      written yet.  Two slot sets alternate with the launch epoch; every part puts the sentinel back into its slots of
-  //      the OTHER set, which the previous launch used and the next one will.  (Device-wide release / acquire fences -- L2
+  //      written yet.  Two slot sets alternate with the launches of THIS kernel (slot_set: the host's count of them --
+  //      not the epoch of `pub`, which k_vad_delta_cmvn's launches advance as well); every part puts the sentinel back
+  //      into its slots of the OTHER set, which the previous launch used and the next one will.  (Device-wide release / acquire fences -- L2
   //      write-back and invalidate on a multi-XCD part -- cost this kernel 17 us when every thread issued one, and
   //      still ~2 us per workgroup with one release store + one acquire fence.)
   const double alpha = (double)(float)(-1.0 / (double)T);
   const unsigned long long SENT = FB_VAD_SENTINEL;
-  unsigned long long *cur = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)(epoch & 1u) * B * NP * dim;
-  unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((epoch + 1u) & 1u) * B * NP * dim;
+  unsigned long long *cur = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)(slot_set & 1u) * B * NP * dim;
+  unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((slot_set + 1u) & 1u) * B * NP * dim;
   double own = 0.0;
   for (int d = tid; d < dim; d += 256) {   // (dim <= 256: at most one dimension per thread)
     double acc = 0.0;
@@ -1554,12 +1563,13 @@ size_t fb_vad_delta_cmvn_p_lds_bytes(const FbFrontendDev &fe, int t_cap) {
          sizeof(float) * ((size_t)((t_cap + 1) & ~1) + (size_t)(tq_cap + 2 * fe.order * fe.dwin) * fe.nc + (size_t)tq_cap * fe.dim) +
          sizeof(int) * (size_t)t_cap + 16;
 }
-// part_sum: two slot sets of B x FB_CMVN_PARTS x dim 64-bit words, every word FB_VAD_SENTINEL before the first launch (and
-// whenever the epoch counter is reset).  Returns false when the batch does not qualify.
+// part_sum: two slot sets of B x FB_CMVN_PARTS x dim 64-bit words, every word FB_VAD_SENTINEL before the first launch;
+// slot_set: the number of launches of this kernel on the buffer since then (a launch that finds the attack's stop flag
+// raised counts: it restores the sentinels it owes).  Returns false when the batch does not qualify.
 size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B) { return (size_t)2 * B * FB_CMVN_PARTS * fe.dim; }
 bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                                 int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                                float *feats, double *part_sum) {
+                                float *feats, double *part_sum, unsigned slot_set) {
   if (B <= 0) return true;
   if (t_max > fe.cmn_window || fe.dim > 256) return false;
   size_t shm = fb_vad_delta_cmvn_p_lds_bytes(fe, t_max);
@@ -1583,11 +1593,11 @@ bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const fl
   }
   const dim3 grid((unsigned)(B * FB_CMVN_PARTS)), blk(256);
   if (fe.order == 2 && fe.dwin == 3)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   else if (fe.order == 2 && fe.dwin == 2)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   else
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   return true;
 }
 

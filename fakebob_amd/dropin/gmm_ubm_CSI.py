@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-gmm_CSI = _systems.reference_pipeline(_systems.gmm_CSI)
+gmm_CSI = _systems.reference_pipeline(_systems.gmm_CSI, __name__)

@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-gmm_OSI = _systems.reference_pipeline(_systems.gmm_OSI)
+gmm_OSI = _systems.reference_pipeline(_systems.gmm_OSI, __name__)

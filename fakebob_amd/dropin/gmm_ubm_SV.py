@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-gmm_SV = _systems.reference_pipeline(_systems.gmm_SV)
+gmm_SV = _systems.reference_pipeline(_systems.gmm_SV, __name__)

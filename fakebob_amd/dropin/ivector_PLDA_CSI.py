@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-iv_CSI = _systems.reference_pipeline(_systems.iv_CSI)
+iv_CSI = _systems.reference_pipeline(_systems.iv_CSI, __name__)

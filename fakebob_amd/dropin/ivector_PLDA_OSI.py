@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-iv_OSI = _systems.reference_pipeline(_systems.iv_OSI)
+iv_OSI = _systems.reference_pipeline(_systems.iv_OSI, __name__)

@@ -3,4 +3,4 @@
 (dropin/README.md)."""
 from fakebob_amd import systems as _systems
 
-iv_SV = _systems.reference_pipeline(_systems.iv_SV)
+iv_SV = _systems.reference_pipeline(_systems.iv_SV, __name__)

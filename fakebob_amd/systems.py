@@ -7,6 +7,7 @@ libfakebob_hip.so instead of >= 10 Kaldi subprocesses per call.  `n_jobs`, `debu
 accepted and ignored; `bits_per_sample` drives the int16 cast exactly as in the reference.
 """
 import os
+import warnings
 
 import numpy as np
 
@@ -46,11 +47,43 @@ def _pipeline_options(text_scores, compress_feats, default=None, mfcc_f32=None):
     return out
 
 
-def reference_pipeline(cls):
+def _apply_frontend(engine, conf_over, text_scores, compress_feats, mfcc_f32, default):
+    """Front-end options of a system under construction -> the engine.  `conf_over`: what pre_model_dir/conf says.
+    A float32 MFCC mode that only the class default asked for (no keyword, no FB_MFCC_F32) falls back to the float64
+    kernel with a warning when the configuration is outside k_mfcc_f32's shape (raw-energy=false, > 31 mel bins, an odd
+    frame length, a padded length other than 512): such a conf worked before the drop-in classes defaulted to float32."""
+    from ._native import NativeError
+    opts = _pipeline_options(text_scores, compress_feats, default, mfcc_f32)
+    over = dict(conf_over, **opts)
+    if not over:
+        inherited = [k for k, _ in _PIPELINE_ENV if getattr(getattr(engine, "cfg", None), k, 0)]
+        if inherited:
+            warnings.warn("this system is built on an engine whose pipeline flags %s were switched on earlier (by a drop-in "
+                          "system sharing it) and names none of them: it inherits them -- pass text_scores / compress_feats / "
+                          "mfcc_f32 = False for the library's full-precision defaults" % inherited)
+        return
+    only_default = (opts.get("mfcc_f32") == 1 and mfcc_f32 is None and os.environ.get("FB_MFCC_F32") not in ("0", "1"))
+    try:
+        engine.set_frontend(**over)
+    except NativeError:
+        if not only_default:
+            raise
+        over["mfcc_f32"] = 0
+        engine.set_frontend(**over)  # (raises again when the float32 mode was not the reason)
+        warnings.warn("this front-end configuration is outside the float32 MFCC kernel's shape (it needs padded length 512, "
+                      "raw-energy, <= 31 mel bins, <= 32 cepstra, an even frame length): the float64 kernel is used instead")
+    if "mfcc_f32" not in opts or "text_scores" not in opts or "compress_feats" not in opts:
+        inherited = [k for k, _ in _PIPELINE_ENV if k not in opts and getattr(getattr(engine, "cfg", None), k, 0)]
+        if inherited:
+            warnings.warn("pipeline flags %s stay on from an earlier system on this engine" % inherited)
+
+
+def reference_pipeline(cls, module=None):
     """The subclass of a system class that behaves like the reference's pipeline by default (both round trips on):
-    what fakebob_amd/dropin/<reference module name>.py exports under the reference's class name."""
+    what fakebob_amd/dropin/<reference module name>.py exports under the reference's class name.  `module`: the
+    exporting module's __name__ -- the subclass then pickles by reference as <module>.<class name>."""
     return type(cls.__name__, (cls,), {"PIPELINE": dict(REFERENCE_PIPELINE), "__doc__": cls.__doc__,
-                                       "__module__": cls.__module__})
+                                       "__module__": module or cls.__module__, "__qualname__": cls.__name__})
 
 
 def default_device():
@@ -88,9 +121,7 @@ class _GmmSystem(object):
         if os.path.isdir(conf):
             from .config import frontend_from_kaldi_conf
             over = frontend_from_kaldi_conf(self.pre_model_dir)
-        over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32))
-        if over:
-            self._engine.set_frontend(**over)
+        _apply_frontend(self._engine, over, text_scores, compress_feats, mfcc_f32, self.PIPELINE)
         self._engine.load_gmm(models)
         self._engine.set_system(self.task, z_means, z_stds)
 
@@ -236,15 +267,11 @@ class _IvSystem(object):
             if os.path.isdir(conf):
                 from .config import frontend_from_kaldi_conf
                 over = frontend_from_kaldi_conf(self.pre_model_dir)
-            over = dict(over, **_pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32))
-            if over:
-                self._engine.set_frontend(**over)
+            _apply_frontend(self._engine, over, text_scores, compress_feats, mfcc_f32, self.PIPELINE)
             d = load_ivector_pre_models(self.pre_model_dir)
             system = IvectorSystem(enrolled=enrolled, z_mean=zm, z_std=zs, **d)
         else:
-            over = _pipeline_options(text_scores, compress_feats, self.PIPELINE, mfcc_f32)
-            if over:
-                self._engine.set_frontend(**over)
+            _apply_frontend(self._engine, {}, text_scores, compress_feats, mfcc_f32, self.PIPELINE)
             system = system.with_enrolled(enrolled, zm, zs)
         self._engine.load_ivector(system, self.task)
 

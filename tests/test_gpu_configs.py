@@ -137,6 +137,56 @@ def test_attack_is_independent_of_the_queue_depth(monkeypatch, batch):
     assert np.array_equal(got[3], ref[3])            # trace rows (bit-identical)
 
 
+@pytest.mark.parametrize("batch", ["4", "2", "3"])
+def test_back_to_back_early_stopping_attacks_on_one_engine(oracle, monkeypatch, batch):
+    """attackMain.py:331,370 calls fake_bob.attack back to back on one model object.  An attack that stops at
+    iteration 0 leaves FB_ATTACK_BATCH - 1 queued launches behind that find the stop flag raised and do nothing;
+    k_vad_delta_cmvn_p's two exchange-slot sets alternate per launch, so after an odd number of such launches the
+    next attack once polled slots that still held the previous attack's CMVN block sums (round-4 advisor finding).
+    The second attack must be the same on a used engine as on a fresh one, bit for bit, and equal the oracle's."""
+    from oracle import oracle as O
+    monkeypatch.setenv("FB_ATTACK_BATCH", batch)
+    ubm, spk = synthetic_gmm_system(n_speakers=3, C=128, D=72)
+    models = [ubm] + spk
+    a1, a2 = synthetic_audio(6, 16000), synthetic_audio(9, 16000)
+    gc, miv, iv = stack_models(models)
+    ctx = O.GmmSystemCtx(O.default_cfg(), "OSI", gc, miv, iv, nthreads=4)
+    s1 = ctx.score(a1[:, None])[0]
+    tgt = int(np.argmax(s1))
+    kw2 = dict(samples_per_draw=10, max_iter=6, target=0, threshold=-1.0, epsilon=0.002)
+
+    def first(e):  # loss[0] < 0 at iteration 0: the launches queued behind it do nothing
+        p = nes_params("OSI", "targeted", samples_per_draw=10, max_iter=8, target=tgt, threshold=float(s1.min() - 5.0),
+                       adver_thresh=-1.0, seed=1)
+        adv, flag, _, tr = e.attack(p, a1)
+        assert flag == 1 and tr.shape[0] == 1
+
+    def second(e):
+        return e.attack(nes_params("OSI", "targeted", seed=11, stream=0, **kw2), a2)
+
+    fresh = Engine(0)
+    used = Engine(0)
+    try:
+        for e in (fresh, used):
+            e.load_gmm(models)
+            e.set_system("OSI")
+        ref = second(fresh)
+        first(used)
+        got = second(used)
+        again = second(used)   # and once more behind a full-length attack
+    finally:
+        fresh.close()
+        used.close()
+    for r in (got, again):
+        assert r[1] == ref[1]
+        assert np.array_equal(r[0], ref[0]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
+    po = O.nes_params("OSI", "targeted", ctx.S, **kw2)
+    adv_o, flag_o, advf_o, tr_o = O.attack(po, ctx.fn, ctx.ctx, a2, seed=11, stream=0)
+    assert flag_o == got[1] and tr_o.shape == got[3].shape
+    assert np.abs(tr_o - got[3]).max() <= 1e-4
+    assert int(np.sum(adv_o != got[0])) == 0
+
+
 def test_attack_on_a_site_with_more_than_ten_models_equals_the_oracle(oracle, monkeypatch):
     """UBM + 12 speakers: k_gmm_fx2w scores them in two passes (round 4).  The whole NES loop on top of that -- get_grad,
     the loss over 12 scores, early stop, trace -- against the oracle on the 1 s / spd = 10 attack the bit-identical
