@@ -125,6 +125,8 @@ def main(argv=None, model_factory=None, bob_factory=None):
     ap.add_argument("--debug", "-debug", default="f", choices=["t", "f"])       # accepted, unused
     ap.add_argument("--threshold", "-thresh", default=0., type=float)
     ap.add_argument("--streams", default=3, type=int, help="attacks in flight per GPU")
+    ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
+                    help="dynamic: free attack streams draw the next attack (ticket counter); static: round-robin deal")
     ap.add_argument("--seed", default=None, type=int, help="Philox key (default: from numpy's global RNG)")
     ap.add_argument("--model_dir", default="./model")
     ap.add_argument("--pre_model_dir", default="pre-models")
@@ -185,14 +187,25 @@ def main(argv=None, model_factory=None, bob_factory=None):
             thr, _, _ = bobs[0].estimate_threshold(pick, fs=fs, bits_per_sample=bits_per_sample)
         threshold = parallel.broadcast_threshold(thr, dist)
 
-    mine = parallel.shard_indices(total, rank, world)
+    # every attack stream of every rank draws the next global attack index when it is free (attack cost ranges from one
+    # iteration -- early stop, FAKEBOB.py:181-191 -- to max_iter); --schedule static: round-robin over ranks and streams
+    queue = parallel.WorkQueue(total, dist, args.schedule, streams=K)
     results = {}
     lock = threading.Lock()
+    errors = []
 
     def worker(k):
+        try:
+            run_stream(k)
+        except BaseException as ex:  # noqa: BLE001  (re-raised below: a dead stream must not look like a short list)
+            errors.append(ex)
+
+    def run_stream(k):
         bob = bobs[k]
-        for j in range(k, len(mine), K):
-            idx = mine[j]
+        while True:
+            idx = queue.next(k)
+            if idx is None:
+                return
             it = items[idx]
             bob._stream = idx + 1         # Philox stream = global attack index: results do not depend on the sharding
             # the reference passes true= only for CSI untargeted (:346) and target= only for targeted attacks (:332,:367)
@@ -206,9 +219,11 @@ def main(argv=None, model_factory=None, bob_factory=None):
     ths = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
     [t.start() for t in ths]
     [t.join() for t in ths]
+    if errors:
+        raise errors[0]
     st = [m.engine.stats() if hasattr(m, "engine") else dict(nes_iters=0, scored_utts=0) for m in models]
     succ = sum(1 for f in results.values() if f == 1)
-    g = parallel.reduce_counters([succ, len(mine), sum(s["nes_iters"] for s in st), sum(s["scored_utts"] for s in st)], dist)
+    g = parallel.reduce_counters([succ, len(results), sum(s["nes_iters"] for s in st), sum(s["scored_utts"] for s in st)], dist)
     if rank == 0:
         if g[1] > 0:
             print('------ attack successful rate %d ------' % (g[0] * 100 / g[1]))

@@ -3,7 +3,12 @@
 Each `(audio, target)` attack of the reference's driver loop is independent (attackMain.py:324-409
 is a plain `for` loop sharing only the read-only model and, for OSI/SV, one pre-computed scalar
 `threshold_estimated`), so the path shards embarrassingly: one process per GPU, model replicated,
-utterances dealt round-robin, NO collective inside an attack.  RCCL (torch.distributed backend
+NO collective inside an attack.  Attack cost varies by two orders of magnitude (early stop at
+FAKEBOB.py:181-191 against max_iter = 1000, attackMain.sh:24), so the attacks are not dealt out in advance: a free
+attack stream DRAWS the next global attack index from a ticket counter (`WorkQueue`) -- a lock-protected counter inside
+one process, an atomic add on the process group's key-value store across ranks (no collective; nccl and gloo alike).
+Results do not depend on who runs what: the Philox stream of an attack is its global index.  `schedule="static"`
+keeps the round-robin deal of earlier rounds (A/B, bench.py's end_to_end line).  RCCL (torch.distributed backend
 "nccl" on ROCm; "gloo" in the CPU tests) is used only for
   * one broadcast of the estimated threshold (1 x float64) from rank 0 -- mirrors
     attackMain.py:356-357 / :393-394 --, one of the job's Philox key (1 x int64) when --seed is omitted, and
@@ -11,6 +16,7 @@ utterances dealt round-robin, NO collective inside an attack.  RCCL (torch.distr
     -- mirrors attackMain.py:312,335-336,411.
 """
 import os
+import threading
 
 
 def dist_env():
@@ -22,6 +28,60 @@ def dist_env():
 def shard_indices(n_items, rank, world):
     """Static round-robin: item i belongs to rank i % world (length-sorted callers get balance)."""
     return list(range(rank, n_items, world))
+
+
+class WorkQueue(object):
+    """Ticket dispenser over the global attack list: next() -> the next index nobody has drawn yet, or None when the
+    list is exhausted.  Thread-safe (the K attack streams of a rank draw from the same object).
+
+    world == 1 or schedule == "static": no communication -- static hands rank r the indices r, r + world, ... in
+    order (what attack_main did before round 5, per stream as well when `streams` is given: stream k of K takes every
+    K-th of them).  Dynamic with world > 1: `store.add(key, 1)` on the default process group's store is atomic across
+    ranks and returns the new value; every rank constructs its queues in the same order, so queue number q uses the
+    same key everywhere."""
+    _made = 0
+
+    def __init__(self, n_items, dist=None, schedule="dynamic", rank=None, world=None, streams=None):
+        if schedule not in ("dynamic", "static"):
+            raise ValueError("schedule must be 'dynamic' or 'static'")
+        r, _, w = dist_env() if dist is not None else (0, 0, 1)
+        self.n = int(n_items)
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.schedule = schedule
+        self._lock = threading.Lock()
+        self._streams = streams
+        self._key = "fakebob/next/%d" % WorkQueue._made
+        WorkQueue._made += 1
+        self._store = None
+        if schedule == "dynamic" and self.world > 1:
+            import torch.distributed as td
+            self._store = td.distributed_c10d._get_default_store()
+        mine = list(range(self.rank, self.n, self.world))
+        if schedule == "static" and streams:
+            self._static = [mine[k::streams] for k in range(streams)]
+        else:
+            self._static = [mine]
+        self._local_next = 0
+        self.drawn = 0    # items this rank has drawn
+
+    def next(self, stream=0):
+        with self._lock:
+            if self.schedule == "static":
+                lst = self._static[stream if self._streams else 0]
+                if not lst:
+                    return None
+                self.drawn += 1
+                return lst.pop(0)
+            if self._store is not None:
+                i = int(self._store.add(self._key, 1)) - 1
+            else:
+                i = self._local_next
+                self._local_next += 1
+            if i >= self.n:
+                return None
+            self.drawn += 1
+            return i
 
 
 def init_process_group(backend=None):
@@ -82,25 +142,48 @@ def reduce_counters(counters, dist=None):
     return [int(x) for x in t.tolist()]
 
 
-def run_sharded(items, attack_fn, estimate_fn=None, dist=None):
-    """Runs `attack_fn(item, threshold) -> (success_flag, n_iters, n_scored)` over this rank's shard.
+def run_sharded(items, attack_fn, estimate_fn=None, dist=None, schedule="dynamic", streams=1):
+    """Runs `attack_fn(item, threshold) -> (success_flag, n_iters, n_scored)` over the items this rank draws
+    (`streams` threads per rank; attack_fn must then be thread-safe -- one engine per stream in the drivers).
 
     estimate_fn() -> threshold runs on rank 0 only and is broadcast (OSI / SV); None for CSI.
     Returns (global_success, global_total, global_iters, global_scored, local_results) where
-    local_results = [(item_index, success_flag)] for this rank."""
+    local_results = [(item_index, success_flag)] for this rank, in the order they finished."""
     rank, _, world = dist_env() if dist is not None else (0, 0, 1)
     thr = None
     if estimate_fn is not None:
         thr = estimate_fn() if rank == 0 else None
         thr = broadcast_threshold(thr, dist)
+    q = WorkQueue(len(items), dist, schedule, streams=streams if streams > 1 else None)
     local = []
-    succ = iters = scored = 0
-    mine = shard_indices(len(items), rank, world)
-    for i in mine:
-        flag, n_it, n_sc = attack_fn(items[i], thr)
-        local.append((i, flag))
-        succ += 1 if flag == 1 else 0
-        iters += n_it
-        scored += n_sc
-    g = reduce_counters([succ, len(mine), iters, scored], dist)
+    tot = [0, 0, 0]
+    lock = threading.Lock()
+    errors = []
+
+    def worker(k):
+        try:
+            while True:
+                i = q.next(k)
+                if i is None:
+                    return
+                flag, n_it, n_sc = attack_fn(items[i], thr)
+                with lock:
+                    local.append((i, flag))
+                    tot[0] += 1 if flag == 1 else 0
+                    tot[1] += n_it
+                    tot[2] += n_sc
+        except BaseException as ex:  # noqa: BLE001  (re-raised on the calling thread)
+            errors.append(ex)
+
+    if streams <= 1:
+        worker(0)
+    else:
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(streams)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    if errors:
+        raise errors[0]
+    g = reduce_counters([tot[0], len(local), tot[1], tot[2]], dist)
+    if g[1] != len(items):
+        raise RuntimeError("work queue handed out %d of %d attacks" % (g[1], len(items)))
     return g[0], g[1], g[2], g[3], local

@@ -5,7 +5,7 @@ import subprocess
 import sys
 import textwrap
 
-from fakebob_amd.parallel import reduce_counters, run_sharded, shard_indices
+from fakebob_amd.parallel import WorkQueue, reduce_counters, run_sharded, shard_indices
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -68,3 +68,86 @@ def test_world_size_2_gloo(tmp_path):
         assert row["g"] == want                    # identical global counters on both ranks
     locals_ = sorted(i for row in rows for i, _ in row["local"])
     assert locals_ == items                        # every utterance attacked exactly once
+
+
+def test_work_queue_single_process_dynamic_and_static():
+    for n in (0, 1, 7, 24):
+        q = WorkQueue(n)                                   # dynamic, one process: a plain counter
+        assert [q.next() for _ in range(n + 2)] == list(range(n)) + [None, None]
+        for world in (1, 2, 4):
+            for streams in (None, 3):
+                got = []
+                for r in range(world):
+                    q = WorkQueue(n, None, "static", rank=r, world=world, streams=streams)
+                    for k in range(streams or 1):
+                        while True:
+                            i = q.next(k)
+                            if i is None:
+                                break
+                            got.append(i)
+                            if streams:                    # stream k of rank r: every K-th of the rank's round-robin share
+                                assert i % world == r and (i // world) % streams == k
+                assert sorted(got) == list(range(n))
+    # K threads on one queue: every item exactly once, and a stream that draws cheap items takes more of them
+    import threading, time
+    q = WorkQueue(60)
+    took = {0: [], 1: [], 2: []}
+    def run(k):
+        while True:
+            i = q.next(k)
+            if i is None:
+                return
+            took[k].append(i)
+            time.sleep(0.02 if k == 0 else 0.001)
+    ths = [threading.Thread(target=run, args=(k,)) for k in took]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert sorted(took[0] + took[1] + took[2]) == list(range(60))
+    assert len(took[0]) < len(took[1]) and len(took[0]) < len(took[2])
+
+
+SKEW_WORKER = textwrap.dedent('''
+    import sys, json, time
+    sys.path.insert(0, %r)
+    from fakebob_amd import parallel as P
+    dist = P.init_process_group("gloo")
+    rank, _, world = P.dist_env()
+    schedule, streams = sys.argv[2], int(sys.argv[3])
+    n = 40
+    cost = [0.1 if i %% 2 == 0 else 0.005 for i in range(n)]    # 1 : 20, every expensive attack on an even index
+    last = [0.0]
+    def attack(item, thr):
+        time.sleep(cost[item])
+        last[0] = time.time()
+        return 1, 1, 51
+    dist.barrier()
+    t0 = time.time()
+    g = P.run_sharded(list(range(n)), attack, None, dist, schedule=schedule, streams=streams)
+    with open(sys.argv[1] + "/%%s_rank%%d.json" %% (schedule, rank), "w") as w:
+        json.dump({"rank": rank, "g": g[:4], "local": sorted(i for i, _ in g[4]), "busy_s": last[0] - t0}, w)
+    dist.barrier()
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_world_size_2_dynamic_queue_balances_skewed_attack_costs(tmp_path):
+    """Attack cost varies by orders of magnitude (early stop against max_iter): with the ticket queue on the process
+    group's store every attack runs exactly once and both ranks finish together, where the static round-robin deal
+    leaves one rank with all the expensive ones.  Two streams per rank, as the drivers run several."""
+    import json
+    script = tmp_path / "skew_worker.py"
+    script.write_text(SKEW_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    busy = {}
+    for port, schedule in ((29619, "dynamic"), (29621, "static")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path), schedule, "2"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:]
+        rows = [json.load(open(str(tmp_path / ("%s_rank%d.json" % (schedule, k))))) for k in range(2)]
+        assert sorted(rows[0]["local"] + rows[1]["local"]) == list(range(40))      # every attack exactly once
+        assert rows[0]["g"] == rows[1]["g"] == [40, 40, 40, 51 * 40]
+        busy[schedule] = [row["busy_s"] for row in rows]
+    d, s = busy["dynamic"], busy["static"]
+    assert abs(d[0] - d[1]) <= 0.15 * max(d), busy           # both ranks busy to the end
+    assert max(s) >= 1.5 * max(d), busy                      # what the static deal costs on this list
