@@ -100,7 +100,11 @@ int fbo_frontend(const fbo_frontend_cfg *cfg, const int16_t *wav, int64_t n,
 
 /* ---- K7 diagonal GMM (Kaldi DiagGmm internal form, float32 params) ---- */
 /* per-frame log-likelihood for one model; returns sum over frames (double);
- * ll_out (optional) gets per-frame float32 values. */
+ * ll_out (optional) gets per-frame float32 values.  The sum over components is Kaldi's VectorBase<float>::LogSumExp --
+ * components below max + log(FLT_EPSILON) are NOT summed -- unless fbo_set_logsumexp(1) asks for the full float64 sum
+ * (process-wide switch: 0 = Kaldi's function, the default; 1 = every component). */
+void fbo_set_logsumexp(int full_sum);
+int fbo_get_logsumexp(void);
 double fbo_diag_gmm_loglikes(const float *gconsts, const float *means_invvars,
                              const float *inv_vars, int C, int D,
                              const float *feats, int Tv, float *ll_out);

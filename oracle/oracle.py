@@ -165,6 +165,14 @@ def frontend(cfg, wav):
     return f[:tv].copy(), To.value
 
 
+def set_logsumexp(full_sum):
+    """Process-wide: False (default) = Kaldi's VectorBase<float>::LogSumExp in the diagonal-GMM frame log-likelihood
+    (components below max + log(FLT_EPSILON) are not summed), True = the full float64 sum.  Returns the old setting."""
+    old = bool(lib().fbo_get_logsumexp())
+    lib().fbo_set_logsumexp(C.c_int(1 if full_sum else 0))
+    return old
+
+
 def diag_gmm_loglikes(gconsts, miv, iv, feats):
     gconsts = np.ascontiguousarray(gconsts, np.float32)
     miv = np.ascontiguousarray(miv, np.float32)
