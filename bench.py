@@ -780,10 +780,10 @@ def main():
 def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
     """Whole attacks with the early stop ON (FAKEBOB.py:181-191), as attackMain.py:324-409 runs them: `n_utts` synthetic
     utterances against the headline system, each with the speaker it already scores highest for as the target and the
-    system threshold a seeded 0.02 ... 0.15 above that score, so the attacks need between a handful and several dozen
-    NES iterations (max_iter caps the rest).  The K engines of the GPU take them from fakebob_amd.parallel.WorkQueue --
+    system threshold calibrated (untimed pass) so that the attack stops at a seeded iteration between 8 and 60.  The K engines of the GPU take them from fakebob_amd.parallel.WorkQueue --
     dealt in advance (`static`: stream k takes every K-th, what rounds 1 - 4 did) or drawn when a stream is free
     (`dynamic`) --, alternating, `reps` times each: wall-clock attacks/s and NES iterations/s, the median run of each.
+    (trace rows = iterations run: the stopping iteration included.)
     Upload of the audio, read-back of the adversarial audio and trace included (fb_attack)."""
     import threading
     import numpy as np
@@ -792,13 +792,26 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
     from fakebob_amd.models import synthetic_audio
     K = len(engs)
     rng = np.random.default_rng(77)
-    items = []
+    items, wanted = [], []
     for u in range(n_utts):
         a = synthetic_audio(200 + u, N_SAMPLES)
         raw, _ = engs[0].score_raw([(a * 32768.0).astype(np.int16)])
         sc = raw[0, 1:] - raw[0, 0]
         tgt = int(np.argmax(sc))
-        kw = dict(kw_common, target=tgt, threshold=float(sc[tgt]) + float(0.02 + 0.13 * rng.random()), max_iter=max_iter)
+        # calibration (untimed): the attack with an unreachable threshold -- with the target already the best speaker the
+        # loss is threshold - s_target, a constant shift that the antithetic estimate cancels -- gives the target score of
+        # the clean iterate per iteration; the threshold of the timed attack sits between the record before a seeded
+        # iteration n in [8, 60] and the score at n, so the early stop fires there (or an iteration or two beside it)
+        kw = dict(kw_common, target=tgt, threshold=float(sc[tgt]) + 10.0, max_iter=72)
+        _adv, _flag, _advf, tr = engs[0].attack(nes_params("OSI", "targeted", seed=42, stream=1000 + u, **kw), a)
+        st = tr[:, 3 + tgt]
+        rec = np.maximum.accumulate(st)
+        want = int(rng.integers(8, 61))
+        cand = [i for i in range(want, len(st)) if st[i] > rec[i - 1]]
+        n_u = cand[0] if cand else int(np.argmax(st))
+        thr = 0.5 * (float(rec[n_u - 1]) + float(st[n_u])) if n_u > 0 else float(st[0]) - 1e-3
+        wanted.append(n_u)
+        kw = dict(kw_common, target=tgt, threshold=thr, max_iter=max_iter)
         items.append((a, nes_params("OSI", "targeted", seed=42, stream=1000 + u, **kw)))
     rows, flags = [0] * n_utts, [0] * n_utts
 
@@ -834,7 +847,8 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
         for sch in ("static", "dynamic"):
             res[sch].append(run(sch))
     out = {"attacks": n_utts, "attacks_in_flight": K, "max_iter": max_iter, "early_stop": True,
-           "iterations_per_attack": list(rows), "successes": int(sum(1 for f in flags if f == 1)),
+           "iterations_per_attack": list(rows), "calibrated_stop_iterations": wanted,
+           "successes": int(sum(1 for f in flags if f == 1)),
            "iterations_total": int(sum(rows)),
            "note": "whole attacks through fb_attack with the early stop ON; the same %d attacks (Philox stream = attack "
                    "index: identical trajectories) dealt statically over the streams or drawn from the ticket queue" % n_utts}

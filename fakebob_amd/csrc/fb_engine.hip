@@ -101,6 +101,9 @@ struct fb_engine {
   int iv_zeroC = -1;  // ... for this component count (position of the zero rows)
   int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
   DevBuf iv_prog, iv_ticket;  // k_iv_solve_rw: progress words, ticket
+  DevBuf iv_tail_counter;     // arrivals of the solve kernels' fused tail (fb_iv_tail.h)
+  bool tail_loss_req = false, tail_loss_done = false;  // enqueue_get_grad asks run_scoring to take the loss body along / it did
+  FbIvTail tail_req = {};
   unsigned iv_rw_epoch = 0;
   int iv_rw_B = -1, iv_rw_R = -1;
   bool iv_linv_dirty = false;  // k_iv_solve_ll used the slot buffer as plain scratch: refill before k_iv_solve_rw polls it
@@ -238,7 +241,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -1341,22 +1344,40 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
                           e->iv_fail.as<int>());
     FBCHK(time_end(e));
     FB_DBG_SYNC(e, "contract");
+    // the back-end and, inside the NES loop, the loss body run in the solve kernels' tail (fb_iv_tail.h); FB_IV_TAIL=split
+    // keeps the separate k_iv_backend / k_loss launches (A/B, tests: same numbers bit for bit)
+    FbIvTail tail = {};
+    {
+      const char *tv_env = getenv("FB_IV_TAIL");
+      const bool split = tv_env && strcmp(tv_env, "split") == 0;
+      if (!e->iv_tail_counter.p) {
+        FBCHK(e->iv_tail_counter.ensure(sizeof(int)));
+        HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), s));
+      }
+      if (!split) {
+        if (e->tail_loss_req && fb_iv_tail_takes_loss(B)) { tail = e->tail_req; tail.loss = 1; }
+        tail.backend = 1;
+        tail.llr = e->raw.as<double>();
+        tail.counter = e->iv_tail_counter.as<int>();
+      }
+    }
+    e->tail_loss_done = tail.loss != 0;
     FBCHK(time_begin(e, 2));
     // FB_IV_SOLVE=ll keeps the one-workgroup-per-matrix kernel (A/B); otherwise the row-wise kernel whenever its grid of
     // 5 workgroups per matrix is resident at once, which is when the chip has idle units to give it
     if (fb_iv_use_rw(e) &&
         fb_launch_iv_solve_rw(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B, e->iv_A.as<double>(),
                               e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>(), e->iv_prog.as<unsigned>(),
-                              e->iv_ticket.as<int>(), e->iv_rw_epoch + 1)) {
+                              e->iv_ticket.as<int>(), e->iv_rw_epoch + 1, tail)) {
       e->iv_rw_epoch += 1;
     } else {
       e->iv_linv_dirty = true;
       fb_launch_iv_solve_ll(s, iv, e->iv_quad.as<double>(), e->iv_linp.as<double>(), e->iv_kchunks, B,
-                            e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>());
+                            e->iv_A.as<double>(), e->iv_linv.as<double>(), e->iv_ivec.as<double>(), e->iv_fail.as<int>(), tail);
     }
     FBCHK(time_end(e, 2));
     FB_DBG_SYNC(e, "solve");
-    fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
+    if (!tail.backend) fb_launch_iv_backend(s, iv, e->iv_ivec.as<double>(), B, e->raw.as<double>());
     FB_DBG_SYNC(e, "backend");
   }
   HIPCHK(hipGetLastError());
@@ -1836,11 +1857,27 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   // GMM systems inside the device-controlled loop: finalisation and loss share one launch
   const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_on(e);
   e->defer_finalize = fuse_fin;
+  if (e->kind == 1) {  // i-vector systems: the loss body rides in the tail of the solve kernel when the batch allows it
+    FbIvTail &t = e->tail_req;
+    t = FbIvTail{};
+    t.tv = e->tv.as<int>();
+    t.task = p->task; t.attack_type = p->attack_type;
+    t.z_mean = e->zmean.as<double>(); t.z_std = e->zstd.as<double>();
+    t.threshold = p->threshold; t.adver_thresh = p->adver_thresh;
+    t.target = p->target; t.true_label = p->true_label;
+    t.dist_part = e->dist_part.as<double>(); t.n_dist_part = with_dist ? ndp : 0;
+    t.scores = e->scores.as<double>(); t.loss_out = e->loss.as<double>();
+    t.out = e->nes_out.as<FbNesDev>(); t.ctl = ctl; t.trace = trace_dev; t.it = trace_row;
+    e->tail_loss_req = true;
+  }
+  e->tail_loss_done = false;
   const int rc = run_scoring(e, B, e->h_frame_off[B]);
+  e->tail_loss_req = false;
   e->defer_finalize = false;
   e->fe.stop = nullptr;
   e->gmm.stop = nullptr;
   FBCHK(rc);
+  if (e->tail_loss_done) return FB_OK;
   if (fuse_fin) {
     if (!e->fin_counter.p) {
       FBCHK(e->fin_counter.ensure(sizeof(int)));
@@ -1888,6 +1925,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     // mis-assign utterances / skip its loss body.  A new attack starts them clean.
     if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
     if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+    if (e->iv_tail_counter.p) HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), e->stream));
     e->vad_part_B = -1;  // ... and k_vad_delta_cmvn_p's exchange slots are refilled with sentinels (run_post_mfcc)
     FbCtlDev h;
     memset(&h, 0, sizeof(h));

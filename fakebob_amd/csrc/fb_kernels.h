@@ -251,6 +251,33 @@ struct FbIvDev {
   const double *plda_psi;       // [L]
   const double *train;          // [S][L] enrolled i-vectors in PLDA space
 };
+// What the posterior-solve kernels run BEHIND the solution of an utterance (round 5; fb_iv_tail.h): the back-end
+// (ivector-subtract-global-mean | transform-vec | ivector-normalize-length, ivector-plda-scoring: k_iv_backend's body) in
+// the workgroup that holds the solution, and -- inside the NES loop -- the loss / loop-control body of k_loss in the
+// workgroup that finishes last (arrival counter, left at zero).  backend = 0: the solve kernels stop at the i-vectors
+// and the caller launches k_iv_backend / k_loss itself (FB_IV_TAIL=split, shapes the tail does not take).
+struct FbIvTail {
+  int backend;          // 1: llr[b][s] written by the solving workgroup
+  int loss;             // 1 (needs backend): the last arriver runs fb_loss_body<true, true>
+  double *llr;          // [B][S]
+  int *counter;         // arrivals (one int, zero before the first launch)
+  const int *tv;
+  int task, attack_type;
+  const double *z_mean, *z_std;
+  double threshold, adver_thresh;
+  int target, true_label;
+  const double *dist_part;
+  int n_dist_part;
+  double *scores, *loss_out;
+  FbNesDev *out;
+  FbCtlDev *ctl;
+  double *trace;
+  int it;
+};
+// doubles of LDS the tail needs behind the solve's own areas (back-end vectors + the loss body's two buffers)
+size_t fb_iv_tail_lds_doubles(const FbIvDev &iv);
+// true when the tail's loss part can run fused for a batch of B utterances (numpy's sum as one block: B - 1 <= 128)
+bool fb_iv_tail_takes_loss(int B);
 void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, const double *sinv_packed,
                          double *sim, double *u);
 // bucket_ws: fb_iv_bucket_ws_ints() ints of workspace, zero before the first use; pairs / llf: rows_cap * nsel
@@ -267,7 +294,7 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // ivector_solve.hip (k_iv_solve_ll): quad is consumed (factored in place); Aall = B x R right-hand sides + a row of
 // R + 64 zeros behind them
 void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                           int B, double *Aall, double *LinvAll, double *ivec, int *fail);
+                           int B, double *Aall, double *LinvAll, double *ivec, int *fail, const FbIvTail &tail);
 // k_iv_solve_rw: the same system with the block rows of a matrix dealt over five workgroups (up-looking Cholesky); false
 // = B x 5 workgroups are more than the chip holds at once (the caller runs fb_launch_iv_solve_ll).  LinvAll: TWO slot
 // sets (fb_iv_solve_rw_linv_doubles), every 64-bit word 0x7ff87ff87ff87ff8 before the first launch and whenever `epoch`
@@ -275,5 +302,6 @@ void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad,
 size_t fb_iv_solve_rw_linv_doubles(const FbIvDev &iv, int B);
 size_t fb_iv_solve_rw_prog_words(const FbIvDev &iv, int B);
 bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks, int B,
-                           double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch);
+                           double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch,
+                           const FbIvTail &tail);
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr);

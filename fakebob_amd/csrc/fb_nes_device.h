@@ -77,6 +77,8 @@ __device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
   return ret;
 }
 
+#define FB_LOSS_LDS 1024
+#define FB_SC_LDS 2048
 // SMALL: samples_per_draw <= 128 -- numpy's sum is a single block then and the kernel needs no
 // recursion stack (the stack lives in scratch memory, which also slows the dispatch down)
 // FUSED: the caller is the last workgroup of k_gmm_finalize_loss; raw[] was written by OTHER workgroups of the same
@@ -90,7 +92,8 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
                                               const double *__restrict__ dist_part, int n_dist_part,
                                               double *__restrict__ scores, double *__restrict__ loss,
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
-                                              double *__restrict__ trace, int it) {
+                                              double *__restrict__ trace, int it, double *__restrict__ s_lv,
+                                              double *__restrict__ s_sc) {
   const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
   __shared__ int s_errw[16];
   // The decisions at the end are one thread's work: everything it needs from global memory is requested HERE and
@@ -98,9 +101,10 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
   // "no voiced frames" flag is reduced over the waves at the end instead of being initialised in LDS first).  Read
   // where they were used, the control block, the window of recent losses, the raw scores (a run-time loop: one L2
   // round trip per model) and the losses were ~20 dependent round trips, 9 of the fused kernel's 18 us.
-  constexpr int FB_LS_LOCAL = 8, FB_LOSS_LDS = 1024, FB_SC_LDS = 2048;
-  __shared__ double s_lv[FB_LOSS_LDS];  // the losses of this iteration (B <= FB_LOSS_LDS; otherwise read back from `loss`)
-  __shared__ double s_sc[FB_SC_LDS];    // the scores while the loss is formed from them (B S <= FB_SC_LDS; otherwise in `scores`)
+  // s_lv[FB_LOSS_LDS]: the losses of this iteration (B <= FB_LOSS_LDS; otherwise read back from `loss`); s_sc[FB_SC_LDS]: the
+  // scores while the loss is formed from them (B S <= FB_SC_LDS; otherwise in `scores`) -- LDS of the caller (static
+  // arrays in the small kernels, a piece of the dynamic allocation in the solve kernels' tail)
+  constexpr int FB_LS_LOCAL = 8;
   const bool sc_lds = (size_t)B * S <= FB_SC_LDS;
   const double dist_first = (int)threadIdx.x < n_dist_part ? dist_part[threadIdx.x] : 0.0;  // in flight with the rest
   FbCtlDev c = {};

@@ -691,8 +691,9 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];
   fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
-                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
+                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc);
 }
 void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                                  int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,

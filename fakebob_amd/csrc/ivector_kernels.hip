@@ -27,6 +27,7 @@
 
 #include "fb_device.h"
 #include "fb_kernels.h"
+#include "fb_iv_tail.h"
 
 typedef double fb_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64
 
@@ -1091,94 +1092,23 @@ void fb_launch_iv_contract(hipStream_t s, const FbIvDev &iv, const double *gamma
 // (K10c, the posterior systems: ivector_solve.hip)
 
 // ------------------------------------------------------ back-end (K11/K12)
-__device__ __forceinline__ double fb_block_sum(double v, double *red) {
-  v = fb_wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += red[w];
-  return r;
-}
-// One workgroup of 1024 threads per utterance.  The two mat-vecs (LDA: L x R, PLDA transform: L x L) are split four
-// ways along the contraction index -- thread (g, t) sums a quarter of the products of output t, the quarters are added
-// in fixed order -- so that a lane's dependent chain is R/4 loads long instead of R, with 20 - 25 of them in flight (the
-// kernel is a latency chain: 77 us with 256 threads and whole dot products per thread, 35 with 8 loads in flight, 30 with
-// 20; five shares over 1000 threads measured the same as four).
+// One workgroup of 1024 threads per utterance: fb_iv_backend_body (fb_iv_tail.h) as a kernel of its own -- what runs when
+// the solve kernels' tail does not take the back-end along (FB_IV_TAIL=split, A/B and tests).  The two mat-vecs (LDA: L x
+// R, PLDA transform: L x L) are split four ways along the contraction index -- thread (g, t) sums a quarter of the
+// products of output t, the quarters are added in fixed order -- so that a lane's dependent chain is R/4 loads long
+// instead of R, with 20 - 25 of them in flight (the kernel is a latency chain: 77 us with 256 threads and whole dot
+// products per thread, 35 with 8 loads in flight, 30 with 20; five shares over 1000 threads measured the same as four).
 __global__ __launch_bounds__(1024) void k_iv_backend(FbIvDev iv, const double *__restrict__ ivec,
                                                      double *__restrict__ llr) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
-  __shared__ double red[16];
-  const int R = iv.R, L = iv.L, S = iv.S, b = blockIdx.x, tid = threadIdx.x;
-  const int g = tid >> 8, t = tid & 255;
-  double *x = smd, *z = x + R, *y = z + L, *part = y + L;  // part[4][L]
-  for (int r = tid; r < R; r += 1024) x[r] = (double)(float)ivec[(size_t)b * R + r] - iv.mean_vec[r];
+  const int R = iv.R, b = blockIdx.x;
+  for (int r = threadIdx.x; r < R; r += 1024) smd[r] = (double)(float)ivec[(size_t)b * R + r] - iv.mean_vec[r];
   __syncthreads();
-  {
-    const int r0 = (int)((long long)R * g / 4), r1 = (int)((long long)R * (g + 1) / 4);
-    for (int l = t; l < L; l += 256) {
-      double acc = (g == 0 && iv.lda_cols == R + 1) ? iv.ldaT[(size_t)R * L + l] : 0.0;
-#pragma unroll 20
-      for (int r = r0; r < r1; ++r) acc = fma(iv.ldaT[(size_t)r * L + l], x[r], acc);
-      part[g * L + l] = acc;
-    }
-  }
-  __syncthreads();
-  double nrm = 0.0;
-  if (g == 0)
-    for (int l = t; l < L; l += 256) {
-      const double acc = ((part[l] + part[L + l]) + part[2 * L + l]) + part[3 * L + l];
-      z[l] = acc;
-      nrm = fma(acc, acc, nrm);
-    }
-  nrm = sqrt(fb_block_sum(nrm, red));
-  const double ratio = nrm / sqrt((double)L);
-  __syncthreads();
-  for (int l = tid; l < L; l += 1024) z[l] = (ratio != 0.0 ? z[l] / ratio : z[l]) - iv.plda_mean[l];
-  __syncthreads();
-  {
-    const int m0 = (int)((long long)L * g / 4), m1 = (int)((long long)L * (g + 1) / 4);
-    for (int l = t; l < L; l += 256) {
-      double acc = 0.0;
-#pragma unroll 25
-      for (int m = m0; m < m1; ++m) acc = fma(iv.pldaT[(size_t)m * L + l], z[m], acc);
-      part[g * L + l] = acc;
-    }
-  }
-  __syncthreads();
-  double dot = 0.0;
-  if (g == 0)
-    for (int l = t; l < L; l += 256) {
-      const double acc = ((part[l] + part[L + l]) + part[2 * L + l]) + part[3 * L + l];
-      y[l] = acc;
-      dot += acc * acc / (iv.plda_psi[l] + 1.0);
-    }
-  dot = fb_block_sum(dot, red);
-  const double nf = sqrt((double)L / dot);
-  __syncthreads();
-  for (int l = tid; l < L; l += 1024) y[l] *= nf;
-  __syncthreads();
-  const double LOG2PI = 1.8378770664093454835606594728112;
-  for (int s = 0; s < S; ++s) {
-    const double *tr = iv.train + (size_t)s * L;
-    double given = 0.0, without = 0.0;
-    for (int l = tid; l < L; l += 1024) {
-      const double psi = iv.plda_psi[l];
-      const double mean = psi / (psi + 1.0) * tr[l];
-      const double var = 1.0 + psi / (psi + 1.0);
-      const double d = y[l] - mean;
-      given += log(var) + d * d / var;
-      without += log(psi + 1.0) + y[l] * y[l] / (psi + 1.0);
-    }
-    given = fb_block_sum(given, red);
-    without = fb_block_sum(without, red);
-    if (tid == 0) {
-      const double sc_ = -0.5 * (given + LOG2PI * L) - (-0.5 * (without + LOG2PI * L));
-      llr[(size_t)b * S + s] = iv.text_scores ? fb_round6(sc_) : sc_;  // ivector-plda-scoring writes text
-    }
-  }
+  fb_iv_backend_body<1024, false>(iv, b, smd, llr);
 }
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr) {
-  size_t shm = sizeof(double) * (size_t)(iv.R + 6 * iv.L);
+  const size_t shm = sizeof(double) * (size_t)fb_ivt_backend_doubles(iv.R, iv.L);
   hipLaunchKernelGGL(k_iv_backend, dim3(B), dim3(1024), shm, s, iv, ivec, llr);
 }
+size_t fb_iv_tail_lds_doubles(const FbIvDev &iv) { return (size_t)fb_ivt_backend_doubles(iv.R, iv.L) + FB_LOSS_LDS + FB_SC_LDS; }
+bool fb_iv_tail_takes_loss(int B) { return B - 1 <= 128 && B <= FB_LOSS_LDS; }

@@ -27,6 +27,7 @@
 
 #include "fb_device.h"
 #include "fb_kernels.h"
+#include "fb_iv_tail.h"
 
 typedef double fb_d4 __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64
 typedef double fb_d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load from an 8-byte aligned packed row
@@ -249,7 +250,7 @@ template <int NTR>
 __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restrict__ quad, const double *__restrict__ linp,
                                                      int n_kchunks, int B, double *__restrict__ AugAll,
                                                      double *__restrict__ LinvAll, double *__restrict__ ivec,
-                                                     int *__restrict__ fail) {
+                                                     int *__restrict__ fail, FbIvTail tail) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
   const int R = iv.R, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -359,7 +360,11 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
     // ---- phase 2: wave 0 factors the block and inverts the factor (registers only); L11 -> A, L11^-1 -> Di, Lg
     if (wv == 0) {
       double X[FB_SV_NB];
-      const int rr = lane & 31;
+      // (rr passes through an empty asm: the 32 identity values (rr == c ? 1 : 0) below do not change from panel to
+      //  panel, so hipcc computed them once in front of the panel loop and -- 64 registers that cannot stay live across
+      //  it -- spilled them: the kernels' 65 / 104 spilled registers of round 4.  Two instructions each, made in place.)
+      int rr = lane & 31;
+      asm volatile("" : "+v"(rr));
       if (lane < FB_SV_NB) {
 #pragma unroll
         for (int c = 0; c < FB_SV_NB; ++c) {
@@ -438,7 +443,9 @@ __global__ __launch_bounds__(512) void k_iv_solve_ll(FbIvDev iv, double *__restr
   for (int r = tid; r < R; r += nt) rhs[r] = aug[r];
   __syncthreads();
   fb_sv_backsub(Q, aug_off, R, npanel, Lg, rhs, Di, Dg, tid, nt);
-  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
+  // the i-vector row, then -- in this workgroup, which holds the solution -- the back-end, and in the workgroup that
+  // finishes last the loss body (fb_iv_tail.h); everything behind rhs is free now
+  fb_iv_tail_run<512>(iv, tail, b, B, rhs, ivec, Dg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
                                                      int n_kchunks, int B, double *__restrict__ AugAll,
                                                      double *__restrict__ LinvAll, double *__restrict__ ivec,
                                                      int *__restrict__ fail, unsigned *__restrict__ prog,
-                                                     int *__restrict__ ticket, unsigned epoch) {
+                                                     int *__restrict__ ticket, unsigned epoch, FbIvTail tail) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
   __shared__ int s_tk;
   const int R = iv.R, tid = threadIdx.x, nt = blockDim.x;
@@ -732,7 +739,8 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     if (has_diag) {
       if (wv == 0) {
         double X[FB_SV_NB];
-        const int rr = lane & 31;
+        int rr = lane & 31;              // (through an empty asm: see k_iv_solve_ll -- keeps the identity values out of
+        asm volatile("" : "+v"(rr));     //  the block-row loop's preheader, where they were spilled)
         if (lane < FB_SV_NB) {
 #pragma unroll
           for (int cc = 0; cc < FB_SV_NB; ++cc) {
@@ -792,7 +800,10 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
   __syncthreads();
   fb_sv_backsub(Q, aug_off, R, npanel, Lcur, rhs, Di, Dg, tid, nt);
   RW_STAMP(15, 1);
-  for (int r = tid; r < R; r += nt) ivec[(size_t)b * R + r] = rhs[r] - (r == 0 ? iv.prior_offset : 0.0);
+  // the i-vector row, the back-end of this utterance and -- in the matrix owner that finishes last -- the loss body
+  // (fb_iv_tail.h), in the row area behind what the back substitution used
+  fb_iv_tail_run<512>(iv, tail, b, B, rhs, ivec, rhs + (((R + 1) & ~1) + FB_SV_NB + 16 * FB_SV_LD));
+  RW_STAMP(15, 2);
 }
 
 // LinvAll: TWO slot sets of B x npanel x 32 x 32 doubles, every word FB_RW_SENT before the first launch / after an epoch
@@ -807,7 +818,7 @@ size_t fb_iv_solve_rw_prog_words(const FbIvDev &iv, int B) { return (size_t)B * 
 template <int G>
 static bool launch_solve_rw(hipStream_t s, size_t shm, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
                             int B, double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket,
-                            unsigned epoch) {
+                            unsigned epoch, const FbIvTail &tail) {
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (fb_device_needs_optin(optin, &bit)) {  // one workgroup per compute unit: more than half of its LDS
@@ -816,7 +827,7 @@ static bool launch_solve_rw(hipStream_t s, size_t shm, const FbIvDev &iv, const 
     optin.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(k_iv_solve_rw<G>, dim3(B * G), dim3(512), std::max(shm, (size_t)82 * 1024), s, iv,
-                     const_cast<double *>(quad), linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+                     const_cast<double *>(quad), linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch, tail);
   return true;
 }
 // workgroups per matrix: FB_RW_G, fewer when B x FB_RW_G workgroups would not be resident at once (FB_IV_RW_G = 2 | 3 | 5
@@ -831,23 +842,25 @@ int fb_iv_solve_rw_groups(int B) {
   return g;
 }
 bool fb_launch_iv_solve_rw(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks, int B,
-                           double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch) {
+                           double *Aall, double *LinvAll, double *ivec, int *fail, unsigned *prog, int *ticket, unsigned epoch,
+                           const FbIvTail &tail) {
   const int R = iv.R, G = fb_iv_solve_rw_groups(B);
   if (B * G > 256 || R < 64) return false;
   const int npanel = (R + FB_SV_NB - 1) / FB_SV_NB;
   const size_t rowd = (size_t)FB_SV_NB * (FB_SV_NB * npanel + 2), bsd = ((R + 1) & ~1) + FB_SV_NB + 16 * FB_SV_LD;
-  const size_t shm = sizeof(double) * (std::max(rowd, bsd) + FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17);
+  const size_t tld = tail.backend ? bsd + fb_iv_tail_lds_doubles(iv) : 0;   // the tail works behind the back substitution's area
+  const size_t shm = sizeof(double) * (std::max(std::max(rowd, bsd), tld) + FB_SV_NB * FB_SV_LD + 128 + FB_SV_NB * FB_SV_LDC + 4 * 16 * 17);
   if (shm > 150 * 1024 || R > 448) return false;
   switch (G) {
-    case 2: return launch_solve_rw<2>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
-    case 3: return launch_solve_rw<3>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
-    default: return launch_solve_rw<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch);
+    case 2: return launch_solve_rw<2>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch, tail);
+    case 3: return launch_solve_rw<3>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch, tail);
+    default: return launch_solve_rw<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, prog, ticket, epoch, tail);
   }
 }
 
 template <int NTR>
 static void launch_solve_ll(hipStream_t s, size_t shm, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                            int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
+                            int B, double *Aall, double *LinvAll, double *ivec, int *fail, const FbIvTail &tail) {
   static std::atomic<unsigned long long> optin{0};
   unsigned long long bit = 0;
   if (shm > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {
@@ -855,12 +868,14 @@ static void launch_solve_ll(hipStream_t s, size_t shm, const FbIvDev &iv, const 
       optin.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(k_iv_solve_ll<NTR>, dim3(B), dim3(512), shm, s, iv, const_cast<double *>(quad), linp, n_kchunks, B, Aall,
-                     LinvAll, ivec, fail);
+                     LinvAll, ivec, fail, tail);
 }
 void fb_launch_iv_solve_ll(hipStream_t s, const FbIvDev &iv, const double *quad, const double *linp, int n_kchunks,
-                           int B, double *Aall, double *LinvAll, double *ivec, int *fail) {
+                           int B, double *Aall, double *LinvAll, double *ivec, int *fail, const FbIvTail &tail) {
   const int R = iv.R;
-  const size_t shm = sizeof(double) * (((R + 1) & ~1) + 2 * FB_SV_NB * FB_SV_LD + 128 + 8 * 16 * FB_SV_LDC + 16 * FB_SV_LD);
-  if (R + 1 <= 7 * 16 * 4) launch_solve_ll<4>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
-  else launch_solve_ll<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail);
+  const size_t own = ((R + 1) & ~1) + 2 * FB_SV_NB * FB_SV_LD + 128 + 8 * 16 * FB_SV_LDC + 16 * FB_SV_LD;
+  const size_t tld = tail.backend ? ((R + 1) & ~1) + fb_iv_tail_lds_doubles(iv) : 0;   // the tail re-uses everything behind rhs
+  const size_t shm = sizeof(double) * std::max(own, tld);
+  if (R + 1 <= 7 * 16 * 4) launch_solve_ll<4>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, tail);
+  else launch_solve_ll<5>(s, shm, iv, quad, linp, n_kchunks, B, Aall, LinvAll, ivec, fail, tail);
 }

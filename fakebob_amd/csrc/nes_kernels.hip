@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void k_loss(const double *__restrict__ raw, co
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                               double *__restrict__ trace, int it) {
   if (ctl && ctl->stop) return;  // queued behind the stopping iteration
+  __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];
   fb_loss_body<SMALL, false>(raw, tv, B, M, task, znorm_all, attack_type, z_mean, z_std, threshold, adver_thresh, target,
-                             true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it);
+                             true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc);
 }
 
 void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int M, int task, int znorm_all,

@@ -111,3 +111,50 @@ def test_ivector_attack_trajectory(engine, oracle, small_iv):
     # observed on MI355X: 0 differing samples (the update is sign(momentum gradient); a flip needs a gradient
     # entry within the 1e-4-scale score error of zero) -- asserted exactly, not as a rate
     assert int(np.sum(adv_g != adv_o)) == 0
+
+
+@pytest.mark.parametrize("solve", ["ll", "rw"])
+def test_solve_tail_equals_the_separate_backend_and_loss_launches(engine, oracle, monkeypatch, solve):
+    """Round 5: the back-end of an utterance runs in the tail of the solve kernel's workgroup that holds its solution,
+    and inside the NES loop the last of those workgroups to arrive runs the loss / loop-control body (fb_iv_tail.h).
+    FB_IV_TAIL=split keeps the separate k_iv_backend / k_loss launches: the same operations in the same order, so scores,
+    gradient estimates, attack traces and adversarial audio must be identical bit for bit -- for both solve kernels, a
+    ragged scoring batch, get_grad and an attack that stops early (its queued iterations find the stop flag raised and
+    the tail's arrival counter must come back to zero for the next attack)."""
+    sy = synthetic_ivector_system(C=256, D=72, R=100, L=50, n_speakers=3, seed=5)
+    sy = sy.with_enrolled(sy.enrolled, z_mean=[-30.0, -50.0, -20.0], z_std=[5.0, 8.0, 4.0])
+    monkeypatch.setenv("FB_IV_SOLVE", solve)
+    wavs = [_wav(0), _wav(1, 9000), _wav(2, 30000), _wav(3, 1700)]
+    audio = synthetic_audio(4, 16000)
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=8)
+
+    def run():
+        engine.load_ivector(sy, "OSI")
+        llr, tv = engine.score_raw(wavs)
+        ivs = engine.debug_ivectors(len(wavs), sy.R)
+        p = nes_params("OSI", "targeted", samples_per_draw=8, seed=3, stream=1, target=1, threshold=0.5)
+        gg = engine.get_grad(p, audio, it=2)
+        s0 = engine.system_scores(engine.score_raw([(audio * 32768).astype(np.int16)])[0])[0]
+        # an attack that needs a few iterations: the target is the best speaker, the threshold just above its score
+        tgt = int(np.argmax(s0))
+        pa = nes_params("OSI", "targeted", samples_per_draw=8, seed=11, stream=0, max_iter=30, target=tgt,
+                        threshold=float(s0[tgt]) + 0.02, epsilon=0.004, max_lr=0.002)
+        a1 = engine.attack(pa, audio)
+        a2 = engine.attack(pa, audio)          # back to back: the counters of the first are clean again
+        return llr, ivs, gg, a1, a2
+
+    monkeypatch.setenv("FB_IV_TAIL", "split")
+    ref = run()
+    monkeypatch.delenv("FB_IV_TAIL", raising=False)
+    got = run()
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+    assert ref[2][0] == got[2][0] and ref[2][2] == got[2][2]
+    assert np.array_equal(ref[2][1], got[2][1]) and np.array_equal(ref[2][3], got[2][3])
+    for a in (got[3], got[4]):
+        assert a[1] == ref[3][1] and np.array_equal(a[0], ref[3][0]) and np.array_equal(a[2], ref[3][2])
+        assert np.array_equal(a[3], ref[3][3])
+    print("attack of the tail test: flag %d after %d iterations" % (got[3][1], got[3][3].shape[0]))
+    assert 1 < got[3][3].shape[0] <= 30
+    llr_o, ivs_o, _ = ctx.score_batch(wavs)
+    assert np.abs(got[0] - llr_o).max() <= 1e-7
+    assert np.abs(got[1] - ivs_o).max() <= 1e-9 * max(1.0, np.abs(ivs_o).max())
