@@ -26,8 +26,9 @@ __host__ __device__ __forceinline__ int fb_ivt_backend_doubles(int R, int L) { r
 
 // x[0 .. R) holds ivec - mean.vec on entry (LDS, first R doubles of `scr`); writes llr[b][0 .. S) (agent-scope stores when
 // `agent`: another workgroup of the same launch reads them).  All NT threads of the workgroup call.
-template <int NT, bool AGENT>
-__device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, double *__restrict__ scr, double *__restrict__ llr) {
+template <int NT>
+__device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, double *__restrict__ scr, double *__restrict__ llr,
+                                                   const bool agent) {
   static_assert(NT == 1024 || NT == 512 || NT == 256, "256 threads per share group");
   constexpr int NG = NT / 256, SH = 4 / NG;   // share groups of 256 threads, shares per group
   const int R = iv.R, L = iv.L, S = iv.S, tid = threadIdx.x;
@@ -50,16 +51,18 @@ __device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, dou
       } else {
         // the shares of a thread advance together (independent chains: twice the loads in flight); a share's own
         // order is unchanged.  Shares differ in length by at most one row.
-        const int n = r1[0] - r0[0];
-        int i = 0;
-#pragma unroll 10
-        for (; i < n; ++i) {
+        int n = r1[0] - r0[0];
 #pragma unroll
-          for (int u = 0; u < SH; ++u)
-            if (r0[u] + i < r1[u]) acc[u] = fma(iv.ldaT[(size_t)(r0[u] + i) * L + l], x[r0[u] + i], acc[u]);
+        for (int u = 1; u < SH; ++u) n = min(n, r1[u] - r0[u]);
+        // (no guards inside: a conditional load is not batched with its neighbours, and the chain of 200 dependent L2
+        //  round trips that resulted cost 100 us -- measured)
+#pragma unroll 10
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+          for (int u = 0; u < SH; ++u) acc[u] = fma(iv.ldaT[(size_t)(r0[u] + i) * L + l], x[r0[u] + i], acc[u]);
         }
 #pragma unroll
-        for (int u = 1; u < SH; ++u)
+        for (int u = 0; u < SH; ++u)
           for (int r = r0[u] + n; r < r1[u]; ++r) acc[u] = fma(iv.ldaT[(size_t)r * L + l], x[r], acc[u]);
       }
 #pragma unroll
@@ -94,16 +97,16 @@ __device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, dou
 #pragma unroll 25
         for (int m = m0[0]; m < m1[0]; ++m) acc[0] = fma(iv.pldaT[(size_t)m * L + l], z[m], acc[0]);
       } else {
-        const int n = m1[0] - m0[0];
-        int i = 0;
-#pragma unroll 10
-        for (; i < n; ++i) {
+        int n = m1[0] - m0[0];
 #pragma unroll
-          for (int u = 0; u < SH; ++u)
-            if (m0[u] + i < m1[u]) acc[u] = fma(iv.pldaT[(size_t)(m0[u] + i) * L + l], z[m0[u] + i], acc[u]);
+        for (int u = 1; u < SH; ++u) n = min(n, m1[u] - m0[u]);
+#pragma unroll 12
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+          for (int u = 0; u < SH; ++u) acc[u] = fma(iv.pldaT[(size_t)(m0[u] + i) * L + l], z[m0[u] + i], acc[u]);
         }
 #pragma unroll
-        for (int u = 1; u < SH; ++u)
+        for (int u = 0; u < SH; ++u)
           for (int m = m0[u] + n; m < m1[u]; ++m) acc[u] = fma(iv.pldaT[(size_t)m * L + l], z[m], acc[u]);
       }
 #pragma unroll
@@ -142,7 +145,7 @@ __device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, dou
     if (tid == 0) {
       double sc_ = -0.5 * (given + LOG2PI * L) - (-0.5 * (without + LOG2PI * L));
       if (iv.text_scores) sc_ = fb_round6(sc_);  // ivector-plda-scoring writes text
-      if (AGENT)
+      if (agent)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(llr + (size_t)b * S + s), (unsigned long long)__double_as_longlong(sc_),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else
@@ -164,8 +167,7 @@ __device__ __forceinline__ void fb_iv_tail_run(const FbIvDev &iv, const FbIvTail
   }
   if (!tl.backend) return;
   __syncthreads();
-  if (tl.loss) fb_iv_backend_body<NT, true>(iv, b, scr, tl.llr);
-  else fb_iv_backend_body<NT, false>(iv, b, scr, tl.llr);
+  fb_iv_backend_body<NT>(iv, b, scr, tl.llr, tl.loss != 0);
   if (!tl.loss) return;
   __shared__ int s_ivt_last;
   if (tid == 0) {

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(1024) void k_iv_backend(FbIvDev iv, const double *_
   const int R = iv.R, b = blockIdx.x;
   for (int r = threadIdx.x; r < R; r += 1024) smd[r] = (double)(float)ivec[(size_t)b * R + r] - iv.mean_vec[r];
   __syncthreads();
-  fb_iv_backend_body<1024, false>(iv, b, smd, llr);
+  fb_iv_backend_body<1024>(iv, b, smd, llr, false);
 }
 void fb_launch_iv_backend(hipStream_t s, const FbIvDev &iv, const double *ivec, int B, double *llr) {
   const size_t shm = sizeof(double) * (size_t)fb_ivt_backend_doubles(iv.R, iv.L);
