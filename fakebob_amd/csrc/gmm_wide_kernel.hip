@@ -727,6 +727,18 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   auto settle = [&](const f32x16 &p0, const f32x16 &p1, float *pm, float *ps, const float (&rt)[2], const FbFxwUpd &u) {
     const unsigned worst = max(__float_as_uint(u.sn0), __float_as_uint(u.sn1));
     FXW_COUNT(0);
+#ifdef FB_FXW_COUNT
+    {  // how many of the update's 16 slices (a register pair = two components x the wave's 64 frames) could have been
+       // skipped wave-uniformly: every value more than 25 log2 units below the frame's running sum -- Kaldi's LogSumExp
+       // drops what lies log2(1 / FLT_EPSILON) = 23 below the maximum (task 3b: measured)
+      const float th0 = __builtin_amdgcn_logf(u.so0) - 25.0f, th1 = __builtin_amdgcn_logf(u.so1) - 25.0f;  // v_log_f32 = log2
+      int n = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (__builtin_amdgcn_ballot_w64(!(p0[r] < th0) || !(p1[r] < th1)) == 0ull) ++n;
+      if ((threadIdx.x & 63) == 0) atomicAdd(&g_fxw_counts[3], (unsigned long long)n);
+    }
+#endif
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst >= guard) != 0ull, 0)) {
       FXW_COUNT(1);
       fb_fxw_slow_update(p0, up[0], rt[0], pm[0], u.so0, pm, ps, rn[0], __float_as_uint(u.sn0) >= guard);

@@ -158,3 +158,32 @@ def test_solve_tail_equals_the_separate_backend_and_loss_launches(engine, oracle
     llr_o, ivs_o, _ = ctx.score_batch(wavs)
     assert np.abs(got[0] - llr_o).max() <= 1e-7
     assert np.abs(got[1] - ivs_o).max() <= 1e-9 * max(1.0, np.abs(ivs_o).max())
+
+
+def test_one_launch_bucket_partition_equals_the_four_launches(engine, oracle, monkeypatch):
+    """k_iv_bucket_one (round 5: count, the two scans and the fill of the (frame, slot) pairs' partition by component in
+    ONE launch with two grid barriers, the fill walked by four waves per block) against the four separate launches
+    (FB_IV_BUCKET_SPLIT=1): the partition is stable either way, so the pairs -- and with them posteriors, statistics,
+    i-vectors and scores -- are identical bit for bit.  FB_IV_SOLVE=rw selects the one-or-two-attacks launch chain, the
+    only one that takes the grid-synchronised kernel; batches of 1 ... 40 utterances give 2 ... 90 blocks, some of them
+    without a single voiced row, and with C = 256 between 3 and 16 components per block in the middle phase (a batch
+    with more components per block than that falls back to the four launches by itself)."""
+    sy = synthetic_ivector_system(C=256, D=72, R=100, L=50, n_speakers=2, seed=5)
+    monkeypatch.setenv("FB_IV_SOLVE", "rw")
+    engine.load_ivector(sy, "CSI")
+    batches = [[_wav(0)] + [_wav(u, 9000 + 700 * u) for u in range(1, 6)],
+               [_wav(u % 7, 16000 + 1300 * (u % 5)) for u in range(40)],
+               [_wav(3, 1700)]]
+    for wavs in batches:
+        monkeypatch.setenv("FB_IV_BUCKET_SPLIT", "1")
+        llr_a, tv_a = engine.score_raw(wavs)
+        iv_a = engine.debug_ivectors(len(wavs), sy.R)
+        monkeypatch.delenv("FB_IV_BUCKET_SPLIT", raising=False)
+        for _ in range(2):                     # twice: the barrier's counters come back to zero
+            llr_b, tv_b = engine.score_raw(wavs)
+            iv_b = engine.debug_ivectors(len(wavs), sy.R)
+            assert np.array_equal(tv_a, tv_b) and np.array_equal(iv_a, iv_b) and np.array_equal(llr_a, llr_b)
+    ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=8)
+    llr_o, ivs_o, _ = ctx.score_batch(batches[0])
+    llr_g, _ = engine.score_raw(batches[0])
+    assert np.abs(llr_g - llr_o).max() <= 1e-7

@@ -168,6 +168,50 @@ def test_products_per_component_tile_follow_the_enrolment(oracle, monkeypatch, e
         assert err["p1"] > 4.0 * err["auto"], err
 
 
+@pytest.mark.parametrize("enrol", ["survey", "realistic"])
+def test_reduced_product_classes_on_very_short_utterances(oracle, monkeypatch, enrol):
+    """The constants of fb_load_gmm's per-tile rule predict the error of an AVERAGE over a few hundred voiced frames
+    whose per-frame errors are random in sign: the error of a mean grows as 1 / sqrt(T_v), and the reference scores
+    lists of arbitrary-length audio (gmm_ubm_OSI.py:70-81, attackMain.py:128).  C = 2048, SURVEY.md 8(d)'s speakers and
+    speakers enrolled on 20 000 frames, the classes as the rule chooses them, utterances of ~5 / 10 / 30 voiced frames
+    and a 0.1 s one in a ragged batch beside two of 3 s: raw and speaker - UBM scores against the float64 oracle within
+    north_star's 1e-4 -- and what the error is against T_v (printed), against one product everywhere (forced) and against
+    three (the float32 accumulation floor, which itself grows for short utterances)."""
+    from fakebob_amd.engine import Engine
+    from fakebob_amd.models import ENROL_REALISTIC, synthetic_gmm_system
+    ubm, spk = synthetic_gmm_system(5, 2048, 72, **(ENROL_REALISTIC if enrol == "realistic" else {}))
+    cfg = oracle.default_cfg()
+    # the first second of the synthetic utterances is loud (SURVEY.md 8(d)'s envelope): nearly every frame is voiced
+    wavs = [_wav(0, 800), _wav(1, 1600), _wav(2, 4800), _wav(3, 1600), _wav(4), _wav(5), _wav(6, 960), _wav(7, 2400)]
+    gc, miv, iv = stack_models([ubm] + spk)
+    raw_o, tv_o = oracle.gmm_score_batch(cfg, wavs, gc, miv, iv, nthreads=8)
+    out = {}
+    for name, env in (("auto", {}), ("p1", {"FB_GMM_DELTA_P": "1"}), ("p3", {"FB_GMM_DELTA_P": "3"})):
+        for k in ("FB_GMM_NARROW", "FB_GMM_MODE", "FB_GMM_DELTA_P", "FB_GMM_DELTA_F6"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(0)
+        try:
+            e.load_gmm([ubm] + spk)
+            tiles = e.gmm_delta_tiles + (e.gmm_delta_tiles_f6,)
+            raw, tv = e.score_raw(wavs)
+        finally:
+            e.close()
+        assert np.array_equal(tv, tv_o)
+        out[name] = (np.abs(raw - raw_o).max(axis=1), np.abs((raw[:, 1:] - raw[:, :1]) - (raw_o[:, 1:] - raw_o[:, :1])).max(axis=1), tiles)
+    monkeypatch.delenv("FB_GMM_DELTA_P", raising=False)
+    print("enrolment %s, tiles (P=1, P=2, P=3, F6) %s; voiced frames %s" % (enrol, out["auto"][2], tv_o.tolist()))
+    for name in ("auto", "p1", "p3"):
+        print("  %-4s max |err| per utterance: raw %s   speaker - UBM %s" % (
+            name, " ".join("%.1e" % v for v in out[name][0]), " ".join("%.1e" % v for v in out[name][1])))
+    assert tv_o.min() >= 3 and tv_o.min() <= 8 and sorted(tv_o)[2] <= 16      # really short ones are in the batch
+    assert out["auto"][0].max() <= SCORE_TOL and out["auto"][1].max() <= SCORE_TOL
+    # the rule's classes stay within a few float32 ulps (1.5e-5 at -150) of the three-product form on every utterance
+    assert out["auto"][0].max() <= 3e-5 + 2.0 * out["p3"][0].max(), (out["auto"][0], out["p3"][0])
+    assert out["auto"][1].max() <= 3e-5 + 2.0 * out["p3"][1].max(), (out["auto"][1], out["p3"][1])
+
+
 def test_delta_product_budget_can_be_relaxed_to_the_north_star_tolerance(oracle, monkeypatch):
     """FB_GMM_DELTA_BUDGET: the error budget of fb_load_gmm's per-tile rule, 6e-6 by default (float32-equivalent scores).
     north_star asks for 1e-4 against the reference: with a budget of 5e-5 the heavily enrolled speakers (20 000 frames)

@@ -23,6 +23,9 @@ if what == "COUNT":
     lib.fb_debug_fxw_counts(out.ctypes.data_as(C.c_void_p))
     print("%s, one scoring pass of 51 utterances: %d updates (per wave), %d rescues, %d reference moves" %
           ((e.gmm_kernel_variant,) + tuple(int(v) for v in out[:3])))
+    print("slices (register pairs = 2 components x 64 frames) whose every value lies more than 25 log2 units below the "
+          "frame's running sum: %d of %d = %.3f (what a wave-uniform skip of their exponentials could save)" %
+          (int(out[3]), 16 * int(out[0]), float(out[3]) / max(1.0, 16.0 * float(out[0]))))
 else:
     e.score_raw(wavs)
     for _ in range(2):
