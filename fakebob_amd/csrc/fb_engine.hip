@@ -102,7 +102,6 @@ struct fb_engine {
   int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
   DevBuf iv_prog, iv_ticket;  // k_iv_solve_rw: progress words, ticket
   DevBuf iv_tail_counter;     // arrivals of the solve kernels' fused tail (fb_iv_tail.h)
-  DevBuf iv_grid_bar;         // k_iv_bucket_one's grid barrier (two counters, left at zero by every launch)
   bool tail_loss_req = false, tail_loss_done = false;  // enqueue_get_grad asks run_scoring to take the loss body along / it did
   FbIvTail tail_req = {};
   unsigned iv_rw_epoch = 0;
@@ -242,7 +241,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->iv_grid_bar, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -1334,14 +1333,9 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                        e->iv_ll.as<float>());
     FB_DBG_SYNC(e, "gmm_dump");
-    if (!e->iv_grid_bar.p) {
-      FBCHK(e->iv_grid_bar.ensure(2 * sizeof(unsigned)));
-      HIPCHK(hipMemsetAsync(e->iv_grid_bar.p, 0, 2 * sizeof(unsigned), s));
-    }
-    // (the one-launch partition synchronises its grid: only in the chain of one or two attacks per GPU, like k_iv_solve_rw)
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
-                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), fb_iv_use_rw(e) ? e->iv_grid_bar.as<unsigned>() : nullptr);
+                             e->iv_pairs.as<int>(), e->iv_llf.as<float>());
     FB_DBG_SYNC(e, "select_post");
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
@@ -1936,7 +1930,6 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
     if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
     if (e->iv_tail_counter.p) HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), e->stream));
-    if (e->iv_grid_bar.p) HIPCHK(hipMemsetAsync(e->iv_grid_bar.p, 0, 2 * sizeof(unsigned), e->stream));
     e->vad_part_B = -1;  // ... and k_vad_delta_cmvn_p's exchange slots are refilled with sentinels (run_post_mfcc)
     FbCtlDev h;
     memset(&h, 0, sizeof(h));

@@ -282,11 +282,9 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
                          double *sim, double *u);
 // bucket_ws: fb_iv_bucket_ws_ints() ints of workspace, zero before the first use; pairs / llf: rows_cap * nsel
 size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap);
-// grid_bar: two unsigned, zero before the first launch -- or null: the bucket partition as four launches (k_iv_bucket_one's
-// grid barrier needs its whole grid resident; the engine passes it only for the launch chain of one or two attacks per GPU)
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, unsigned *grid_bar);
+                              int *pairs, float *llf);
 // gammaT [C][Bpad], XT [C*D][Bpad]: utterance-minor, zero-padded to Bpad (multiple of 32)
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);

@@ -291,144 +291,56 @@ __global__ __launch_bounds__(64) void k_iv_bucket_fill(FbIvDev iv, const int *__
   }
 }
 
-// The four launches above as ONE (round 5): count -> scan over the blocks -> scan over the components -> fill, separated
-// by two grid barriers.  k_iv_bucket_count / _scan_blocks / _scan / _fill were 4.8 + 8.6 + 4.5 + 16.1 us and three launch
-// boundaries of a lone attack's chain; here
-//   * a block keeps the histograms of its four 16-frame sub-blocks in LDS across the barriers, so the fill is walked by
-//     FOUR waves (16 frames each, in order: the partition stays stable) instead of one wave over 64 frames -- the serial
-//     LDS read-modify-write per frame is what the fill's time was;
-//   * only the block totals travel: cnt[blk][k] out, pref[blk][k] (exclusive prefix over the blocks) back, every word by
-//     agent-scope (write-through) stores / loads, the barrier itself an arrival counter polled by one thread per block
-//     behind s_waitcnt of every storing thread -- no device-wide fence (they cost microseconds per workgroup
-//     on eight XCDs);
-//   * block 0 also writes bstart / wstart / nz for the kernels behind (fullcov, stats).
-// A grid barrier needs the whole grid resident at once: the launcher takes this kernel only for the launch chain of one
-// or two attacks per GPU (fb_set_fused_chain(e, 1), like k_iv_solve_rw) and at most FB_IV_B1_MAX blocks -- two such grids
-// (32 KB of LDS per block: five blocks per compute unit) then always fit beside each other, whatever else is running
-// drains without their help, and nothing waits for a block that cannot start.
-#define FB_IV_B1_MAX 512
-__device__ __forceinline__ void fb_iv_grid_barrier(unsigned *bar, unsigned target) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);          // this thread's agent-scope stores are complete ...
-  __syncthreads();                        // ... and so are the whole block's
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ int fb_iv_ld_i32(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fb_iv_st_i32(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ __launch_bounds__(256) void k_iv_bucket_one(FbIvDev iv, const int *__restrict__ n_rows_ptr, const int *__restrict__ sel,
-                                                        int n_blk, int *__restrict__ cnt, int *__restrict__ pref,
-                                                        int *__restrict__ hist, int *__restrict__ bstart, int *__restrict__ wstart,
-                                                        int *__restrict__ nz, int *__restrict__ pairs, unsigned *__restrict__ bar) {
-  extern __shared__ int s_h[];                  // [4][Cpad]: the sub-blocks' histograms, later their first slots
-  __shared__ int s_part[16][17], s_wsum[3][4];
+// (Round 5 built the four launches above as ONE -- count, the two scans and the fill separated by two grid barriers on an
+// arrival counter, every exchanged word an agent-scope store / load, no device-wide fence -- and measured it: 41 - 46 us
+// against the 34.6 us + three launch boundaries of the separate kernels.  On the eight-XCD MI355X a grid barrier costs
+// what a kernel boundary costs -- the write-through of the block's stores, the arrival, the poll: 4 - 5 us -- and the
+// phases between them are memory round trips either way.  Removed; what stayed is its fill, below.)
+//
+// k_iv_bucket_fill4 (round 5): the fill with FOUR waves per partition block.  The serial part of the fill is one LDS
+// read-modify-write per frame (a frame's slots in parallel: their components are distinct); a block of 64 frames walked by
+// one wave was 16 us.  Here the block first counts its four 16-frame sub-blocks apart (LDS histograms, as
+// k_iv_bucket_count does for the whole block), turns them into the sub-blocks' first slots -- bucket start + the blocks
+// before this one (pref) + the sub-blocks before this one --, and every wave walks its own 16 frames: the partition is the
+// same stable one (sub-blocks in order, frames in order).
+__global__ __launch_bounds__(256) void k_iv_bucket_fill4(FbIvDev iv, const int *__restrict__ n_rows_ptr,
+                                                         const int *__restrict__ sel, const int *__restrict__ pref,
+                                                         const int *__restrict__ bstart, int *__restrict__ pairs) {
+  extern __shared__ int s_h[];                  // [4][Cpad]: the sub-blocks' histograms, then their first slots
   const int C = iv.C, Cpad = iv.Cpad, nsel = iv.nsel, n_rows = *n_rows_ptr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, blk = blockIdx.x;
   const int r0 = blk * FB_IV_FB, r1 = min(n_rows, r0 + FB_IV_FB);
-  // ---- 1. histograms of the four 16-frame sub-blocks (wave w = frames r0 + 16 w ..), the block's totals to memory
+  if (r0 >= r1) return;
+  const int q0 = r0 + 16 * w, q1 = min(r1, q0 + 16);
+  int kv[16];   // the 16 frames' selections of this slot: one batch of loads for both passes
+#pragma unroll
+  for (int u = 0; u < 16; ++u) kv[u] = (lane < nsel && q0 + u < q1) ? sel[(q0 + u) * nsel + lane] : -1;
   for (int i = tid; i < 4 * Cpad; i += 256) s_h[i] = 0;
   __syncthreads();
-  {
-    const int q0 = r0 + 16 * w, q1 = min(r1, q0 + 16);
-    for (int e = q0 * nsel + lane; e < q1 * nsel; e += 64) {
-      const int k = sel[e];
-      if (k >= 0 && k < C) atomicAdd(&s_h[w * Cpad + k], 1);
-    }
-  }
-  __syncthreads();
-  for (int k = tid; k < C; k += 256)
-    fb_iv_st_i32(&cnt[(size_t)blk * Cpad + k], (s_h[k] + s_h[Cpad + k]) + (s_h[2 * Cpad + k] + s_h[3 * Cpad + k]));
-  fb_iv_grid_barrier(bar, (unsigned)n_blk);
-  // ---- 2. exclusive prefix over the blocks, per component: the components are dealt over the blocks (cpb each), a
-  //         component's n_blk counts over 16 threads (k_iv_bucket_scan_blocks's two passes)
-  {
-    const int cpb = (C + n_blk - 1) / n_blk;                 // <= 16 (the launcher checks)
-    const int kk = tid >> 4, seg = tid & 15;
-    const int k = blk * cpb + kk;
-    const bool kok = kk < cpb && k < C;
-    const int per = (n_blk + 15) / 16, j0 = seg * per, j1 = min(n_blk, j0 + per);
-    int tot = 0;
-    if (kok)
-      for (int j = j0; j < j1; ++j) tot += fb_iv_ld_i32(&cnt[(size_t)j * Cpad + k]);
-    s_part[kk][seg] = tot;
-    __syncthreads();
-    int run = 0;
-    for (int q = 0; q < seg; ++q) run += s_part[kk][q];
-    if (kok) {
-      for (int j = j0; j < j1; ++j) {
-        fb_iv_st_i32(&pref[(size_t)j * Cpad + k], run);
-        run += fb_iv_ld_i32(&cnt[(size_t)j * Cpad + k]);
-      }
-      if (seg == 15) fb_iv_st_i32(&hist[k], run);
-    }
-  }
-  fb_iv_grid_barrier(bar, 2u * (unsigned)n_blk);
-  // ---- 3. bucket starts = exclusive scan of hist over the components, by every block for itself (thread = a run of
-  //         components); block 0 writes bstart / wstart / nz for the kernels behind
-  {
-    const int per = (C + 255) / 256, lo = tid * per, hi = min(C, lo + per);
-    int a = 0, bsum = 0, nzc = 0;
-    for (int k = lo; k < hi; ++k) {
-      const int hk = fb_iv_ld_i32(&hist[k]);
-      a += hk; bsum += (hk + FB_IV_CH - 1) / FB_IV_CH; nzc += hk > 0;
-    }
-    int ia = a, ib = bsum, ic = nzc;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64), uc = __shfl_up(ic, o, 64);
-      if (lane >= o) { ia += ua; ib += ub; ic += uc; }
-    }
-    if (lane == 63) { s_wsum[0][w] = ia; s_wsum[1][w] = ib; s_wsum[2][w] = ic; }
-    __syncthreads();
-    int ra = ia - a, rb = ib - bsum, rc = ic - nzc;
-    for (int i = 0; i < w; ++i) { ra += s_wsum[0][i]; rb += s_wsum[1][i]; rc += s_wsum[2][i]; }
-    if (blk == 0 && tid == 255) { bstart[C] = ra + a; wstart[C] = rb + bsum; nz[C] = rc + nzc; }
-    for (int k = lo; k < hi; ++k) {
-      const int hk = fb_iv_ld_i32(&hist[k]);
-      // first slot of sub-block 0 of this block in bucket k; the sub-blocks behind it follow (in place of their counts)
-      const int p0 = ra + fb_iv_ld_i32(&pref[(size_t)blk * Cpad + k]);
-      const int c0 = s_h[k], c1 = s_h[Cpad + k], c2 = s_h[2 * Cpad + k];
-      s_h[k] = p0; s_h[Cpad + k] = p0 + c0; s_h[2 * Cpad + k] = p0 + c0 + c1; s_h[3 * Cpad + k] = p0 + c0 + c1 + c2;
-      if (blk == 0) {
-        bstart[k] = ra;
-        wstart[k] = rb;
-        if (hk > 0) nz[rc++] = k;
-      }
-      ra += hk;
-      rb += (hk + FB_IV_CH - 1) / FB_IV_CH;
-    }
+  for (int u = 0; u < 16; ++u)
+    if (kv[u] >= 0 && kv[u] < C) atomicAdd(&s_h[w * Cpad + kv[u]], 1);
+  __syncthreads();
+  for (int k = tid; k < C; k += 256) {
+    const int p0 = bstart[k] + pref[(size_t)blk * Cpad + k];
+    const int c0 = s_h[k], c1 = s_h[Cpad + k], c2 = s_h[2 * Cpad + k];
+    s_h[k] = p0; s_h[Cpad + k] = p0 + c0; s_h[2 * Cpad + k] = p0 + c0 + c1; s_h[3 * Cpad + k] = p0 + c0 + c1 + c2;
   }
   __syncthreads();
-  // ---- 4. fill: wave w walks its 16 frames in order, the slots of a frame in parallel (distinct components)
-  {
-    int *pos = s_h + w * Cpad;
-    const int q0 = r0 + 16 * w, q1 = min(r1, q0 + 16);
-    for (int r = q0; r < q1; ++r) {
-      if (lane < nsel) {
-        const int e = r * nsel + lane;
-        const int k = sel[e];
-        if (k >= 0 && k < C) {
-          const int p = pos[k];
-          pos[k] = p + 1;
-          pairs[p] = e;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int *pos = s_h + w * Cpad;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int r = q0 + u;
+    if (r >= q1) break;
+    const int k = kv[u];
+    if (k >= 0 && k < C) {
+      const int p = pos[k];
+      pos[k] = p + 1;
+      pairs[p] = r * nsel + lane;
     }
-  }
-  // ---- the arrival counter back to zero for the next launch: nobody polls it any more once every block is here
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned done = __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (unsigned)n_blk - 1u) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -785,7 +697,7 @@ size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
 }
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, unsigned *grid_bar) {
+                              int *pairs, float *llf) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
   int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *nz = wstart + (C + 1) + C,
@@ -802,18 +714,13 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
     else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);  // C <= 4096 (fb_load_ivector)
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
-  // grid_bar != null: the caller vouches for at most two such grids on the GPU at a time (see k_iv_bucket_one)
-  const bool one = grid_bar != nullptr && n_blk <= FB_IV_B1_MAX && (C + n_blk - 1) / n_blk <= 16 && 4 * lds_c <= 32 * 1024 &&
-                   getenv("FB_IV_BUCKET_SPLIT") == nullptr;
-  if (one) {
-    hipLaunchKernelGGL(k_iv_bucket_one, dim3(n_blk), dim3(256), 4 * lds_c, s, iv, n_rows_ptr, sel, n_blk, cnt, pref, hist, bstart,
-                       wstart, nz, pairs, grid_bar);
-  } else {
-    hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
-    hipLaunchKernelGGL(k_iv_bucket_scan_blocks, dim3((C + 63) / 64), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
-    hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, nz);
+  hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
+  hipLaunchKernelGGL(k_iv_bucket_scan_blocks, dim3((C + 63) / 64), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
+  hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, nz);
+  if (4 * lds_c <= 64 * 1024 && getenv("FB_IV_FILL1") == nullptr)
+    hipLaunchKernelGGL(k_iv_bucket_fill4, dim3(n_blk), dim3(256), 4 * lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
+  else   // (FB_IV_FILL1=1: the one-wave fill, A/B and tests)
     hipLaunchKernelGGL(k_iv_bucket_fill, dim3(n_blk), dim3(64), lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
-  }
   const int n_pairs_cap = rows_cap * iv.nsel;
   const int work_cap = C + (n_pairs_cap + FB_IV_CH - 1) / FB_IV_CH;
   const char *fc_env = getenv("FB_IV_FULLCOV");  // "lds": the triangle-form kernel (A/B runs, tests); read per launch

@@ -160,29 +160,24 @@ def test_solve_tail_equals_the_separate_backend_and_loss_launches(engine, oracle
     assert np.abs(got[1] - ivs_o).max() <= 1e-9 * max(1.0, np.abs(ivs_o).max())
 
 
-def test_one_launch_bucket_partition_equals_the_four_launches(engine, oracle, monkeypatch):
-    """k_iv_bucket_one (round 5: count, the two scans and the fill of the (frame, slot) pairs' partition by component in
-    ONE launch with two grid barriers, the fill walked by four waves per block) against the four separate launches
-    (FB_IV_BUCKET_SPLIT=1): the partition is stable either way, so the pairs -- and with them posteriors, statistics,
-    i-vectors and scores -- are identical bit for bit.  FB_IV_SOLVE=rw selects the one-or-two-attacks launch chain, the
-    only one that takes the grid-synchronised kernel; batches of 1 ... 40 utterances give 2 ... 90 blocks, some of them
-    without a single voiced row, and with C = 256 between 3 and 16 components per block in the middle phase (a batch
-    with more components per block than that falls back to the four launches by itself)."""
+def test_four_wave_fill_equals_the_one_wave_fill(engine, oracle, monkeypatch):
+    """k_iv_bucket_fill4 (round 5: a partition block's 64 frames filled by four waves, 16 frames each, behind a count of
+    the four sub-blocks) against the one-wave fill (FB_IV_FILL1=1): the partition of the (frame, slot) pairs by component
+    is the same stable one, so the pairs -- and with them posteriors, statistics, i-vectors and scores -- are identical
+    bit for bit.  Batches of 1 ... 40 utterances: 2 ... 90 blocks, ragged last blocks, sub-blocks without a frame."""
     sy = synthetic_ivector_system(C=256, D=72, R=100, L=50, n_speakers=2, seed=5)
-    monkeypatch.setenv("FB_IV_SOLVE", "rw")
     engine.load_ivector(sy, "CSI")
     batches = [[_wav(0)] + [_wav(u, 9000 + 700 * u) for u in range(1, 6)],
                [_wav(u % 7, 16000 + 1300 * (u % 5)) for u in range(40)],
                [_wav(3, 1700)]]
     for wavs in batches:
-        monkeypatch.setenv("FB_IV_BUCKET_SPLIT", "1")
+        monkeypatch.setenv("FB_IV_FILL1", "1")
         llr_a, tv_a = engine.score_raw(wavs)
         iv_a = engine.debug_ivectors(len(wavs), sy.R)
-        monkeypatch.delenv("FB_IV_BUCKET_SPLIT", raising=False)
-        for _ in range(2):                     # twice: the barrier's counters come back to zero
-            llr_b, tv_b = engine.score_raw(wavs)
-            iv_b = engine.debug_ivectors(len(wavs), sy.R)
-            assert np.array_equal(tv_a, tv_b) and np.array_equal(iv_a, iv_b) and np.array_equal(llr_a, llr_b)
+        monkeypatch.delenv("FB_IV_FILL1", raising=False)
+        llr_b, tv_b = engine.score_raw(wavs)
+        iv_b = engine.debug_ivectors(len(wavs), sy.R)
+        assert np.array_equal(tv_a, tv_b) and np.array_equal(iv_a, iv_b) and np.array_equal(llr_a, llr_b)
     ctx = oracle.IvSystemCtx(oracle.default_cfg(), sy, nthreads=8)
     llr_o, ivs_o, _ = ctx.score_batch(batches[0])
     llr_g, _ = engine.score_raw(batches[0])
