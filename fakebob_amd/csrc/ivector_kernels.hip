@@ -89,6 +89,15 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 // their running maximum; a round = wave arg-max of the 64 lane maxima by DPP (no LDS, no bpermute),
 // then only the owning lane removes the winner and rescans its registers.  Order: descending by
 // (value, index) like std::greater<pair<float,int>> (gmm-gselect).
+// (Round 5 built the alternative the round-4 review asked for -- no dump: every lane of the matrix-core kernel keeps a
+//  sorted list of its 16 largest values as 32-bit keys (value with its index in the low significand bits: an insertion
+//  is a chain of 16 v_med3_f32), 128 - 256 keys per frame instead of 2 048 values, and a merge kernel recomputes the ~22
+//  candidates around the 20th key exactly (float64 sums in the oracle's order) and selects on those; exact by
+//  construction, lists of 4 and of 16 gave bit-identical i-vectors, parity green -- and measured it at configs[2] size:
+//  k_gmm_fx2 with the lists 64.7 us (four chunks) / 73.0 (eight) against the dump's 51.4 -- some lane of the 64 inserts
+//  in nearly every round, 16 + 16 ln(n / 16) insertions per lane are ~100 rounds per chunk --, the merge 80 - 123 us
+//  against this kernel's 45 (20 wave-maximum rounds over the keys, ~22 scattered 576-byte parameter rows per frame,
+//  20 arg-max rounds): 153 us against 97.  Removed; the dump stays.)
 template <int NJ>
 __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
                                                    const int *__restrict__ n_rows_ptr, int *__restrict__ sel) {
@@ -765,6 +774,10 @@ __device__ __forceinline__ int fb_wave_lower_bound(const int *__restrict__ a, in
   const unsigned long long ge = __ballot(v >= key);
   return ge ? lo + (int)__builtin_ctzll(ge) : hi;
 }
+// (Round 5, measured and removed: the bucket's pairs staged in LDS for the searches and reads of a run -- 62 -> 80 us, the
+//  copy + barrier per item and the occupancy the 16 KB cost outweigh the dependent round trips the other waves hide --; the
+//  active list made by this kernel's last workgroup instead of k_iv_active's own launch -- 62.3 + 4.4 -> 73 us: 2 048
+//  arrivals on one counter cost more than the launch.)
 #define FB_IV_SG 8  // feature rows in flight per wave (two register buffers of this size).  Round 4: 16 -> 8 -- the kernel is a
                     // chain of dependent round trips per (bucket, utterance) run, hidden by OTHER waves: 50 registers and eight waves
                     // per SIMD (the whole grid resident) beat the deeper prefetch at 100 registers, 84 -> 61 us (spd 200: 354 -> 267);
