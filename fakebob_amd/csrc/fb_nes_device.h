@@ -174,12 +174,12 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
   }
   // max |audio - adver| over the perturb kernel's per-workgroup partials (order-independent: every thread takes a
   // strided share instead of thread 0 walking up to N / 256 entries alone)
-  __shared__ double s_dmax[4];
+  __shared__ double s_dmax[16];   // one per wave (the solve kernels' tail calls this body with 512 threads)
   {
     double dm = dist_first > 0.0 ? dist_first : 0.0;
     for (int i = threadIdx.x + blockDim.x; i < n_dist_part; i += blockDim.x) { const double v = dist_part[i]; dm = v > dm ? v : dm; }
     dm = fb_wave_max(dm);
-    if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dm;
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) s_dmax[threadIdx.x >> 6] = dm;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(my_err, o, 64); my_err = v > my_err ? v : my_err; }
     if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) s_errw[threadIdx.x >> 6] = my_err;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     const double *sc0 = sc_lds ? s_sc : scores;  // row 0 = the clean adver
     for (int m = 0; m < S && m < 62; ++m) out->score0[m] = sc0[m];
     double d = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
+    for (int i = 0; i < (int)(blockDim.x >> 6) && i < 16; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
     out->distance = d;
     out->err = s_err;
     if (ctl) {
