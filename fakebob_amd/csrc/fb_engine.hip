@@ -121,6 +121,7 @@ struct fb_engine {
   int pre_ndp = 0;
   bool defer_finalize = false;  // run_scoring leaves the GMM finalisation to the fused finalize + loss launch
   int vad_part_B = -1, vad_part_dim = -1;  // slot layout the sentinel-filled exchange buffer of k_vad_delta_cmvn_p was prepared for
+  int ctl_seq = 0;         // loss bodies queued on the control block since its reset (FbCtlDev::pub_seq)
   unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernels on vad_pub (its published counts carry the epoch)
   unsigned vad_p_launches = 0;  // launches of k_vad_delta_cmvn_p on vad_part since its sentinel fill (its slot sets alternate with them)
   FbCtlDev *h_ctl = nullptr;  // pinned
@@ -1844,7 +1845,8 @@ static bool fb_fuse_on(const fb_engine *e) {
 }
 static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uint32_t iter,
                             const double *noise_dev, bool with_dist, FbCtlDev *ctl = nullptr,
-                            double *trace_dev = nullptr, int trace_row = 0) {
+                            double *trace_dev = nullptr, int trace_row = 0, const FbUpdArgs *upd = nullptr,
+                            bool *upd_done = nullptr) {
   const int half = p->samples_per_draw / 2, B = 2 * half + 1;
   int ndp = 0;
   const int *stop = ctl ? &ctl->stop : nullptr;
@@ -1892,7 +1894,8 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
                                 e->tv.as<int>(), p->task, p->attack_type, e->zmean.as<double>(), e->zstd.as<double>(),
                                 p->threshold, p->adver_thresh, p->target, p->true_label, e->dist_part.as<double>(),
                                 with_dist ? ndp : 0, e->scores.as<double>(), e->loss.as<double>(),
-                                e->nes_out.as<FbNesDev>(), ctl, trace_dev, trace_row);
+                                e->nes_out.as<FbNesDev>(), ctl, trace_dev, trace_row, upd ? ++e->ctl_seq : 0, upd);
+    if (upd && upd_done) *upd_done = true;
     return FB_OK;
   }
   fb_launch_loss(e->stream, e->raw.as<double>(), e->tv.as<int>(), B, e->n_out, p->task, e->kind, p->attack_type,
@@ -1938,6 +1941,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     h.plateau_length = p->plateau_length;
     h.disable_stop = disable_stop ? 1 : 0;
     h.ticks = ticks;
+    e->ctl_seq = 0;   // (h.pub_seq = 0: the loss bodies of this attack count from 1)
     *e->h_ctl = h;
     HIPCHK(hipMemcpyAsync(ctl, e->h_ctl, sizeof(FbCtlDev), hipMemcpyHostToDevice, e->stream));
     FBCHK(sync_stream(e));  // h_ctl is reused for the read-back below
@@ -1956,9 +1960,26 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
         noise_dev = e->noise.as<double>();
       }
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
-      FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base));
+      // GMM systems on the fused chain: the update of this iteration and the batch of the next one ride in the launch
+      // that finalises the scores and runs the loss body (k_gmm_finalize_loss_update; FB_FUSE_UPD=0: two launches)
+      const bool upd_ok = !noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e);
+      const char *fu_env = getenv("FB_FUSE_UPD");   // (read per iteration: A/B inside one process)
+      const bool no_fuse_upd = fu_env && fu_env[0] == '0';
+      FbUpdArgs ua = {};
+      bool upd_done = false;
+      if (upd_ok && e->kind == 0 && !no_fuse_upd) {
+        ua.loss = e->loss.as<double>(); ua.N = N; ua.half = half; ua.sigma = p->sigma; ua.zbuf = e->zbuf.as<float>();
+        ua.momentum = p->momentum; ua.one_minus_m = one_minus_m; ua.epsilon = p->epsilon; ua.audio = e->audio.as<double>();
+        ua.grad_m = e->grad_m.as<double>(); ua.adver = e->adver.as<double>(); ua.seed = p->seed; ua.next_iter = (uint32_t)(it + 1);
+        ua.stream = p->stream; ua.q = e->wav.as<int16_t>(); ua.dist_part = e->dist_part.as<double>();
+        ua.qscale = ldexp(1.0, nes_bits(p) - 1);
+      }
+      FBCHK(enqueue_get_grad(e, p, N, (uint32_t)it, noise_dev, true, ctl, trace_dev, it - it_base, ua.loss ? &ua : nullptr, &upd_done));
       FB_DBG_SYNC(e, "loss");
-      if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e)) {
+      if (upd_done) {
+        e->pre_ndp = (int)((N + 255) / 256);
+        e->pre_iter = (long long)it + 1;
+      } else if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e)) {
         // momentum sign step of this iteration + the perturbed batch of the next one in a single launch
         e->pre_ndp = fb_launch_update_perturb(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(),
                                               p->momentum, one_minus_m, p->epsilon, e->audio.as<double>(),

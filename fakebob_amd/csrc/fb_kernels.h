@@ -59,6 +59,9 @@ struct FbCtlDev {
   double *ls;  // [plateau_length] recent losses
   int n_ls, plateau_length;
   int stop, broke, stop_iter, iters_done, err, disable_stop;
+  int pub_seq;   // the number of the last loss body that has published its results (k_gmm_finalize_loss_update: the
+                 // update workgroups of the same launch poll it); the host counts the loss bodies it queues
+  int pad_;
   unsigned long long *ticks;  // nullable: [1 + max_iter] device constant-rate clock (wall_clock64): [0] = start of the
                               // attack, [1 + it] = iteration it's loss evaluated -- the per-iteration times of the
                               // reference's trace (FAKEBOB.py:205-212)
@@ -79,6 +82,22 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 // k_grad_update (iteration `next_iter - 1`) + k_perturb (iteration next_iter) in one launch; device-controlled attacks
 // with Philox noise and half <= FB_FUSE_MAX_HALF only.  Returns the number of distance partials written.
 #define FB_FUSE_MAX_HALF 40
+// the arguments of k_update_perturb, for the launch that carries it behind the GMM finalisation + loss (below)
+struct FbUpdArgs {
+  const double *loss;
+  int64_t N;
+  int half;
+  double sigma;
+  float *zbuf;
+  double momentum, one_minus_m, epsilon;
+  const double *audio;
+  double *grad_m, *adver;
+  uint64_t seed;
+  uint32_t next_iter, stream;
+  int16_t *q;
+  double *dist_part;
+  double qscale;
+};
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
                              double *adver, const FbCtlDev *ctl, uint64_t seed, uint32_t next_iter, uint32_t stream,
@@ -220,7 +239,7 @@ void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *
                                  const int *tv, int task, int attack_type, const double *z_mean, const double *z_std,
                                  double threshold, double adver_thresh, int target, int true_label,
                                  const double *dist_part, int n_dist_part, double *scores, double *loss, FbNesDev *out,
-                                 FbCtlDev *ctl, double *trace, int it);
+                                 FbCtlDev *ctl, double *trace, int it, int pub_seq = 0, const FbUpdArgs *upd = nullptr);
 // enrolment statistics of a single model from its dump matrix ll[rows][ld]: occ[C], F[C][D] (float64)
 void fb_launch_gmm_post_stats(hipStream_t s, int C, int ld, int D, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, float *mx, float *inv_sum, double *occ,

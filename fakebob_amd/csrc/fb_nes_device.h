@@ -93,7 +93,10 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
                                               double *__restrict__ scores, double *__restrict__ loss,
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                               double *__restrict__ trace, int it, double *__restrict__ s_lv,
-                                              double *__restrict__ s_sc) {
+                                              double *__restrict__ s_sc, const int pub_seq = 0) {
+  // pub_seq != 0: workgroups of the SAME launch wait for this body's results (k_gmm_finalize_loss_update's update part):
+  // the losses, the step size and the stop flag go out as agent-scope (write-through) stores, and when they are complete
+  // ctl->pub_seq = pub_seq tells the pollers -- no device-wide fence
   const int S = (task == FB_TASK_CSI || znorm_all) ? M : M - 1;
   __shared__ int s_errw[16];
   // The decisions at the end are one thread's work: everything it needs from global memory is requested HERE and
@@ -169,7 +172,9 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
       for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
       l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
     }
-    loss[b] = l;
+    if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(loss + b), (unsigned long long)__double_as_longlong(l),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else loss[b] = l;
     if (b < FB_LOSS_LDS) s_lv[b] = l;
   }
   // max |audio - adver| over the perturb kernel's per-workgroup partials (order-independent: every thread takes a
@@ -184,6 +189,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(my_err, o, 64); my_err = v > my_err ? v : my_err; }
     if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) s_errw[threadIdx.x >> 6] = my_err;
   }
+  if (pub_seq) __builtin_amdgcn_s_waitcnt(0);   // this thread's loss stores are complete before thread 0 may publish
   __syncthreads();
   if (threadIdx.x == 0) {
     const int spd = B - 1;
@@ -212,12 +218,16 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     if (ctl) {
       double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
       double lr = c.lr;
+      auto set_stop = [&]() {
+        if (pub_seq) __hip_atomic_store(&ctl->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else ctl->stop = 1;
+      };
       if (s_err) {
         ctl->err = s_err;
-        ctl->stop = 1;
+        set_stop();
       } else {
         if (al < 0.0 && !c.disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
-          ctl->stop = 1;
+          set_stop();
           ctl->broke = 1;
           ctl->stop_iter = it;
         } else {  // :195-200
@@ -255,7 +265,9 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
               if (lr > c.min_lr) {
                 const double l2 = __ddiv_rn(lr, c.plateau_drop);
                 lr = l2 > c.min_lr ? l2 : c.min_lr;
-                ctl->lr = lr;
+                if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->lr), (unsigned long long)__double_as_longlong(lr),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else ctl->lr = lr;
               }
               n = 0;
             }
@@ -269,6 +281,154 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
         if (c.ticks) c.ticks[it + 1] = wall_clock64();  // [0] = the attack's start (k_stamp)
         ctl->iters_done = it + 1;
       }
+      if (pub_seq) {   // everything the pollers read is complete, then the word they poll
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(&ctl->pub_seq, pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// k_grad_update (momentum sign step of iteration `iter`) + k_perturb (the batch of iteration iter + 1) for the 256
+// consecutive samples of workgroup `bidx` (nes_kernels.hip: k_update_perturb's description).  WAIT (round 5): the
+// workgroup is part of the launch that also finalises the GMM scores and runs the loss body (k_gmm_finalize_loss_update,
+// gmm_kernels.hip): what does not depend on the losses -- staging this iteration's normals, DRAWING the next iteration's
+// (Philox + Box-Muller: most of the kernel's time) -- is done first, then one thread polls the control block until loss body
+// number wait_seq has published (or the attack has stopped), and the losses and the step size are read with agent-scope
+// loads.  Same arithmetic in the same order either way: trajectories are bit-identical.
+template <bool SMALL, bool WAIT>
+__device__ __forceinline__ void fb_update_perturb_body(const double *__restrict__ loss, int64_t N, int half, double sigma,
+                                                       float *__restrict__ zbuf, double momentum, double one_minus_m,
+                                                       double epsilon, const double *__restrict__ audio,
+                                                       double *__restrict__ grad_m, double *__restrict__ adver,
+                                                       const FbCtlDev *__restrict__ ctl, uint64_t seed, uint32_t next_iter,
+                                                       uint32_t stream, int16_t *__restrict__ q, double *__restrict__ dist_part,
+                                                       double qscale, const int bidx, const int wait_seq, double *s_loss) {
+  const int spd = 2 * half;
+  double *s_a = s_loss + spd;
+  float *s_z = reinterpret_cast<float *>(s_a + 256);
+  constexpr int MAXI = 5;   // (sample quad, pair) items per thread: 64 half / 512, half <= FB_FUSE_MAX_HALF
+  float zn[WAIT ? MAXI : 1][4];
+  double lr;
+  if constexpr (!WAIT) {
+    if (ctl->stop) return;
+    lr = ctl->lr;
+    for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
+  }
+  const int64_t n = (int64_t)bidx * 256 + threadIdx.x;  // phase 1: threads 0 .. 255
+  for (int e = threadIdx.x; e < half * 256; e += blockDim.x) {
+    const int64_t ns = (int64_t)bidx * 256 + (e & 255);
+    s_z[e] = zbuf[(int64_t)(e >> 8) * N + (ns < N ? ns : N - 1)];
+  }
+  const int64_t n4_0 = (int64_t)bidx * 64;  // first sample quad of the block
+  // (WAIT: the sample's state is requested before the wait as well -- one memory round trip less behind the release)
+  double pre_gm = 0.0, pre_a = 0.0, pre_au = 0.0;
+  if (WAIT && threadIdx.x < 256 && n < N) { pre_gm = grad_m[n]; pre_a = adver[n]; pre_au = audio[n]; }
+  if constexpr (WAIT) {
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      const int idx = (int)threadIdx.x + u * (int)blockDim.x;
+      if (idx < 64 * half) fb_noise4(seed, next_iter, stream, (uint32_t)(n4_0 + (idx & 63)), (uint32_t)(idx >> 6), zn[u]);
+    }
+    __shared__ int s_stop;
+    if (threadIdx.x == 0) {
+      int st;
+      for (;;) {
+        st = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st || __hip_atomic_load(&ctl->pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_seq) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      // (a stop raised by THIS launch's loss body is published before pub_seq: look again behind it)
+      s_stop = st | __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_stop) return;
+    lr = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->lr), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+    for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = fb_ld_agent_f64(loss + 1 + i);
+  }
+  __syncthreads();
+  double dmax = 0.0;
+  if (threadIdx.x >= 256) {
+    // phase 2 only
+  } else if (n < N) {
+    auto el = [&](int i) -> D1 {
+      const int j = i < half ? i : i - half;
+      double z = (double)s_z[j * 256 + threadIdx.x];
+      if (i >= half) z = -z;
+      return D1{__dmul_rn(s_loss[i], z)};
+    };
+    double g = __longlong_as_double(0x7ff8000000000000ll);
+    if (spd > 0) {
+      const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+      g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
+    }
+    double gm = __dadd_rn(__dmul_rn(momentum, WAIT ? pre_gm : grad_m[n]), __dmul_rn(one_minus_m, g));
+    grad_m[n] = gm;
+    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
+    double a = __dsub_rn(WAIT ? pre_a : adver[n], __dmul_rn(lr, sg));
+    const double au = WAIT ? pre_au : audio[n];
+    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
+    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
+    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
+    a = a < lo ? lo : a;
+    a = a > hi ? hi : a;
+    adver[n] = a;
+    s_a[threadIdx.x] = a;
+    q[n] = fb_quantize(a, qscale);  // column 0 of the next batch: the clean adver
+    const double d = fabs(__dsub_rn(au, a));
+    dmax = d;
+  } else {
+    s_a[threadIdx.x] = 0.0;
+  }
+  {  // distance partial of the NEXT iteration's trace row (max |audio - adver|, as k_perturb reports it)
+    __shared__ double red[4];
+    double m = fb_wave_max(dmax);
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = m;  // waves 0 .. 3 hold the samples
+    __syncthreads();  // also: s_a complete
+    if (threadIdx.x == 0) {
+      double r = red[0];
+      for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
+      dist_part[bidx] = r;
+    }
+  }
+  // ---- phase 2: the perturbed columns of iteration next_iter for this block's samples
+  int u = 0;
+  for (int idx = threadIdx.x; idx < 64 * half; idx += blockDim.x, ++u) {
+    const int n4l = idx & 63, j = idx >> 6;
+    const int64_t n0 = (n4_0 + n4l) * 4;
+    if (n0 >= N) continue;
+    const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
+    float zf[4];
+    if constexpr (WAIT) {
+      // (u is a compile-time constant after unrolling only for u < MAXI: select instead of indexing)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = zn[0][k];
+#pragma unroll
+        for (int t = 1; t < MAXI; ++t) v = u == t ? zn[t][k] : v;
+        zf[k] = v;
+      }
+    } else {
+      fb_noise4(seed, next_iter, stream, (uint32_t)(n4_0 + n4l), (uint32_t)j, zf);
+    }
+    float *zp = zbuf + (int64_t)j * N + n0;
+    int16_t *qp = q + (int64_t)(1 + j) * N + n0;
+    int16_t *qm = q + (int64_t)(1 + half + j) * N + n0;
+    int16_t vp[4], vm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double a = s_a[4 * n4l + k], z = (double)zf[k];
+      vp[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, z), a), qscale);   // noise_audios = sigma * noise + audio (:237)
+      vm[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, -z), a), qscale);
+    }
+    if (cnt == 4 && ((N & 3) == 0)) {
+      *reinterpret_cast<float4 *>(zp) = make_float4(zf[0], zf[1], zf[2], zf[3]);
+      *reinterpret_cast<short4 *>(qp) = make_short4(vp[0], vp[1], vp[2], vp[3]);
+      *reinterpret_cast<short4 *>(qm) = make_short4(vm[0], vm[1], vm[2], vm[3]);
+    } else {
+      for (int k = 0; k < cnt; ++k) { zp[k] = zf[k]; qp[k] = vp[k]; qm[k] = vm[k]; }
     }
   }
 }

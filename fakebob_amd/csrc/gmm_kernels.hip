@@ -608,8 +608,9 @@ __global__ __launch_bounds__(256) void k_gmm_finalize(FbGmmDev g, const float *_
 // no faster (its time is the last workgroup's chain of small global round trips) and the wider workgroups get in the
 // way of the other attacks' kernels: 7.3 k against 8.0 k it/s with three attacks in flight, measured.
 #define FB_FIN_THREADS 256
+// (the body of one workgroup: utterance b, model m, n_arrive workgroups in all; 256 or 512 threads)
 template <bool SMALL>
-__global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
+__device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,
                                                            int n_chunks, const int *__restrict__ row_off, int B,
                                                            double *__restrict__ raw, int *__restrict__ counter,
@@ -620,9 +621,9 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
                                                            const double *__restrict__ dist_part, int n_dist_part,
                                                            double *__restrict__ scores, double *__restrict__ loss,
                                                            FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
-                                                           double *__restrict__ trace, int it) {
+                                                           double *__restrict__ trace, int it, const int b, const int m,
+                                                           const int n_arrive, const int pub_seq) {
   if (ctl && ctl->stop) return;  // queued behind the stopping iteration
-  const int b = blockIdx.x, m = blockIdx.y;
   const int r0 = row_off[b], r1 = row_off[b + 1];
   __shared__ double red[256];
   __shared__ int s_last;
@@ -686,21 +687,93 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
     // kernel's time on the eight-XCD MI355X.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
-    s_last = (atomicAdd(counter, 1) == (int)(gridDim.x * gridDim.y) - 1);
+    s_last = (atomicAdd(counter, 1) == n_arrive - 1);
   }
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];
   fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
-                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc);
+                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq);
 }
+template <bool SMALL>
+__global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
+                                                           const float *__restrict__ part_s, int rows_cap,
+                                                           int n_chunks, const int *__restrict__ row_off, int B,
+                                                           double *__restrict__ raw, int *__restrict__ counter,
+                                                           const int *__restrict__ tv, int task, int attack_type,
+                                                           const double *__restrict__ z_mean,
+                                                           const double *__restrict__ z_std, double threshold,
+                                                           double adver_thresh, int target, int true_label,
+                                                           const double *__restrict__ dist_part, int n_dist_part,
+                                                           double *__restrict__ scores, double *__restrict__ loss,
+                                                           FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
+                                                           double *__restrict__ trace, int it) {
+  fb_gmm_finalize_loss_body<SMALL>(g, part_m, part_s, rows_cap, n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean,
+                                   z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
+                                   ctl, trace, it, (int)blockIdx.x, (int)blockIdx.y, (int)(gridDim.x * gridDim.y), 0);
+}
+// ... and the momentum sign step + the next iteration's perturbed batch in the SAME launch (round 5): B x M workgroups
+// finalise and -- the last of them -- run the loss body, the N / 256 workgroups behind them are k_update_perturb's
+// (fb_update_perturb_body<WAIT>): they stage this iteration's normals and draw the next iteration's while the scores are
+// finalised, then wait for the loss body's publication (ctl->pub_seq, agent-scope stores / loads: no device-wide
+// fence) and go on.  One launch boundary less in a lone attack's chain, and the Philox + Box-Muller work -- most of
+// k_update_perturb -- off its critical path.  Workgroups are dispatched in index order: the finalising ones are running
+// or done before an update workgroup can wait for them.
+template <bool SMALL>
+__global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, const float *__restrict__ part_m,
+                                                           const float *__restrict__ part_s, int rows_cap,
+                                                           int n_chunks, const int *__restrict__ row_off, int B,
+                                                           double *__restrict__ raw, int *__restrict__ counter,
+                                                           const int *__restrict__ tv, int task, int attack_type,
+                                                           const double *__restrict__ z_mean,
+                                                           const double *__restrict__ z_std, double threshold,
+                                                           double adver_thresh, int target, int true_label,
+                                                           const double *__restrict__ dist_part, int n_dist_part,
+                                                           double *__restrict__ scores, double *__restrict__ loss,
+                                                           FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
+                                                           double *__restrict__ trace, int it, int pub_seq, FbUpdArgs u) {
+  extern __shared__ double s_dyn_upd[];
+  const int n_fin = B * g.M, lin = (int)blockIdx.x;
+  if (lin < n_fin) {
+    fb_gmm_finalize_loss_body<SMALL>(g, part_m, part_s, rows_cap, n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean,
+                                     z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
+                                     ctl, trace, it, lin % B, lin / B, n_fin, pub_seq);
+  } else {
+    fb_update_perturb_body<SMALL, true>(u.loss, u.N, u.half, u.sigma, u.zbuf, u.momentum, u.one_minus_m, u.epsilon, u.audio, u.grad_m,
+                                        u.adver, ctl, u.seed, u.next_iter, u.stream, u.q, u.dist_part, u.qscale, lin - n_fin, pub_seq,
+                                        s_dyn_upd);
+  }
+}
+
 void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                                  int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
                                  const int *tv, int task, int attack_type, const double *z_mean, const double *z_std,
                                  double threshold, double adver_thresh, int target, int true_label,
                                  const double *dist_part, int n_dist_part, double *scores, double *loss, FbNesDev *out,
-                                 FbCtlDev *ctl, double *trace, int it) {
+                                 FbCtlDev *ctl, double *trace, int it, int pub_seq, const FbUpdArgs *upd) {
+  if (upd) {   // finalisation + loss + the update / next batch in one launch
+    const int blocks = (int)((upd->N + 255) / 256);
+    const size_t shm = sizeof(double) * (size_t)(2 * upd->half + 256) + sizeof(float) * 256 * (size_t)(upd->half > 0 ? upd->half : 1);
+    {  // (the finalising workgroups' ~34 KB of static LDS + the update's normals: past 64 KB from samples_per_draw = 54 on)
+      static std::atomic<unsigned long long> optin{0};
+      unsigned long long bit = 0;
+      if (fb_device_needs_optin(optin, &bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gmm_finalize_loss_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gmm_finalize_loss_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        optin.fetch_or(bit, std::memory_order_release);
+      }
+    }
+    if (B - 1 <= 128)
+      hipLaunchKernelGGL(k_gmm_finalize_loss_update<true>, dim3(B * g.M + blocks), dim3(512), shm, s, g, part_m, part_s, rows_cap,
+                         n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                         true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, pub_seq, *upd);
+    else
+      hipLaunchKernelGGL(k_gmm_finalize_loss_update<false>, dim3(B * g.M + blocks), dim3(512), shm, s, g, part_m, part_s, rows_cap,
+                         n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                         true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, pub_seq, *upd);
+    return;
+  }
   if (B - 1 <= 128)
     hipLaunchKernelGGL(k_gmm_finalize_loss<true>, dim3(B, g.M), dim3(FB_FIN_THREADS), 0, s, g, part_m, part_s, rows_cap, n_chunks,
                        row_off, B, raw, counter, tv, task, attack_type, z_mean, z_std, threshold, adver_thresh, target,

@@ -303,90 +303,9 @@ __global__ __launch_bounds__(FB_UP_THREADS) void k_update_perturb(const double *
                                                         uint64_t seed, uint32_t next_iter, uint32_t stream,
                                                         int16_t *__restrict__ q, double *__restrict__ dist_part,
                                                         double qscale) {
-  if (ctl->stop) return;
-  const double lr = ctl->lr;
   extern __shared__ double s_loss[];  // loss[1..spd], the block's updated samples [256], the block's normals [half][256]
-  const int spd = 2 * half;
-  double *s_a = s_loss + spd;
-  float *s_z = reinterpret_cast<float *>(s_a + 256);
-  for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;  // phase 1: threads 0 .. 255
-  for (int e = threadIdx.x; e < half * 256; e += blockDim.x) {
-    const int64_t ns = (int64_t)blockIdx.x * 256 + (e & 255);
-    s_z[e] = zbuf[(int64_t)(e >> 8) * N + (ns < N ? ns : N - 1)];
-  }
-  __syncthreads();
-  double dmax = 0.0;
-  if (threadIdx.x >= 256) {
-    // phase 2 only
-  } else if (n < N) {
-    auto el = [&](int i) -> D1 {
-      const int j = i < half ? i : i - half;
-      double z = (double)s_z[j * 256 + threadIdx.x];
-      if (i >= half) z = -z;
-      return D1{__dmul_rn(s_loss[i], z)};
-    };
-    double g = __longlong_as_double(0x7ff8000000000000ll);
-    if (spd > 0) {
-      const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
-      g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
-    }
-    double gm = __dadd_rn(__dmul_rn(momentum, grad_m[n]), __dmul_rn(one_minus_m, g));
-    grad_m[n] = gm;
-    double sg = gm > 0.0 ? 1.0 : (gm < 0.0 ? -1.0 : gm);  // np.sign (0 -> 0, nan -> nan)
-    double a = __dsub_rn(adver[n], __dmul_rn(lr, sg));
-    const double au = audio[n];
-    double lo = __dsub_rn(au, epsilon), hi = __dadd_rn(au, epsilon);
-    lo = lo < -1.0 ? -1.0 : (lo > 1.0 ? 1.0 : lo);  // np.clip(audio -/+ eps, -1, 1)  (:163-164)
-    hi = hi < -1.0 ? -1.0 : (hi > 1.0 ? 1.0 : hi);
-    a = a < lo ? lo : a;
-    a = a > hi ? hi : a;
-    adver[n] = a;
-    s_a[threadIdx.x] = a;
-    q[n] = fb_quantize(a, qscale);  // column 0 of the next batch: the clean adver
-    const double d = fabs(__dsub_rn(au, a));
-    dmax = d;
-  } else {
-    s_a[threadIdx.x] = 0.0;
-  }
-  {  // distance partial of the NEXT iteration's trace row (max |audio - adver|, as k_perturb reports it)
-    __shared__ double red[4];
-    double m = fb_wave_max(dmax);
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = m;  // waves 0 .. 3 hold the samples
-    __syncthreads();  // also: s_a complete
-    if (threadIdx.x == 0) {
-      double r = red[0];
-      for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
-      dist_part[blockIdx.x] = r;
-    }
-  }
-  // ---- phase 2: the perturbed columns of iteration next_iter for this block's samples
-  const int64_t n4_0 = (int64_t)blockIdx.x * 64;  // first sample quad of the block
-  for (int idx = threadIdx.x; idx < 64 * half; idx += blockDim.x) {
-    const int n4l = idx & 63, j = idx >> 6;
-    const int64_t n0 = (n4_0 + n4l) * 4;
-    if (n0 >= N) continue;
-    const int cnt = (N - n0) >= 4 ? 4 : (int)(N - n0);
-    float zf[4];
-    fb_noise4(seed, next_iter, stream, (uint32_t)(n4_0 + n4l), (uint32_t)j, zf);
-    float *zp = zbuf + (int64_t)j * N + n0;
-    int16_t *qp = q + (int64_t)(1 + j) * N + n0;
-    int16_t *qm = q + (int64_t)(1 + half + j) * N + n0;
-    int16_t vp[4], vm[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double a = s_a[4 * n4l + k], z = (double)zf[k];
-      vp[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, z), a), qscale);   // noise_audios = sigma * noise + audio (:237)
-      vm[k] = fb_quantize(__dadd_rn(__dmul_rn(sigma, -z), a), qscale);
-    }
-    if (cnt == 4 && ((N & 3) == 0)) {
-      *reinterpret_cast<float4 *>(zp) = make_float4(zf[0], zf[1], zf[2], zf[3]);
-      *reinterpret_cast<short4 *>(qp) = make_short4(vp[0], vp[1], vp[2], vp[3]);
-      *reinterpret_cast<short4 *>(qm) = make_short4(vm[0], vm[1], vm[2], vm[3]);
-    } else {
-      for (int k = 0; k < cnt; ++k) { zp[k] = zf[k]; qp[k] = vp[k]; qm[k] = vm[k]; }
-    }
-  }
+  fb_update_perturb_body<SMALL, false>(loss, N, half, sigma, zbuf, momentum, one_minus_m, epsilon, audio, grad_m, adver, ctl, seed,
+                                       next_iter, stream, q, dist_part, qscale, (int)blockIdx.x, 0, s_loss);
 }
 // returns the number of distance partials the launch writes (one per workgroup)
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,

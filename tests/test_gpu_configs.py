@@ -187,6 +187,42 @@ def test_back_to_back_early_stopping_attacks_on_one_engine(oracle, monkeypatch, 
     assert int(np.sum(adv_o != got[0])) == 0
 
 
+@pytest.mark.parametrize("spd,n", [(10, 16000), (50, 24000), (64, 9000)])
+def test_update_in_the_finalising_launch_equals_the_separate_launch(monkeypatch, spd, n):
+    """Round 5: on the fused chain the momentum sign step and the next iteration's perturbed batch ride in the launch
+    that finalises the GMM scores and runs the loss body (k_gmm_finalize_loss_update): their workgroups draw the next
+    iteration's normals while the scores are finalised and wait for the loss body's publication.  FB_FUSE_UPD=0 keeps
+    k_update_perturb as a launch of its own: same arithmetic in the same order, so an attack that runs to max_iter, one
+    that stops early and one right behind it on the same engine must be identical bit for bit (samples_per_draw = 64:
+    the launch needs more than 64 KB of LDS per workgroup)."""
+    ubm, spk = synthetic_gmm_system(n_speakers=3, C=128, D=72)
+    audio = synthetic_audio(6, n)
+    e = Engine(0)
+    try:
+        e.load_gmm([ubm] + spk)
+        e.set_system("OSI")
+        e.set_fused_chain(True)
+        raw, _ = e.score_raw([(audio * 32768.0).astype(np.int16)])
+        sc = raw[0, 1:] - raw[0, 0]
+        tgt = int(np.argmax(sc))
+        p_stop = nes_params("OSI", "targeted", samples_per_draw=spd, max_iter=40, target=tgt, threshold=float(sc[tgt]) + 0.01,
+                            epsilon=0.004, max_lr=0.002, seed=11, stream=2)
+        p_full = nes_params("OSI", "targeted", samples_per_draw=spd, max_iter=7, target=tgt, threshold=float(sc.max()) + 50.0, seed=5)
+
+        def run():
+            return [e.attack(p_full, audio), e.attack(p_stop, audio), e.attack(p_stop, audio), e.get_grad(p_full, audio, it=3)]
+        monkeypatch.setenv("FB_FUSE_UPD", "0")
+        ref = run()
+        monkeypatch.delenv("FB_FUSE_UPD", raising=False)
+        got = run()
+    finally:
+        e.close()
+    for a, b in zip(ref[:3], got[:3]):
+        assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert ref[0][3].shape[0] == 7 and 1 <= ref[1][3].shape[0] < 40 and ref[1][1] == 1
+    assert ref[3][0] == got[3][0] and np.array_equal(ref[3][1], got[3][1])
+
+
 def test_attack_on_a_site_with_more_than_ten_models_equals_the_oracle(oracle, monkeypatch):
     """UBM + 12 speakers: k_gmm_fx2w scores them in two passes (round 4).  The whole NES loop on top of that -- get_grad,
     the loss over 12 scores, early stop, trace -- against the oracle on the 1 s / spd = 10 attack the bit-identical
