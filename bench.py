@@ -359,7 +359,7 @@ def bench_ivector(args, torch):
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
 GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 # bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip, a round-1 PROBE, not a specification):
 # the clock drops to ~1.6 GHz under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF peak
 MFMA16_POWER_LIMITED_TFLOPS_PROBE = 1660.0
@@ -367,7 +367,7 @@ MFMA16_POWER_LIMITED_TFLOPS_PROBE = 1660.0
 
 def kernel_source_hash():
     """sha256 over the HIP sources and headers the library is built from: what profiles/<TRAFFIC_FILE> was taken on
-    (tools/profile/prof_r04.sh records it) must be what runs now, or the committed PMC traffic is not this build's."""
+    (tools/profile/prof_r05.sh records it) must be what runs now, or the committed PMC traffic is not this build's."""
     import hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, "fakebob_amd", "csrc")
@@ -389,7 +389,7 @@ def committed_traffic(key):
         now = kernel_source_hash()
         if tj.get("kernel_source_sha16") != now:
             print("bench.py: profiles/%s was taken on kernel sources %s, this build is %s -- roofline.traffic is NOT "
-                  "reported (re-run tools/profile/prof_r04.sh)" % (TRAFFIC_FILE, tj.get("kernel_source_sha16"), now),
+                  "reported (re-run tools/profile/prof_r05.sh)" % (TRAFFIC_FILE, tj.get("kernel_source_sha16"), now),
                   file=sys.stderr)
             return None, {"traffic_stale": True, "traffic_profiled_on": tj.get("kernel_source_sha16"), "kernel_source_sha16": now}
         return tj["kernels"][key]["hbm_bytes_per_launch"], {
@@ -530,7 +530,7 @@ def main():
                     help="untimed iterations per attack run once before the declared warm-up (module load, first-touch "
                          "allocations, clock ramp of a cold GPU); reported in config.precondition_steps")
     ap.add_argument("--chain", default="auto", choices=["auto", "fused", "unfused"],
-                    help="launch chain of the attack loop (fb_set_fused_chain): auto = 5 launches per iteration with fewer "
+                    help="launch chain of the attack loop (fb_set_fused_chain): auto = 4 launches per iteration with fewer "
                          "than 3 attacks in flight, the 8 separate launches otherwise (they interleave better)")
     ap.add_argument("--task", default=None, choices=["SV", "OSI", "CSI"],
                     help="--arch iv: the system (configs[2]: SV, the default; configs[4]: OSI).  --arch gmm: OSI (headline, "
@@ -657,7 +657,7 @@ def main():
                        "repeats": len(dts), "windows_ms": [1e3 * x for x in dts],
                        "timing": "value / ms_per_step: the MEDIAN of `repeats` consecutive windows of exactly `steps` steps, each "
                                  "between (barrier + device synchronize) pairs and max over ranks; windows_ms lists them all",
-                       "launch_chain": "5 launches per iteration (fused)" if fused else "8 launches per iteration",
+                       "launch_chain": "4 launches per iteration (fused)" if fused else "8 launches per iteration",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "gmm_kernel": variant,
                        "gmm_delta_p": {"tiles_p1": tiles[0], "tiles_p2": tiles[1], "tiles_p3": tiles[2],

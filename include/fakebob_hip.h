@@ -234,11 +234,12 @@ int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, v
                   const double *audio, int64_t N, const double *noise_all, int16_t *adv_i16,
                   double *adver_f64, double *trace, int *n_trace, int *success_flag);
 
-/* Launch chain of the device-controlled attack loop.  on = 1: 5 launches per NES iteration (VAD + deltas + CMVN in
- * one, finalisation + loss + loop control in one, update of iteration i + perturbation of i + 1 in one) -- fastest
- * for ONE attack per GPU, the reference's own use; on = 0: the 8 separate launches, which interleave better when
- * several engines share a GPU (3 or more attacks in flight: +5 % NES iterations/s, profiles/r03_*); -1: default
- * (fused unless FB_NO_FUSE is set).  Trajectories are bit-identical either way. */
+/* Launch chain of the device-controlled attack loop.  on = 1: 4 launches per NES iteration of a GMM system (MFCC; VAD +
+ * deltas + CMVN; GMM log-likelihoods; finalisation + loss + loop control + update of iteration i + perturbation of
+ * i + 1 in one) and, for i-vector systems, the five-workgroups-per-matrix posterior solve -- fastest for ONE or TWO
+ * attacks per GPU, the reference's own use; on = 0: the 8 separate launches, which interleave better when several
+ * engines share a GPU (3 or more attacks in flight: +10 % NES iterations/s, profiles/r05_*); -1: default (fused unless
+ * FB_NO_FUSE is set).  Trajectories are bit-identical either way. */
 int fb_set_fused_chain(fb_engine *e, int on);
 
 /* Work counters since engine creation: what the driver reduces over ranks next to the success counter
