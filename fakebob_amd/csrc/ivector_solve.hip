@@ -63,32 +63,44 @@ __device__ __forceinline__ void fb_sv_gap(double (&X)[FB_SV_NB], const double (&
 // column lprev every lane finds in the broadcast buffer bc[(C-1) & 1].
 template <int C>
 __device__ __forceinline__ void fb_sv_col(double (&X)[FB_SV_NB], double *__restrict__ bc, int lane, double lprev, bool &bad) {
+  // The pivot and its reciprocal square root FIRST (round 5): the chain of the whole factorisation runs through them, and
+  // in front of them stood the requests of the broadcast column (a dozen LDS instructions' issue) and the first slice of
+  // the deferred updates, which waits for that column to arrive -- ~200 of a pivot's ~470 cycles (ISA of round 4's build)
+  const double d = fb_sv_readlane(X[C], C);
+  double ri;                            // 1/sqrt(d): v_rsq_f64 + two Newton steps (full double precision)
+  // (as a volatile statement with a memory clobber: left to the compiler the instruction sinks to its first use, behind
+  //  the column's requests again)
+  asm volatile("v_rsq_f64_e32 %0, %1" : "=v"(ri) : "s"(d) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
   double col[FB_SV_NB];
   if constexpr (C >= 1) {
 #pragma unroll
     for (int cc = C + 1; cc < FB_SV_NB; ++cc) col[cc] = bc[((C - 1) & 1) * 64 + cc];
   }
-  const double d = fb_sv_readlane(X[C], C);
-  fb_sv_gap<C, 0>(X, col, lprev);   // (the first slice holds column C + 1, which the readlane step below continues)
   bad |= !(d > 0.0);                // off the chain: a non-positive pivot yields NaNs below and is reported
-  double ri = __builtin_amdgcn_rsq(d);  // 1/sqrt(d): v_rsq_f64 + two Newton steps (full double precision)
-  fb_sv_gap<C, 1>(X, col, lprev);
+  // the first Newton step while the column is on its way from LDS (a slice of the deferred updates in front of it would
+  // hold the chain until the column arrives); the slices then fill the bubbles of the second step
   const double hd = -0.5 * d;
   double t = hd * ri;
-  fb_sv_gap<C, 2>(X, col, lprev);
+  __builtin_amdgcn_sched_barrier(0);
   double u1 = fma(t, ri, 1.5);
-  fb_sv_gap<C, 3>(X, col, lprev);
+  __builtin_amdgcn_sched_barrier(0);
   ri = ri * u1;
-  fb_sv_gap<C, 4>(X, col, lprev);
+  __builtin_amdgcn_sched_barrier(0);
+  fb_sv_gap<C, 0>(X, col, lprev);   // (the first slice holds column C + 1, which the readlane step below continues)
+  fb_sv_gap<C, 1>(X, col, lprev);
+  fb_sv_gap<C, 2>(X, col, lprev);
   t = hd * ri;
-  fb_sv_gap<C, 5>(X, col, lprev);
+  fb_sv_gap<C, 3>(X, col, lprev);
+  fb_sv_gap<C, 4>(X, col, lprev);
   u1 = fma(t, ri, 1.5);
+  fb_sv_gap<C, 5>(X, col, lprev);
   fb_sv_gap<C, 6>(X, col, lprev);
   ri = ri * u1;
   fb_sv_gap<C, 7>(X, col, lprev);
+  fb_sv_gap<C, 8>(X, col, lprev);
   const double l = X[C] * ri;       // lower half: L[rr][C]; upper half: Linv[C][rr]
   X[C] = l;
-  fb_sv_gap<C, 8>(X, col, lprev);
   if constexpr (C + 1 < FB_SV_NB) {
     if constexpr (C + 2 < FB_SV_NB) {
       bc[(C & 1) * 64 + lane] = l;  // for the columns behind C + 1, one pivot later; a wave's LDS accesses stay in order
