@@ -476,3 +476,75 @@ def test_pipeline_option_precedence_and_dropin_defaults(monkeypatch):
             % (os.path.join(root, "fakebob_amd", "dropin"), root))
     env = {k: v for k, v in os.environ.items() if k not in ("FB_TEXT_SCORES", "FB_COMPRESS_FEATS", "FB_MFCC_F32")}
     subprocess.run([sys.executable, "-c", code], check=True, env=env)
+
+
+def test_class_default_float32_mfcc_falls_back_and_dropin_classes_pickle_by_reference(tmp_path, monkeypatch):
+    """Round-4 advisor findings on the host side.  (1) The drop-in subclasses ask for Kaldi's float32 MFCC arithmetic by
+    class default; a configuration outside the float32 kernel's shape (raw-energy=false, > 31 mel bins, ...) must then
+    fall back to the float64 kernel with a warning -- it worked before the default existed --, while an explicit keyword
+    or FB_MFCC_F32=1 keeps the error.  (2) A library system built on an engine whose pipeline flags an earlier drop-in
+    system switched on warns that it inherits them.  (3) The drop-in classes carry their own module and qualified name,
+    so they pickle by reference."""
+    import pickle
+    import sys
+    import warnings
+    from fakebob_amd import systems as S
+    from fakebob_amd._native import NativeError
+
+    class Cfg(object):
+        text_scores = compress_feats = mfcc_f32 = 0
+
+    class Eng(object):
+        def __init__(self, f32_ok):
+            self.cfg, self.calls, self.f32_ok = Cfg(), [], f32_ok
+
+        def set_frontend(self, **kw):
+            self.calls.append(dict(kw))
+            if kw.get("mfcc_f32") and not self.f32_ok:
+                raise NativeError(-1, "mfcc_f32 needs padded_length 512, raw_energy, ...")
+            for k, v in kw.items():
+                setattr(self.cfg, k, v)
+
+    for k in ("FB_MFCC_F32", "FB_TEXT_SCORES", "FB_COMPRESS_FEATS"):
+        monkeypatch.delenv(k, raising=False)
+    e = Eng(f32_ok=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        S._apply_frontend(e, {"raw_energy": 0}, None, None, None, S.REFERENCE_PIPELINE)
+    assert len(e.calls) == 2 and e.calls[0]["mfcc_f32"] == 1 and e.calls[1]["mfcc_f32"] == 0 and e.calls[1]["raw_energy"] == 0
+    assert e.cfg.mfcc_f32 == 0 and e.cfg.text_scores == 1 and any("float64 kernel" in str(x.message) for x in w)
+    for kw, env in ((True, None), (None, "1")):            # asked for explicitly: the error stands
+        e = Eng(f32_ok=False)
+        if env:
+            monkeypatch.setenv("FB_MFCC_F32", env)
+        with pytest.raises(NativeError):
+            S._apply_frontend(e, {"raw_energy": 0}, None, None, kw, S.REFERENCE_PIPELINE)
+        monkeypatch.delenv("FB_MFCC_F32", raising=False)
+        assert len(e.calls) == 1
+    e = Eng(f32_ok=True)                                   # a shape the kernel takes: one call, no warning
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        S._apply_frontend(e, {}, None, None, None, S.REFERENCE_PIPELINE)
+    assert len(e.calls) == 1 and e.cfg.mfcc_f32 == 1 and not w
+    with warnings.catch_warnings(record=True) as w:       # a library class (no defaults) on that engine inherits the flags
+        warnings.simplefilter("always")
+        S._apply_frontend(e, {}, None, None, None, None)
+    assert len(e.calls) == 1 and any("inherits" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:       # ... and says what it wants when it names them
+        warnings.simplefilter("always")
+        S._apply_frontend(e, {}, False, False, False, None)
+    assert e.cfg.mfcc_f32 == 0 and e.cfg.text_scores == 0 and not w
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fakebob_amd", "dropin"))
+    try:
+        import gmm_ubm_OSI as D1
+        import ivector_PLDA_SV as D2
+        for mod, name in ((D1, "gmm_OSI"), (D2, "iv_SV")):
+            cls = getattr(mod, name)
+            assert cls.__module__ == mod.__name__ and cls.__qualname__ == name and cls.PIPELINE == S.REFERENCE_PIPELINE
+            assert pickle.loads(pickle.dumps(cls)) is cls
+            assert issubclass(cls, getattr(S, name)) and getattr(S, name).PIPELINE is None
+    finally:
+        sys.path.pop(0)
+        for m in ("gmm_ubm_OSI", "ivector_PLDA_SV"):
+            sys.modules.pop(m, None)
