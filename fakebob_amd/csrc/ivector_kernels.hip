@@ -97,7 +97,9 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 //  k_gmm_fx2 with the lists 64.7 us (four chunks) / 73.0 (eight) against the dump's 51.4 -- some lane of the 64 inserts
 //  in nearly every round, 16 + 16 ln(n / 16) insertions per lane are ~100 rounds per chunk --, the merge 80 - 123 us
 //  against this kernel's 45 (20 wave-maximum rounds over the keys, ~22 scattered 576-byte parameter rows per frame,
-//  20 arg-max rounds): 153 us against 97.  Removed; the dump stays.)
+//  20 arg-max rounds): 153 us against 97.  Removed; the dump stays.  Also built and removed: this kernel with TWO frames per
+//  wave (a frame over a half-wave, 64 values per lane, every round's instructions serving two frames): bit-identical, and
+//  84.9 us against 45 -- at 141 registers three waves per SIMD no longer hide the 16 KB a wave waits for.)
 template <int NJ>
 __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
                                                    const int *__restrict__ n_rows_ptr, int *__restrict__ sel) {
