@@ -129,6 +129,8 @@ struct fb_engine {
   int evg_n = 0;
   int t_max = 0;
   std::vector<int32_t> h_frame_rec;
+  int uni_T = 0;        // frames per utterance when every utterance of the batch has the same length (NES batches), else 0
+  int64_t uni_n = 0;    // ... and that length
   DevBuf wav, wav_off, frame_off, chunk_off, chunk_sum, mfcc, mfcc_cm, vrank, tv, row_off, dfeat, feats, part_m, part_s, raw;
   std::vector<int64_t> h_wav_off;
   std::vector<int> h_frame_off, h_chunk_off;
@@ -370,7 +372,7 @@ extern "C" int fb_set_frontend(fb_engine *e, const fb_frontend_cfg *c) {
   // tables exactly as they were
   if (sizeof(double) * (size_t)(fb_mfcc_layout_doubles(P, L, nb, nc, (int)mel_w.size())) > 150 * 1024)
     return fb_fail(FB_E_ARG, "front-end tables do not fit LDS (padded_length %d, %d mel bins)", P, nb);
-  const bool f32_shape = P == 512 && nb <= 31 && nc <= 32 && (L & 1) == 0;  // k_mfcc_f32's tables exist for these
+  const bool f32_shape = P == 512 && nb <= 31 && nc <= 32 && (L & 1) == 0 && fb_mfcc_f32_mel_pieces(mel_len.data(), nb) <= 64;  // k_mfcc_f32's tables exist for these
   if (c->mfcc_f32 && !(f32_shape && c->raw_energy != 0))
     return fb_fail(FB_E_ARG, "mfcc_f32 needs padded_length 512, raw_energy, <= 31 mel bins, <= 32 cepstra and an even frame length");
   std::vector<float> t32;
@@ -1077,6 +1079,12 @@ static int prepare_batch(fb_engine *e, const int64_t *off, int B) {
     if (T > e->cfg.cmn_window) e->any_long = true;
     if (T > e->t_max) e->t_max = T;
   }
+  {  // equal lengths: k_mfcc_f32 computes a frame's record instead of loading it
+    bool uni = true;
+    for (int b = 1; b < B && uni; ++b) uni = (off[b + 1] - off[b]) == (off[1] - off[0]);
+    e->uni_T = uni ? e->h_frame_off[1] : 0;
+    e->uni_n = uni ? off[1] - off[0] : 0;
+  }
   {  // per-frame records for k_mfcc_r16: {absolute start sample (int64), start within the utterance, n}
     const int total = e->h_frame_off[B];
     e->h_frame_rec.resize((size_t)4 * total);
@@ -1260,7 +1268,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   }
   FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * e->n_out));
   hipStream_t s = e->stream;
-  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), total_frames, e->mfcc.as<float>())))
+  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), total_frames, e->mfcc.as<float>(), e->uni_T, e->uni_n, e->h_wav_off[0])))
     fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
                    e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, B));
@@ -2414,7 +2422,7 @@ static int debug_frontend(fb_engine *e, const int16_t *wav, int64_t n) {
   FBCHK(e->row_off.ensure(sizeof(int) * 2));
   FBCHK(e->feats.ensure(sizeof(float) * (size_t)T * fe.dim));
   hipStream_t s = e->stream;
-  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), T, e->mfcc.as<float>())))
+  if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), T, e->mfcc.as<float>(), e->uni_T, e->uni_n, e->h_wav_off[0])))
     fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
                    e->frame_rec.as<int32_t>(), 1, T, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, 1));

@@ -120,11 +120,14 @@ void fb_launch_mfcc(hipStream_t s, const FbFrontendDev &fe, int melw_n, const in
 bool fb_mfcc_f32_supported(const FbFrontendDev &fe);
 // the float32 table blob of k_mfcc_f32 (its LDS image up to the per-wave buffers) from the float64 host tables
 #include <vector>
+int fb_mfcc_f32_mel_pieces(const int *mel_len, int nb);  // chunks of 12 weights the filters split into (k_mfcc_f32: <= 64)
 std::vector<float> fb_mfcc_f32_table(int L, int nb, int nc, const double *window, const double *tw_half, const double *tw_full,
                                      const int *mel_first, const int *mel_len, const int *mel_off, const double *mel_w, int melw_n,
                                      const double *dct, const double *lifter);
+// uni_T > 0: every utterance has uni_n samples / uni_T frames and the first one starts at sample uni_base -- a frame's
+// record is computed, not loaded (one dependent global round trip less at the head of every wave)
 bool fb_launch_mfcc_f32(hipStream_t s, const FbFrontendDev &fe, int melw_n, const int16_t *wav, const int32_t *frame_rec,
-                        int total_frames, float *mfcc);
+                        int total_frames, float *mfcc, int uni_T = 0, int64_t uni_n = 0, int64_t uni_base = 0);
 // VAD + per-utt voiced ranks.  vrank[f] = rank among voiced frames of its utt or -1; tv[b].
 // counter: one device int, zero before the first launch (the kernel leaves it at zero); row_off[B+1]
 // = exclusive scan of max(tv, 0), written by the workgroup that finishes last

@@ -298,8 +298,8 @@ static void fft_c2c(const fbo_mfcc_tables *t, double *re, double *im) {
  *   - mean = (float)sum / (float)L; d(s) = x[s] - mean; y[s] = (d(s) - pre d(s-1)) win[s], d(-1) := d(0);
  *   - z[p] = (y[2p], y[2p+1]); 256-point complex DFT as 16 x 16: dft16 over a of z[16 a + t], times W256^(t k1),
  *     dft16 over t; a dft16 is 4 x dft4, the W16 twiddles, 4 x dft4;
- *   - real-FFT unpack, power, mel sums, log (the polynomial log of the product, float64, then one rounding to float32),
- *     DCT sums, lifter.
+ *   - real-FFT unpack, power, mel sums (chunks of 12 weights), log (the polynomial log of the product, float64, then
+ *     one rounding to float32), DCT sums (two half rows), lifter.
  * Only what the recipe uses is taken (padded_length 512, raw energy); anything else returns 0 frames. */
 typedef struct { float x, y; } c32;
 static c32 c32_add(c32 a, c32 b) { c32 r = {a.x + b.x, a.y + b.y}; return r; }
@@ -408,17 +408,26 @@ static int fbo_mfcc_f32(const fbo_frontend_cfg *c, const int16_t *wav, int64_t n
       pw[k] = 0.25f * fmaf(xr, xr, xi * xi);
     }
     for (int b = 0; b < nb; ++b) {
+      /* the filter's weights in chunks of 12: every chunk an in-order fmaf chain from zero, the chunk sums added left
+       * to right (the product gives a chunk to one lane) */
       float e = 0.0f;
       const float *w = t->mel_w + (size_t)b * Nc;
-      for (int i = t->mel_first[b]; i < t->mel_first[b] + t->mel_len[b]; ++i) e = fmaf(w[i], pw[i], e);
+      const int first = t->mel_first[b], len = t->mel_len[b];
+      for (int c0 = 0; c0 < len; c0 += 12) {
+        float ch = 0.0f;
+        for (int i = first + c0; i < first + (c0 + 12 < len ? c0 + 12 : len); ++i) ch = fmaf(w[i], pw[i], ch);
+        e = c0 == 0 ? ch : e + ch;
+      }
       double ed = (double)e;
       if (ed < (double)FLT_EPSILON) ed = (double)FLT_EPSILON;
       lm[b] = (float)log_poly_f64(ed);
     }
-    for (int k = 0; k < nc; ++k) {
-      float acc = 0.0f;
-      for (int b = 0; b < nb; ++b) acc = fmaf(t->dct[k * nb + b], lm[b], acc);
-      out[(size_t)f * nc + k] = acc * t->lifter[k];
+    for (int k = 0; k < nc; ++k) { /* the row as two halves, each an in-order fmaf chain, added */
+      const int hl = (nb + 1) / 2;
+      float a0 = 0.0f, a1 = 0.0f;
+      for (int b = 0; b < hl; ++b) a0 = fmaf(t->dct[k * nb + b], lm[b], a0);
+      for (int b = hl; b < nb; ++b) a1 = fmaf(t->dct[k * nb + b], lm[b], a1);
+      out[(size_t)f * nc + k] = (a0 + a1) * t->lifter[k];
     }
     if (c->use_energy) {
       double le = log_poly_f64(energy > (double)FLT_EPSILON ? energy : (double)FLT_EPSILON);

@@ -23,7 +23,14 @@ def engine32():
     e.close()
 
 
-def test_mfcc_f32_matrix_is_bit_identical_to_the_oracle_twin(engine32, oracle):
+@pytest.mark.parametrize("path", ["default", "FB_MFCC_HALFWORDS", "FB_MFCC_RECORDS"])
+def test_mfcc_f32_matrix_is_bit_identical_to_the_oracle_twin(engine32, oracle, path, monkeypatch):
+    """A lone utterance takes the kernel's fast paths: frame records computed from the common utterance length, and one
+    32-bit load per sample pair (every interior frame starts on an even sample).  FB_MFCC_HALFWORDS: the 16-bit loads
+    that frames at an odd sample offset of a packed batch take; FB_MFCC_RECORDS: the per-frame records a batch of
+    different lengths loads."""
+    if path != "default":
+        monkeypatch.setenv(path, "1")
     cfg32, cfg64 = oracle.default_cfg(mfcc_f32=1), oracle.default_cfg()
     rng = np.random.default_rng(5)
     wavs = [_wav(0), _wav(1, 16000), (rng.normal(size=30000) * 4000).astype(np.int16), np.zeros(8000, np.int16),
