@@ -1346,8 +1346,20 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
 // workgroup with a smaller ticket is running or done.  A part also waits for LATER tickets -- the other parts of its own
 // utterance --, which cannot deadlock: at any time at most one utterance is only partly started, every other started
 // utterance has all its parts running and completes without anybody else's help, freeing its slots.
-template <int ORDER, int WIN>
-__global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, const float *__restrict__ mfcc,
+#ifdef FB_VAD_STAMP  // instrumented build (tools/profile/vad_instrumented.sh): where a workgroup of k_vad_delta_cmvn_p spends its time
+__device__ unsigned long long g_vad_stamps[256 * 12];
+extern "C" int fb_debug_vad_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vad_stamps), sizeof(g_vad_stamps)) == hipSuccess ? 0 : -1;
+}
+#define VD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_vad_stamps[blockIdx.x * 12 + (k)] = wall_clock64(); } while (0)
+#else
+#define VD_STAMP(k) do { } while (0)
+#endif
+// NC > 0: the number of cepstra as a compile-time constant (the recipe's 24): the row strides of the delta taps, the block
+// sums and the row writes become instruction immediates -- with one wave per SIMD every address instruction is exposed.
+#define FB_VADP_THREADS 512
+template <int ORDER, int WIN, int NC>
+__global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontendDev fe, const float *__restrict__ mfcc,
                                                           const int *__restrict__ frame_off, int B, int t_cap,
                                                           unsigned epoch, int *__restrict__ ticket,
                                                           unsigned long long *__restrict__ pub, int *__restrict__ tv,
@@ -1358,29 +1370,25 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     // the host counts this launch, so the next one polls the slot set the last REAL launch filled.  Workgroup i puts the
     // sentinel back into the i-th (utterance, part) slot of that set (any bijection does).
     unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((slot_set + 1u) & 1u) * B * FB_CMVN_PARTS * fe.dim;
-    for (int d = threadIdx.x; d < fe.dim; d += 256)
+    for (int d = threadIdx.x; d < fe.dim; d += FB_VADP_THREADS)
       __hip_atomic_store(&nxt[(size_t)blockIdx.x * fe.dim + d], FB_VAD_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
+  VD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  __shared__ int s_tk, s_run, s_wtot[4], s_rbase;
+  constexpr int NT = FB_VADP_THREADS, NW = NT / 64;  // two waves per SIMD: the float64 tap chains and LDS round trips of one hide behind the other's
+  __shared__ int s_tk, s_wtot[NW], s_wt2[NW], s_rbase;
   __shared__ float s_thr;
   constexpr int NP = FB_CMVN_PARTS;
-  const int nc = fe.nc, dim = fe.dim, tid = threadIdx.x;
+  const int nc = NC > 0 ? NC : fe.nc, dim = NC > 0 && ORDER > 0 ? NC * (ORDER + 1) : fe.dim, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
+  // (atomicInc wraps to zero behind the last ticket: nobody else will draw)
   if (tid == 0) {
-    const int tk = atomicAdd(ticket, 1);
-    if (tk == B * NP - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else will draw
-    s_tk = tk;
-    s_run = 0;
+    s_tk = (int)atomicInc(reinterpret_cast<unsigned *>(ticket), (unsigned)(B * NP - 1));
   }
-  __syncthreads();
-  const int b = s_tk / NP, part = s_tk - b * NP;
-  const int base = frame_off[b], T = frame_off[b + 1] - base;
   const int order = ORDER > 0 ? ORDER : fe.order, dwin = ORDER > 0 ? WIN : fe.dwin;
   const int maxlen = 2 * order * dwin + 1, ctx = order * dwin;
-  const int tq = (T + NP - 1) / NP, tq_cap = (t_cap + NP - 1) / NP;
-  const int t0 = min(T, part * tq), t1 = min(T, t0 + tq), Tn = t1 - t0;   // own frames
+  const int tq_cap = (t_cap + NP - 1) / NP;
   double *s_sum = s_dyn;                                        // [dim]
   double *s_sc = s_sum + dim;                                   // [(order+1)][maxlen]
   double *s_red = s_sc + (order + 1) * maxlen;                  // [256]
@@ -1388,20 +1396,54 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   float *s_mf = s_c0 + ((t_cap + 1) & ~1);                      // [ctx + tq_cap + ctx][nc] own rows, edges clamped
   float *s_df = s_mf + (size_t)(tq_cap + 2 * ctx) * nc;         // [tq_cap][dim]
   int *s_vr = reinterpret_cast<int *>(s_df + (size_t)tq_cap * dim);  // [t_cap]
-  for (int i = tid; i < (order + 1) * maxlen; i += 256) s_sc[i] = fe.dscale[i];
+  const int n_sc = (order + 1) * maxlen;
+  const double sc_own = fe.dscale[min(tid, n_sc - 1)];          // (in flight while the ticket is drawn)
+  __syncthreads();
+  VD_STAMP(1);
+  const int b = s_tk / NP, part = s_tk - b * NP;
+  const int base = frame_off[b], T = frame_off[b + 1] - base;
+  const int tq = (T + NP - 1) / NP;
+  const int t0 = min(T, part * tq), t1 = min(T, t0 + tq), Tn = t1 - t0;   // own frames
   {
+    // All of a thread's loads are issued before the first of them is waited for (unconditional loads on clamped
+    // indices): a plain copy loop waits once per trip.  (Staging the rows of the GUESS ticket == blockIdx while the
+    // atomic is in flight was tried: the 204 atomics race, almost no workgroup draws its own index, and staging twice
+    // costs more than the round trip saved.)
     const float *src = mfcc + (size_t)base * nc;
-    for (int t = tid; t < T; t += 256) s_c0[t] = src[(size_t)t * nc];
     const int n = (Tn + 2 * ctx) * nc;
-    for (int i = tid; i < n; i += 256) {
-      const int r = i / nc, d = i - r * nc;
+    constexpr int KC = 1, KM = 5;
+    float c0v[KC], mv[KM];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) c0v[k] = src[(size_t)min(tid + NT * k, T - 1) * nc];
+    int r = tid / nc, d = tid - r * nc;                         // row / column of element tid + NT k, stepped without dividing
+    const int dr = NT / nc, dd = NT - dr * nc;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
       const int tt = min(max(t0 - ctx + r, 0), T - 1);          // Kaldi clamps the frame index at both ends
-      s_mf[i] = src[(size_t)tt * nc + d];
+      mv[k] = src[(size_t)tt * nc + d];                         // (behind the last element: a clamped row, never stored)
+      r += dr;
+      d += dd;
+      if (d >= nc) { d -= nc; ++r; }
     }
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (tid + NT * k < T) s_c0[tid + NT * k] = c0v[k];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (tid + NT * k < n) s_mf[tid + NT * k] = mv[k];
+    for (int t = tid + NT * KC; t < T; t += NT) s_c0[t] = src[(size_t)t * nc];   // (longer than the recipe's shapes)
+    for (int i = tid + NT * KM; i < n; i += NT) {
+      const int r2 = i / nc, d2 = i - r2 * nc;
+      const int tt = min(max(t0 - ctx + r2, 0), T - 1);
+      s_mf[i] = src[(size_t)tt * nc + d2];
+    }
+    if (tid < n_sc) s_sc[tid] = sc_own;
+    for (int i = tid + NT; i < n_sc; i += NT) s_sc[i] = fe.dscale[i];
   }
   __syncthreads();
+  VD_STAMP(2);
   // ---- VAD of the whole utterance on the C0 column (k_vad's arithmetic: 256 strided float64 partial sums, binary tree)
-  {
+  if (tid < 256) {
     double prt = 0.0;
     for (int t = tid; t < T; t += 256) prt += (double)s_c0[t];
     s_red[tid] = prt;
@@ -1414,7 +1456,11 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   if (tid == 0) s_thr = (float)(fe.vad_thr + fe.vad_mean_scale * s_red[0] / (double)T);
   __syncthreads();
   const float thr = s_thr;
-  for (int tb = 0; tb < T; tb += 256) {
+  VD_STAMP(3);
+  // votes and voiced ranks, NT frames per trip (one for the recipe's utterances): a ballot per wave, ONE barrier, and
+  // every thread adds up the wave counts itself
+  int run = 0;
+  for (int tb = 0; tb < T; tb += NT) {
     const int t = tb + tid;
     int v = 0;
     if (t < T) {
@@ -1425,16 +1471,20 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     }
     const unsigned long long bal = __ballot(v);
     const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wtot[w] = __popcll(bal);
+    if (lane == 0) s_wt2[w] = __popcll(bal);
     __syncthreads();
-    int woff = 0;
-    for (int i = 0; i < w; ++i) woff += s_wtot[i];
-    if (t < T) s_vr[t] = v ? (s_run + woff + pre) : -1;
-    __syncthreads();
-    if (tid == 0) s_run += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-    __syncthreads();
+    int before = run;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int c = s_wt2[i];
+      if (i == w && t < T) s_vr[t] = v ? before + pre : -1;
+      before += c;
+    }
+    run = before;
+    if (tb + NT < T) __syncthreads();
   }
-  const int n_voiced = s_run;
+  const int n_voiced = run;
+  VD_STAMP(4);
   if (tid == 0 && part == 0) {
     tv[b] = n_voiced;
     __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELAXED,
@@ -1448,8 +1498,10 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
       for (int j = 0; j < 2 * ORDER * WIN + 1; ++j) creg[i][j] = s_sc[i * (2 * ORDER * WIN + 1) + j];
   }
   // ---- add-deltas of the own frames: thread = (frame, coefficient) pairs in flat order; float64 taps in order
-  for (int idx = tid; idx < Tn * nc; idx += 256) {
-    const int t = idx / nc, d = idx - t * nc;                   // t: own frame index; its row in s_mf is t + ctx
+  int t = tid / nc, d = tid - t * nc;                           // t: own frame index; its row in s_mf is t + ctx
+  const int t_step = NT / nc, d_step = NT - t_step * nc;        // (frame, coefficient) of idx + NT without dividing
+  for (int idx = tid; idx < Tn * nc; idx += NT, t += t_step, d += d_step) {
+    if (d >= nc) { d -= nc; ++t; }
     if constexpr (ORDER > 0) {
 #pragma unroll
       for (int i = 0; i <= ORDER; ++i) {
@@ -1478,6 +1530,7 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     }
   }
   __syncthreads();
+  VD_STAMP(5);
   // ---- this part's block of the CMVN column sums (frame by frame from zero), exchanged with the other parts.
   //      No flags and no fences: a block sum is ONE 64-bit word, stored and polled with relaxed agent-scope atomics; a
   //      slot that still holds the sentinel (a NaN no sum can be: a NaN sum is stored as another NaN) has not been
@@ -1491,7 +1544,9 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   unsigned long long *cur = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)(slot_set & 1u) * B * NP * dim;
   unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((slot_set + 1u) & 1u) * B * NP * dim;
   double own = 0.0;
-  for (int d = tid; d < dim; d += 256) {   // (dim <= 256: at most one dimension per thread)
+  for (int d = tid; d < dim; d += NT) {   // (dim <= 256: at most one dimension per thread)
+    // frame by frame from zero.  (Requesting the next eight values before these eight are added, with a branch-free
+    // tail, was tried twice: 1.3 -> 2.0 us -- the selects and clamps cost this single wave more than the round trips.)
     double acc = 0.0;
     int t = 0;
     for (; t + 8 <= Tn; t += 8) {
@@ -1508,10 +1563,11 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     __hip_atomic_store(&cur[((size_t)b * NP + part) * dim + d], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&nxt[((size_t)b * NP + part) * dim + d], SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  VD_STAMP(6);
   // ---- row offset: voiced counts of the utterances before this one (the count travels IN the polled word)
   {
     int mine = 0;
-    for (int i = tid; i < b; i += 256) {
+    for (int i = tid; i < b; i += NT) {
       unsigned long long v;
       do {
         v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1523,7 +1579,8 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if (lane == 0) s_wtot[w] = mine;
   }
-  for (int d = tid; d < dim; d += 256) {
+  VD_STAMP(7);
+  for (int d = tid; d < dim; d += NT) {
     double tot = 0.0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -1541,7 +1598,8 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
   }
   __syncthreads();
   if (tid == 0) {
-    const int a = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    int a = 0;
+    for (int i = 0; i < NW; ++i) a += s_wtot[i];
     s_rbase = a;
     if (part == 0) {
       row_off[b] = a;
@@ -1549,13 +1607,17 @@ __global__ __launch_bounds__(256) void k_vad_delta_cmvn_p(FbFrontendDev fe, cons
     }
   }
   __syncthreads();
+  VD_STAMP(8);
   // ---- CMVN + voiced-row compaction of the own frames: thread = (frame, dimension) pairs in flat order
   const int rbase = s_rbase;
-  for (int idx = tid; idx < Tn * dim; idx += 256) {
-    const int t = idx / dim, d = idx - t * dim;
-    const int r = s_vr[t0 + t];
-    if (r >= 0) feats[(size_t)(rbase + r) * dim + d] = (float)__dadd_rn((double)s_df[idx], s_sum[d]);
+  int tw = tid / dim, dw = tid - tw * dim;
+  const int tw_step = NT / dim, dw_step = NT - tw_step * dim;
+  for (int idx = tid; idx < Tn * dim; idx += NT, tw += tw_step, dw += dw_step) {
+    if (dw >= dim) { dw -= dim; ++tw; }
+    const int r = s_vr[t0 + tw];
+    if (r >= 0) feats[(size_t)(rbase + r) * dim + dw] = (float)__dadd_rn((double)s_df[idx], s_sum[dw]);
   }
+  VD_STAMP(9);
 }
 size_t fb_vad_delta_cmvn_p_lds_bytes(const FbFrontendDev &fe, int t_cap) {
   const int maxlen = 2 * fe.order * fe.dwin + 1, tq_cap = (t_cap + FB_CMVN_PARTS - 1) / FB_CMVN_PARTS;
@@ -1583,21 +1645,23 @@ bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const fl
     unsigned long long bit = 0;
     bool ok = true;
     if (fb_device_needs_optin(optin, &bit)) {
-      const void *fns[] = {reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 3>), reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 2>),
-                           reinterpret_cast<const void *>(k_vad_delta_cmvn_p<-1, 0>)};
+      const void *fns[] = {reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 3, 24>), reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 3, 0>),
+                           reinterpret_cast<const void *>(k_vad_delta_cmvn_p<2, 2, 0>), reinterpret_cast<const void *>(k_vad_delta_cmvn_p<-1, 0, 0>)};
       for (const void *fn : fns)
         ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
       if (ok) optin.fetch_or(bit, std::memory_order_release);
     }
     if (ok) shm = std::max(shm, (size_t)82 * 1024);
   }
-  const dim3 grid((unsigned)(B * FB_CMVN_PARTS)), blk(256);
-  if (fe.order == 2 && fe.dwin == 3)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
+  const dim3 grid((unsigned)(B * FB_CMVN_PARTS)), blk(FB_VADP_THREADS);
+  if (fe.order == 2 && fe.dwin == 3 && fe.nc == 24 && fe.dim == 72)
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3, 24>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
+  else if (fe.order == 2 && fe.dwin == 3)
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 3, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   else if (fe.order == 2 && fe.dwin == 2)
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<2, 2, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   else
-    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
+    hipLaunchKernelGGL((k_vad_delta_cmvn_p<-1, 0, 0>), grid, blk, shm, s, fe, mfcc, frame_off, B, t_max, epoch, ticket, pub, tv, row_off, feats, part_sum, slot_set);
   return true;
 }
 
