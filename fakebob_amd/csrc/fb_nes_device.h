@@ -83,6 +83,12 @@ __device__ __forceinline__ T fb_np_sum(F elem, int lo, int n) {
 // recursion stack (the stack lives in scratch memory, which also slows the dispatch down)
 // FUSED: the caller is the last workgroup of k_gmm_finalize_loss; raw[] was written by OTHER workgroups of the same
 // launch and is read with agent-scope loads.
+#ifdef FB_FIN_STAMP  // instrumented build of k_gmm_finalize_loss_update (tools/profile/fin_instrumented.sh): only gmm_kernels.hip is built with it
+static __device__ unsigned long long g_fin_stamps[1024 * 12];
+#define FN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fin_stamps[blockIdx.x * 12 + (k)] = wall_clock64(); } while (0)
+#else
+#define FN_STAMP(k) do { } while (0)
+#endif
 template <bool SMALL, bool FUSED>
 __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, const int *__restrict__ tv,
                                               int B, int M, int task, int znorm_all, int attack_type,
@@ -112,15 +118,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
   const double dist_first = (int)threadIdx.x < n_dist_part ? dist_part[threadIdx.x] : 0.0;  // in flight with the rest
   FbCtlDev c = {};
   double lsv[FB_LS_LOCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (threadIdx.x == 0) {
-    if (ctl) {
-      c = *ctl;
-      if (c.plateau_length > 0 && c.plateau_length <= FB_LS_LOCAL) {
-#pragma unroll
-        for (int i = 0; i < FB_LS_LOCAL; ++i) lsv[i] = c.ls[i < c.plateau_length ? i : c.plateau_length - 1];
-      }
-    }
-  }
+  if (threadIdx.x == 0 && ctl) c = *ctl;
   int my_err = 0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     if (tv && tv[b] <= 0) my_err = b + 1 > my_err ? b + 1 : my_err;
@@ -143,40 +141,99 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
       return FUSED ? fb_ld_agent_f64(raw + (size_t)b * M + m) : raw[(size_t)b * M + m];
     };
     double *sc = sc_lds ? s_sc + (size_t)b * S : scores + (size_t)b * S;
-    if (task == FB_TASK_CSI || znorm_all) {
-      // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
-      for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r(m), z_mean[m]), z_std[m]);
-    } else {
-      const double r_ubm = r(0);
-      for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r(1 + m), r_ubm);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
-    }
-    if (sc_lds) for (int m = 0; m < S; ++m) scores[(size_t)b * S + m] = sc[m];
+#ifdef FB_FIN_STAMP
+    if (rv[0] == 12345.678) FN_STAMP(11); else FN_STAMP(11);  // (raw scores arrived)
+#endif
     double l;
-    if (task == FB_TASK_SV) {
-      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
-    } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
-      double mx = -INFINITY;
-      for (int m = 0; m < S; ++m) mx = sc[m] > mx ? sc[m] : mx;
-      l = __dsub_rn(__dadd_rn(threshold, adver_thresh), mx);  // :269
-    } else if (task == FB_TASK_OSI) {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
-      double mx = om > threshold ? om : threshold;
-      l = __dsub_rn(__dadd_rn(mx, adver_thresh), sc[target]);  // :262
-    } else if (attack_type == FB_TARGETED) {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
-      l = __dsub_rn(__dadd_rn(om, adver_thresh), sc[target]);  // :281
+    if (M <= FB_RAW_LOCAL) {
+      // at most eight scores: they stay in registers (the general path below writes them to LDS and reads every one back
+      // through run-time loops -- a dozen dependent LDS round trips in the one workgroup everybody waits for); the same
+      // operations on the same values in the same order
+      double scr[FB_RAW_LOCAL];
+      if (task == FB_TASK_CSI || znorm_all) {
+        double zm[FB_RAW_LOCAL], zs[FB_RAW_LOCAL];
+#pragma unroll
+        for (int m = 0; m < FB_RAW_LOCAL; ++m) { zm[m] = z_mean[m < M ? m : M - 1]; zs[m] = z_std[m < M ? m : M - 1]; }
+#pragma unroll
+        for (int m = 0; m < FB_RAW_LOCAL; ++m) scr[m] = __ddiv_rn(__dsub_rn(rv[m], zm[m]), zs[m]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < FB_RAW_LOCAL; ++m) scr[m] = __dsub_rn(rv[m + 1 < FB_RAW_LOCAL ? m + 1 : FB_RAW_LOCAL - 1], rv[0]);
+      }
+#pragma unroll
+      for (int m = 0; m < FB_RAW_LOCAL; ++m)
+        if (m < S) {
+          sc[m] = scr[m];
+          if (sc_lds) scores[(size_t)b * S + m] = scr[m];
+        }
+      auto pick = [&](int i) -> double {
+        double v = scr[0];
+#pragma unroll
+        for (int q = 1; q < FB_RAW_LOCAL; ++q) v = i == q ? scr[q] : v;
+        return v;
+      };
+      auto max_but = [&](int skip) -> double {   // max over m < S, m != skip, in index order
+        double om = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < FB_RAW_LOCAL; ++m)
+          if (m < S && m != skip) om = scr[m] > om ? scr[m] : om;
+        return om;
+      };
+      if (task == FB_TASK_SV) {
+        l = __dsub_rn(__dadd_rn(threshold, adver_thresh), scr[0]);  // FAKEBOB.py:297
+      } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
+        l = __dsub_rn(__dadd_rn(threshold, adver_thresh), max_but(-1));  // :269
+      } else if (task == FB_TASK_OSI) {
+        const double om = max_but(target);
+        const double mx = om > threshold ? om : threshold;
+        l = __dsub_rn(__dadd_rn(mx, adver_thresh), pick(target));  // :262
+      } else if (attack_type == FB_TARGETED) {
+        l = __dsub_rn(__dadd_rn(max_but(target), adver_thresh), pick(target));  // :281
+      } else {
+        l = __dsub_rn(__dadd_rn(pick(true_label), adver_thresh), max_but(true_label));  // :291
+      }
     } else {
-      double om = -INFINITY;
-      for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
-      l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
+      if (task == FB_TASK_CSI || znorm_all) {
+        // gmm_ubm_CSI.py:93; ivector_PLDA_OSI.py:119 / _CSI.py:118 / _SV.py:85
+        for (int m = 0; m < M; ++m) sc[m] = __ddiv_rn(__dsub_rn(r(m), z_mean[m]), z_std[m]);
+      } else {
+        const double r_ubm = r(0);
+        for (int m = 0; m < S; ++m) sc[m] = __dsub_rn(r(1 + m), r_ubm);  // gmm_ubm_OSI.py:89, gmm_ubm_SV.py:77
+      }
+      if (sc_lds) for (int m = 0; m < S; ++m) scores[(size_t)b * S + m] = sc[m];
+      if (task == FB_TASK_SV) {
+        l = __dsub_rn(__dadd_rn(threshold, adver_thresh), sc[0]);  // FAKEBOB.py:297
+      } else if (task == FB_TASK_OSI && attack_type == FB_UNTARGETED) {
+        double mx = -INFINITY;
+        for (int m = 0; m < S; ++m) mx = sc[m] > mx ? sc[m] : mx;
+        l = __dsub_rn(__dadd_rn(threshold, adver_thresh), mx);  // :269
+      } else if (task == FB_TASK_OSI) {
+        double om = -INFINITY;
+        for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+        double mx = om > threshold ? om : threshold;
+        l = __dsub_rn(__dadd_rn(mx, adver_thresh), sc[target]);  // :262
+      } else if (attack_type == FB_TARGETED) {
+        double om = -INFINITY;
+        for (int m = 0; m < S; ++m) if (m != target) om = sc[m] > om ? sc[m] : om;
+        l = __dsub_rn(__dadd_rn(om, adver_thresh), sc[target]);  // :281
+      } else {
+        double om = -INFINITY;
+        for (int m = 0; m < S; ++m) if (m != true_label) om = sc[m] > om ? sc[m] : om;
+        l = __dsub_rn(__dadd_rn(sc[true_label], adver_thresh), om);  // :291
+      }
     }
     if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(loss + b), (unsigned long long)__double_as_longlong(l),
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else loss[b] = l;
     if (b < FB_LOSS_LDS) s_lv[b] = l;
   }
+  // (the window of recent losses hangs off a pointer IN the control block: requested here, behind the raw scores, it
+  //  arrives during the barrier and the mean below; requested at the top it put a second round trip in front of them)
+  if (threadIdx.x == 0 && ctl && c.plateau_length > 0 && c.plateau_length <= FB_LS_LOCAL) {
+#pragma unroll
+    for (int i = 0; i < FB_LS_LOCAL; ++i) lsv[i] = c.ls[i < c.plateau_length ? i : c.plateau_length - 1];
+  }
+  FN_STAMP(6);
   // max |audio - adver| over the perturb kernel's per-workgroup partials (order-independent: every thread takes a
   // strided share instead of thread 0 walking up to N / 256 entries alone)
   __shared__ double s_dmax[16];   // one per wave (the solve kernels' tail calls this body with 512 threads)
@@ -189,15 +246,22 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(my_err, o, 64); my_err = v > my_err ? v : my_err; }
     if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) s_errw[threadIdx.x >> 6] = my_err;
   }
-  if (pub_seq) __builtin_amdgcn_s_waitcnt(0);   // this thread's loss stores are complete before thread 0 may publish
+  // (pub_seq: a thread's loss stores must be complete before thread 0 publishes -- every thread waits for its own BEHIND
+  //  this barrier, while thread 0 does the serial part below, and a second barrier precedes the publication: the two
+  //  store round trips -- the threads' and thread 0's -- overlap each other and the arithmetic instead of adding up)
   __syncthreads();
+  FN_STAMP(7);
+  // Thread 0: what the pollers of a fused launch wait for -- the stop flag and the step size -- is decided and stored
+  // FIRST and published; the bookkeeping (outputs, the window of losses, the trace row, counters) follows the
+  // publication: 1.5 us of one lane's stores off the path of the 188 workgroups that wait.
+  double al = 0.0, final_loss = 0.0, d = 0.0, lr = c.lr;
+  int s_err = 0, n_ls_new = c.n_ls;
+  bool stop_now = false, broke = false, window = false;
   if (threadIdx.x == 0) {
     const int spd = B - 1;
     const bool lds_l = B <= FB_LOSS_LDS;
-    int s_err = 0;
     for (int i = 0; i < (int)((blockDim.x + 63) >> 6) && i < 16; ++i) s_err = s_errw[i] > s_err ? s_errw[i] : s_err;
-    const double al = lds_l ? s_lv[0] : loss[0];
-    out->adver_loss = al;
+    al = lds_l ? s_lv[0] : loss[0];
     double lsum;
     if (lds_l) {
       auto el = [&](int i) { return D1{s_lv[1 + i]}; };
@@ -207,84 +271,101 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
       lsum = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
     }
     // np.mean :243 -- of an empty slice when samples_per_draw < 2: NaN, like NumPy
-    const double final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
+    final_loss = spd > 0 ? __ddiv_rn(lsum, (double)spd) : __longlong_as_double(0x7ff8000000000000ll);
+    FN_STAMP(8);
+    for (int i = 0; i < (int)(blockDim.x >> 6) && i < 16; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
+    if (ctl) {
+      if (s_err) {
+        stop_now = true;
+      } else if (al < 0.0 && !c.disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
+        stop_now = true;
+        broke = true;
+      } else {  // :195-200
+        const int PL = c.plateau_length;
+        if (PL > 0) {
+          window = true;
+          int n = c.n_ls;
+          bool up = false;
+          if (PL <= FB_LS_LOCAL) {  // the window of recent losses in registers
+            if (n < PL) {
+#pragma unroll
+              for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == n) lsv[i] = final_loss;
+              ++n;
+            } else {
+#pragma unroll
+              for (int i = 1; i < FB_LS_LOCAL; ++i) if (i < PL) lsv[i - 1] = lsv[i];
+#pragma unroll
+              for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) lsv[i] = final_loss;
+            }
+            double last = lsv[0];
+#pragma unroll
+            for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) last = lsv[i];
+            up = n == PL && last > lsv[0];
+          } else {  // (a long window stays in memory)
+            if (n < PL) {
+              c.ls[n++] = final_loss;
+            } else {
+              for (int i = 1; i < PL; ++i) c.ls[i - 1] = c.ls[i];
+              c.ls[PL - 1] = final_loss;
+            }
+            up = n == PL && c.ls[PL - 1] > c.ls[0];
+          }
+          if (up) {
+            if (lr > c.min_lr) {
+              const double l2 = __ddiv_rn(lr, c.plateau_drop);
+              lr = l2 > c.min_lr ? l2 : c.min_lr;
+              if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->lr), (unsigned long long)__double_as_longlong(lr),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else ctl->lr = lr;
+            }
+            n = 0;
+          }
+          n_ls_new = n;
+        }
+      }
+      if (stop_now) {
+        if (pub_seq) __hip_atomic_store(&ctl->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else ctl->stop = 1;
+      }
+    }
+  }
+  FN_STAMP(9);
+  if (pub_seq) {   // everything the pollers read is complete, then the word they poll
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    FN_STAMP(10);
+    __syncthreads();
+    if (threadIdx.x == 0 && ctl) __hip_atomic_store(&ctl->pub_seq, pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {  // the bookkeeping
+    out->adver_loss = al;
     out->final_loss = final_loss;
     const double *sc0 = sc_lds ? s_sc : scores;  // row 0 = the clean adver
     for (int m = 0; m < S && m < 62; ++m) out->score0[m] = sc0[m];
-    double d = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6) && i < 16; ++i) d = s_dmax[i] > d ? s_dmax[i] : d;
     out->distance = d;
     out->err = s_err;
     if (ctl) {
-      double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
-      double lr = c.lr;
-      auto set_stop = [&]() {
-        if (pub_seq) __hip_atomic_store(&ctl->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else ctl->stop = 1;
-      };
       if (s_err) {
         ctl->err = s_err;
-        set_stop();
       } else {
-        if (al < 0.0 && !c.disable_stop) {  // FAKEBOB.py:181 -- break before the learning-rate step
-          set_stop();
+        if (broke) {
           ctl->broke = 1;
           ctl->stop_iter = it;
-        } else {  // :195-200
+        } else if (window) {
           const int PL = c.plateau_length;
-          if (PL > 0) {
-            int n = c.n_ls;
-            bool up = false;
-            if (PL <= FB_LS_LOCAL) {  // the window of recent losses in registers (fetched at the top)
-              if (n < PL) {
+          if (PL <= FB_LS_LOCAL) {
 #pragma unroll
-                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == n) lsv[i] = final_loss;
-                c.ls[n++] = final_loss;
-              } else {
-#pragma unroll
-                for (int i = 1; i < FB_LS_LOCAL; ++i) if (i < PL) lsv[i - 1] = lsv[i];
-#pragma unroll
-                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) lsv[i] = final_loss;
-#pragma unroll
-                for (int i = 0; i < FB_LS_LOCAL; ++i) if (i < PL) c.ls[i] = lsv[i];
-              }
-              double last = lsv[0];
-#pragma unroll
-              for (int i = 0; i < FB_LS_LOCAL; ++i) if (i == PL - 1) last = lsv[i];
-              up = n == PL && last > lsv[0];
-            } else {
-              if (n < PL) {
-                c.ls[n++] = final_loss;
-              } else {
-                for (int i = 1; i < PL; ++i) c.ls[i - 1] = c.ls[i];
-                c.ls[PL - 1] = final_loss;
-              }
-              up = n == PL && c.ls[PL - 1] > c.ls[0];
-            }
-            if (up) {
-              if (lr > c.min_lr) {
-                const double l2 = __ddiv_rn(lr, c.plateau_drop);
-                lr = l2 > c.min_lr ? l2 : c.min_lr;
-                if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->lr), (unsigned long long)__double_as_longlong(lr),
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else ctl->lr = lr;
-              }
-              n = 0;
-            }
-            ctl->n_ls = n;
+            for (int i = 0; i < FB_LS_LOCAL; ++i) if (i < PL) c.ls[i] = lsv[i];
           }
+          ctl->n_ls = n_ls_new;
         }
+        double *row = trace ? trace + (size_t)it * (3 + S) : nullptr;
         if (row) {
           row[0] = d; row[1] = al; row[2] = lr;
           for (int m = 0; m < S; ++m) row[3 + m] = sc0[m];
         }
         if (c.ticks) c.ticks[it + 1] = wall_clock64();  // [0] = the attack's start (k_stamp)
         ctl->iters_done = it + 1;
-      }
-      if (pub_seq) {   // everything the pollers read is complete, then the word they poll
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        __hip_atomic_store(&ctl->pub_seq, pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -305,6 +386,7 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
                                                        const FbCtlDev *__restrict__ ctl, uint64_t seed, uint32_t next_iter,
                                                        uint32_t stream, int16_t *__restrict__ q, double *__restrict__ dist_part,
                                                        double qscale, const int bidx, const int wait_seq, double *s_loss) {
+  FN_STAMP(0);
   const int spd = 2 * half;
   double *s_a = s_loss + spd;
   float *s_z = reinterpret_cast<float *>(s_a + 256);
@@ -332,6 +414,7 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
       if (idx < 64 * half) fb_noise4(seed, next_iter, stream, (uint32_t)(n4_0 + (idx & 63)), (uint32_t)(idx >> 6), zn[u]);
     }
     __shared__ int s_stop;
+    FN_STAMP(1);
     if (threadIdx.x == 0) {
       int st;
       for (;;) {
@@ -342,6 +425,7 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
       // (a stop raised by THIS launch's loss body is published before pub_seq: look again behind it)
       s_stop = st | __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    FN_STAMP(2);
     __syncthreads();
     if (s_stop) return;
     lr = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->lr), __ATOMIC_RELAXED,
@@ -349,6 +433,7 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
     for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = fb_ld_agent_f64(loss + 1 + i);
   }
   __syncthreads();
+  FN_STAMP(3);
   double dmax = 0.0;
   if (threadIdx.x >= 256) {
     // phase 2 only
@@ -393,6 +478,7 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
       dist_part[bidx] = r;
     }
   }
+  FN_STAMP(4);
   // ---- phase 2: the perturbed columns of iteration next_iter for this block's samples
   int u = 0;
   for (int idx = threadIdx.x; idx < 64 * half; idx += blockDim.x, ++u) {
@@ -431,5 +517,6 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
       for (int k = 0; k < cnt; ++k) { zp[k] = zf[k]; qp[k] = vp[k]; qm[k] = vm[k]; }
     }
   }
+  FN_STAMP(5);
 }
 

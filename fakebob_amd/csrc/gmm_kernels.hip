@@ -624,6 +624,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
                                                            double *__restrict__ trace, int it, const int b, const int m,
                                                            const int n_arrive, const int pub_seq) {
   if (ctl && ctl->stop) return;  // queued behind the stopping iteration
+  FN_STAMP(0);
   const int r0 = row_off[b], r1 = row_off[b + 1];
   __shared__ double red[256];
   __shared__ int s_last;
@@ -663,6 +664,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     if (wide) s_ll[r - r0] = ll;
     else acc += (double)ll;
   }
+  FN_STAMP(1);
   if (wide) {
     __syncthreads();
     if (threadIdx.x < 256)
@@ -674,6 +676,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
+  FN_STAMP(2);
   if (threadIdx.x == 0) {
     const int tvb = r1 - r0;
     double avg = tvb > 0 ? red[0] / (double)tvb : __longlong_as_double(0x7ff8000000000000ll);
@@ -689,13 +692,24 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     __builtin_amdgcn_s_waitcnt(0);
     s_last = (atomicAdd(counter, 1) == n_arrive - 1);
   }
+  FN_STAMP(3);
   __syncthreads();
   if (!s_last) return;
+  FN_STAMP(4);
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];
+  // (stamps, tools/profile/fin_instrumented.sh: the body takes ~6 us -- 1.5 until the raw scores are there, ~2.5 forming
+  //  the losses, 0.7 barrier, 0.7 one lane's mean, 0.7 decisions, 0.3 publication.  A rehearsal pass without stores ran
+  //  first to see whether cold instruction fetch is behind it: the second pass took 5.4 us, so it is not.)
   fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
                             true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq);
+  FN_STAMP(5);
 }
+#ifdef FB_FIN_STAMP
+extern "C" int fb_debug_fin_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(g_fin_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <bool SMALL>
 __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,

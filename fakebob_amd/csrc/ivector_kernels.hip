@@ -779,7 +779,11 @@ __device__ __forceinline__ int fb_wave_lower_bound(const int *__restrict__ a, in
 // (Round 5, measured and removed: the bucket's pairs staged in LDS for the searches and reads of a run -- 62 -> 80 us, the
 //  copy + barrier per item and the occupancy the 16 KB cost outweigh the dependent round trips the other waves hide --; the
 //  active list made by this kernel's last workgroup instead of k_iv_active's own launch -- 62.3 + 4.4 -> 73 us: 2 048
-//  arrivals on one counter cost more than the launch.)
+//  arrivals on one counter cost more than the launch; every item's bucket bounds fetched up front by lane j, the run bounds
+//  of a bucket of <= 64 pairs from ONE load of its pairs (popcount of entries below the key, the run's pairs shuffled out
+//  of those registers), the next item's pairs requested ahead -- 7 dependent round trips per item down to 2, and 62 -> 71 us
+//  (spd 200: 268 -> 321): at eight resident waves per SIMD the launch is bound by instructions issued per item, not by
+//  the chain, and the shuffles and the 78 registers (six waves) cost more than the round trips the other waves hide.)
 #define FB_IV_SG 8  // feature rows in flight per wave (two register buffers of this size).  Round 4: 16 -> 8 -- the kernel is a
                     // chain of dependent round trips per (bucket, utterance) run, hidden by OTHER waves: 50 registers and eight waves
                     // per SIMD (the whole grid resident) beat the deeper prefetch at 100 registers, 84 -> 61 us (spd 200: 354 -> 267);
