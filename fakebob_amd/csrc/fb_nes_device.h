@@ -435,18 +435,45 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
   __syncthreads();
   FN_STAMP(3);
   double dmax = 0.0;
+  const int smp = threadIdx.x & 255;   // the sample of the block this thread works on in phase 1
+  auto el = [&](int i) -> D1 {
+    const int j = i < half ? i : i - half;
+    double z = (double)s_z[j * 256 + smp];
+    if (i >= half) z = -z;
+    return D1{__dmul_rn(s_loss[i], z)};
+  };
+  // The fused launch's 512 threads: NumPy's block sum (fb_np_sum_block, 8 <= n <= 128) keeps eight running sums r0 .. r7
+  // over the strided terms and adds them as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)); thread t < 256 forms the
+  // left half for sample t, thread t + 256 the right half, handed over through s_a -- the same additions, half as many
+  // per thread, on the path everybody behind the publication is on.
+  const bool split = WAIT && SMALL && spd >= 8 && blockDim.x == 512;
+  D1 half_sum = D1::zero();
+  if (split) {
+    const int64_t ns = (int64_t)bidx * 256 + smp;
+    if (ns < N) {
+      const int o = threadIdx.x >= 256 ? 4 : 0;
+      D1 a0 = el(o), a1 = el(o + 1), a2 = el(o + 2), a3 = el(o + 3);
+      for (int i = 8; i < spd - (spd % 8); i += 8) {
+        a0 = a0 + el(i + o); a1 = a1 + el(i + o + 1); a2 = a2 + el(i + o + 2); a3 = a3 + el(i + o + 3);
+      }
+      half_sum = (a0 + a1) + (a2 + a3);
+    }
+    if (threadIdx.x >= 256) s_a[smp] = half_sum.v;
+    __syncthreads();
+  }
   if (threadIdx.x >= 256) {
     // phase 2 only
   } else if (n < N) {
-    auto el = [&](int i) -> D1 {
-      const int j = i < half ? i : i - half;
-      double z = (double)s_z[j * 256 + threadIdx.x];
-      if (i >= half) z = -z;
-      return D1{__dmul_rn(s_loss[i], z)};
-    };
     double g = __longlong_as_double(0x7ff8000000000000ll);
     if (spd > 0) {
-      const double gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+      double gs;
+      if (split) {
+        D1 res = half_sum + D1{s_a[threadIdx.x]};
+        for (int i = spd - (spd % 8); i < spd; ++i) res = res + el(i);
+        gs = res.v;
+      } else {
+        gs = SMALL ? fb_np_sum_block<D1>(el, 0, spd).v : fb_np_sum<D1>(el, 0, spd).v;
+      }
       g = __ddiv_rn(__ddiv_rn(gs, (double)spd), sigma);
     }
     double gm = __dadd_rn(__dmul_rn(momentum, WAIT ? pre_gm : grad_m[n]), __dmul_rn(one_minus_m, g));
