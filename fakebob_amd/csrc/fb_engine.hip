@@ -112,7 +112,7 @@ struct fb_engine {
   DevBuf zmean, zstd;
   std::vector<double> h_zmean, h_zstd;
   // batch scratch
-  DevBuf frame_rec, vad_counter, vad_pub, vad_part, fin_counter, ctl, ctl_ls, trace_dev, ticks, enr_ll, enr_aux, enr_stats;
+  DevBuf frame_rec, vad_counter, vad_pub, vad_part, fin_counter, fin_xch, ctl, ctl_ls, trace_dev, ticks, enr_ll, enr_aux, enr_stats;
   std::vector<double> iter_seconds;  // per-iteration device times of the last fb_attack / fb_attack_ext
   long long bench_it = -1;  // fb_bench_nes: next iteration index of the attack left resident (-1: none)
   int64_t bench_N = 0;
@@ -123,6 +123,7 @@ struct fb_engine {
   int vad_part_B = -1, vad_part_dim = -1;  // slot layout the sentinel-filled exchange buffer of k_vad_delta_cmvn_p was prepared for
   int ctl_seq = 0;         // loss bodies queued on the control block since its reset (FbCtlDev::pub_seq)
   unsigned vad_epoch = 0;  // launches of the fused VAD/CMVN kernels on vad_pub (its published counts carry the epoch)
+  bool fin_xch_clean = false;  // fin_xch holds sentinels everywhere (k_gmm_finalize_loss_update's exchange slots)
   unsigned vad_p_launches = 0;  // launches of k_vad_delta_cmvn_p on vad_part since its sentinel fill (its slot sets alternate with them)
   FbCtlDev *h_ctl = nullptr;  // pinned
   hipEvent_t evg_ring[2 * 16] = {};
@@ -240,7 +241,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->fe_tables, &e->fe_tables32, &e->gmm_items, &e->gmm_images_bx, &e->gmm_images_fx, &e->gmm_images_fd, &e->gmm_images_fd2, &e->gmm_images_fd3, &e->gmm_anchor, &e->zmean, &e->zstd, &e->wav, &e->wav_off,
-                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
+                    &e->frame_rec, &e->vad_counter, &e->vad_pub, &e->vad_part, &e->fin_counter, &e->fin_xch, &e->ctl, &e->ctl_ls, &e->trace_dev, &e->ticks, &e->enr_ll, &e->enr_aux, &e->enr_stats, &e->frame_off, &e->chunk_off, &e->chunk_sum, &e->mfcc, &e->mfcc_cm, &e->vrank, &e->tv, &e->row_off, &e->dfeat, &e->feats,
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
@@ -1897,6 +1898,18 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
       FBCHK(e->fin_counter.ensure(sizeof(int)));
       HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
     }
+    FbUpdArgs ux;
+    if (upd && getenv("FB_FIN_COUNTER") == nullptr) {  // (FB_FIN_COUNTER=1: the arrival counter instead of the exchange slots, A/B)
+      const size_t had = e->fin_xch.cap;
+      FBCHK(e->fin_xch.ensure(sizeof(unsigned long long) * (size_t)B * e->gmm.M));
+      if (e->fin_xch.cap != had || !e->fin_xch_clean) {
+        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->fin_xch.p), (int)FB_VAD_SENTINEL32, e->fin_xch.cap / 4, e->stream));
+        e->fin_xch_clean = true;
+      }
+      ux = *upd;
+      ux.xch = e->fin_xch.as<unsigned long long>();
+      upd = &ux;
+    }
     fb_launch_gmm_finalize_loss(e->stream, e->gmm, e->part_m.as<float>(), e->part_s.as<float>(), e->last_total_frames,
                                 e->last_chunks, e->row_off.as<int>(), B, e->raw.as<double>(), e->fin_counter.as<int>(),
                                 e->tv.as<int>(), p->task, p->attack_type, e->zmean.as<double>(), e->zstd.as<double>(),
@@ -1940,6 +1953,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     // mis-assign utterances / skip its loss body.  A new attack starts them clean.
     if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
     if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+    e->fin_xch_clean = false;  // (refilled with sentinels before its next use)
     if (e->iv_tail_counter.p) HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), e->stream));
     e->vad_part_B = -1;  // ... and k_vad_delta_cmvn_p's exchange slots are refilled with sentinels (run_post_mfcc)
     FbCtlDev h;

@@ -97,6 +97,7 @@ struct FbUpdArgs {
   int16_t *q;
   double *dist_part;
   double qscale;
+  unsigned long long *xch;  // nullable: B x M exchange slots of the finalising workgroups, every one FB_VAD_SENTINEL between launches
 };
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,

@@ -622,7 +622,8 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
                                                            double *__restrict__ scores, double *__restrict__ loss,
                                                            FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                                            double *__restrict__ trace, int it, const int b, const int m,
-                                                           const int n_arrive, const int pub_seq) {
+                                                           const int n_arrive, const int pub_seq,
+                                                           unsigned long long *__restrict__ xch = nullptr, const bool consumer = false) {
   if (ctl && ctl->stop) return;  // queued behind the stopping iteration
   FN_STAMP(0);
   const int r0 = row_off[b], r1 = row_off[b + 1];
@@ -633,6 +634,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
   // workgroup size)
   constexpr int FB_LL_LDS = 2048;
   __shared__ float s_ll[FB_LL_LDS];
+  __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];  // the loss body's (one workgroup of the launch runs it)
   const bool wide = r1 - r0 <= FB_LL_LDS;
   double acc = 0.0;
   for (int r = r0 + threadIdx.x; r < r1; r += (wide ? (int)blockDim.x : 256)) {
@@ -677,6 +679,43 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     __syncthreads();
   }
   FN_STAMP(2);
+  if (xch) {
+    // Round 5, the fused launch: no arrival counter.  Every workgroup leaves its score in its exchange slot (an
+    // agent-scope store, nothing to wait for) and is done; the LAST-INDEXED workgroup -- every other one was dispatched
+    // before it -- polls the B x M slots until none holds the sentinel, puts the sentinels back for the next launch and
+    // runs the loss body on the values.  (The counter cost a store round trip, then an atomic round trip, then the
+    // queue of 306 atomics on one word: the loss body started ~8.2 us into the launch with the last score formed at 5.3.)
+    if (threadIdx.x == 0) {
+      const int tvb = r1 - r0;
+      double avg = tvb > 0 ? red[0] / (double)tvb : __longlong_as_double(0x7ff8000000000000ll);
+      if (g.text_scores && tvb > 0) avg = fb_round6(avg);
+      raw[(size_t)b * g.M + m] = avg;
+      unsigned long long bits = (unsigned long long)__double_as_longlong(avg);
+      if (avg != avg) bits = 0x7ff8000000000000ull;   // (never the sentinel)
+      __hip_atomic_store(xch + (size_t)b * g.M + m, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    FN_STAMP(3);
+    if (!consumer) return;
+    double *s_raw = reinterpret_cast<double *>(s_ll);   // FB_LL_LDS floats = 1024 doubles: free now (B M <= 1024, the launcher's condition)
+    __syncthreads();                                     // (every thread is past its reads of s_ll)
+    // (touching the control block, tv and the distance partials here, ahead of the body's own loads: no gain, measured)
+    for (int i = threadIdx.x; i < B * g.M; i += blockDim.x) {
+      unsigned long long v;
+      for (;;) {
+        v = __hip_atomic_load(xch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != FB_VAD_SENTINEL) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_raw[i] = __longlong_as_double((long long)v);
+      __hip_atomic_store(xch + i, FB_VAD_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    FN_STAMP(4);
+    fb_loss_body<SMALL, false>(s_raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
+                               true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq);
+    FN_STAMP(5);
+    return;
+  }
   if (threadIdx.x == 0) {
     const int tvb = r1 - r0;
     double avg = tvb > 0 ? red[0] / (double)tvb : __longlong_as_double(0x7ff8000000000000ll);
@@ -697,7 +736,6 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
   if (!s_last) return;
   FN_STAMP(4);
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];
   // (stamps, tools/profile/fin_instrumented.sh: the body takes ~6 us -- 1.5 until the raw scores are there, ~2.5 forming
   //  the losses, 0.7 barrier, 0.7 one lane's mean, 0.7 decisions, 0.3 publication.  A rehearsal pass without stores ran
   //  first to see whether cold instruction fetch is behind it: the second pass took 5.4 us, so it is not.)
@@ -752,7 +790,7 @@ __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, co
   if (lin < n_fin) {
     fb_gmm_finalize_loss_body<SMALL>(g, part_m, part_s, rows_cap, n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean,
                                      z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
-                                     ctl, trace, it, lin % B, lin / B, n_fin, pub_seq);
+                                     ctl, trace, it, lin % B, lin / B, n_fin, pub_seq, n_fin <= 1024 ? u.xch : nullptr, lin == n_fin - 1);
   } else {
     fb_update_perturb_body<SMALL, true>(u.loss, u.N, u.half, u.sigma, u.zbuf, u.momentum, u.one_minus_m, u.epsilon, u.audio, u.grad_m,
                                         u.adver, ctl, u.seed, u.next_iter, u.stream, u.q, u.dist_part, u.qscale, lin - n_fin, pub_seq,
