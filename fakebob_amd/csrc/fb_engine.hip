@@ -1175,6 +1175,7 @@ static int time_end(fb_engine *e, int what = 1) {
 }
 
 static bool fb_fuse_on(const fb_engine *e);
+static bool fb_fuse_part(const fb_engine *e, int part);  // 0: VAD + deltas + CMVN, 1: finalisation + loss, 2: update + next batch
 // k_iv_solve_rw (five workgroups per matrix) is the LATENCY form of the posterior solve: it finishes a batch of 51 systems
 // sooner, on 255 compute units instead of 51 -- right for one attack per GPU, wrong when several attacks share the chip
 // and the idle units are what their kernels run on.  fb_set_fused_chain(e, 1) -- what the drivers choose for one or two
@@ -1196,7 +1197,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
   // make_mfcc.sh's `copy-feats --compress=true`: what VAD / deltas / CMVN read.  The one-launch kernel below takes the
   // round trip along on its LDS copy of the matrix when it can (utterances of up to 512 frames: every NES batch)
   const bool cm = e->cfg.compress_feats != 0;
-  const bool cm_fused = cm && fb_fuse_on(e) && fb_vad_delta_cmvn_compresses(e->t_max);
+  const bool cm_fused = cm && fb_fuse_part(e, 0) && fb_vad_delta_cmvn_compresses(e->t_max);
   // (out of place -- every workgroup of k_feat_compress reduces the header from the whole input matrix --, then the two
   //  buffers swap roles: e->mfcc is the matrix the later stages and fb_debug_mfcc read)
   auto compress = [&]() -> int {
@@ -1221,7 +1222,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
     }
     // without the CompressedMatrix phase an utterance is split over four workgroups (k_vad_delta_cmvn_p); FB_VAD_WHOLE=1
     // keeps the one-workgroup kernel (A/B; same results bit for bit)
-    if (fb_fuse_on(e) && !cm_fused && getenv("FB_VAD_WHOLE") == nullptr &&
+    if (fb_fuse_part(e, 0) && !cm_fused && getenv("FB_VAD_WHOLE") == nullptr &&
         fb_launch_vad_delta_cmvn_p(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                    e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
                                    e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>(), e->vad_p_launches)) {
@@ -1229,7 +1230,7 @@ static int run_post_mfcc(fb_engine *e, int B) {
       e->vad_p_launches += 1;
       return FB_OK;
     }
-    if (fb_fuse_on(e) && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
+    if (fb_fuse_part(e, 0) && fb_launch_vad_delta_cmvn(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                              e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
                                              e->row_off.as<int>(), e->feats.as<float>(), cm_fused ? e->mfcc.as<float>() : nullptr)) {
       e->vad_epoch += 1;
@@ -1848,6 +1849,20 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
 }
 
 // One get_grad on the device-resident adver: perturb -> score -> loss.  Async.
+// FB_FUSE_PARTS=<bit mask> chooses the fusions one by one whatever the chain setting says (experiments: bit 0 the
+// front-end's k_vad_delta_cmvn(_p), bit 1 k_gmm_finalize_loss, bit 2 the update kernels); read per call
+static bool fb_fuse_part(const fb_engine *e, int part) {
+  if (const char *ev = getenv("FB_FUSE_PARTS")) return ((atoi(ev) >> part) & 1) != 0;
+  // fb_set_fused_chain(e, 0) -- three or more attacks per GPU -- keeps ONE fusion: k_update_perturb (momentum step + the
+  // next batch) instead of k_grad_update + k_perturb.  Measured with three attacks in flight, every combination twice
+  // (tools/profile/r05_parts.sh): none 11.69 / 11.74 k it/s, this one 11.87 / 11.87, the front-end's 11.52 / 11.50, all
+  // three 11.31 / 11.26.  FB_NO_FUSE=1 still means every launch on its own.
+  if (part == 2 && e->fuse_opt == 0 && getenv("FB_NO_FUSE") == nullptr) return true;
+  // (i-vector systems, whose iteration the GMM kernels do not dominate, keep the front-end's fusion as well: 2 225 / 2 227
+  //  -> 2 241 / 2 244 it/s with three attacks in flight, tools/profile/r05_parts_iv.sh)
+  if (part == 0 && e->fuse_opt == 0 && e->kind == 1 && getenv("FB_NO_FUSE") == nullptr) return true;
+  return fb_fuse_on(e);
+}
 static bool fb_fuse_on(const fb_engine *e) {
   if (e->fuse_opt >= 0) return e->fuse_opt != 0;  // fb_set_fused_chain
   return getenv("FB_NO_FUSE") == nullptr;  // FB_NO_FUSE=1: the 8-launch chain (A/B, debugging; read per call)
@@ -1870,7 +1885,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   }
   e->pre_iter = -1;
   // GMM systems inside the device-controlled loop: finalisation and loss share one launch
-  const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_on(e);
+  const bool fuse_fin = ctl && e->kind == 0 && fb_fuse_part(e, 1);
   e->defer_finalize = fuse_fin;
   if (e->kind == 1) {  // i-vector systems: the loss body rides in the tail of the solve kernel when the batch allows it
     FbIvTail &t = e->tail_req;
@@ -1984,7 +1999,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
       // GMM systems on the fused chain: the update of this iteration and the batch of the next one ride in the launch
       // that finalises the scores and runs the loss body (k_gmm_finalize_loss_update; FB_FUSE_UPD=0: two launches)
-      const bool upd_ok = !noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e);
+      const bool upd_ok = !noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_part(e, 1) && fb_fuse_part(e, 2);
       const char *fu_env = getenv("FB_FUSE_UPD");   // (read per iteration: A/B inside one process)
       const bool no_fuse_upd = fu_env && fu_env[0] == '0';
       FbUpdArgs ua = {};
@@ -2001,7 +2016,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       if (upd_done) {
         e->pre_ndp = (int)((N + 255) / 256);
         e->pre_iter = (long long)it + 1;
-      } else if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_on(e)) {
+      } else if (!noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_part(e, 2)) {
         // momentum sign step of this iteration + the perturbed batch of the next one in a single launch
         e->pre_ndp = fb_launch_update_perturb(e->stream, e->loss.as<double>(), N, half, p->sigma, e->zbuf.as<float>(),
                                               p->momentum, one_minus_m, p->epsilon, e->audio.as<double>(),
