@@ -531,7 +531,7 @@ def main():
                          "allocations, clock ramp of a cold GPU); reported in config.precondition_steps")
     ap.add_argument("--chain", default="auto", choices=["auto", "fused", "unfused"],
                     help="launch chain of the attack loop (fb_set_fused_chain): auto = 4 launches per iteration with fewer "
-                         "than 3 attacks in flight, 7 launches otherwise (everything separate but the update: they interleave better)")
+                         "than 3 attacks in flight, 6 launches otherwise (finalisation and loss on their own: they interleave better)")
     ap.add_argument("--task", default=None, choices=["SV", "OSI", "CSI"],
                     help="--arch iv: the system (configs[2]: SV, the default; configs[4]: OSI).  --arch gmm: OSI (headline, "
                          "default) or CSI = configs[3]'s per-GPU work (GMM CSI untargeted, speaker models only)")
@@ -657,7 +657,7 @@ def main():
                        "repeats": len(dts), "windows_ms": [1e3 * x for x in dts],
                        "timing": "value / ms_per_step: the MEDIAN of `repeats` consecutive windows of exactly `steps` steps, each "
                                  "between (barrier + device synchronize) pairs and max over ranks; windows_ms lists them all",
-                       "launch_chain": "4 launches per iteration (fused)" if fused else "7 launches per iteration (separate; the update and the next batch in one)",
+                       "launch_chain": "4 launches per iteration (fused)" if fused else "6 launches per iteration (mfcc; vad + deltas + cmvn; gmm; finalize; loss; update + next batch)",
                        "voiced_rows_per_iter": rows, "utterances_per_iter": SPD + 1,
                        "gmm_kernel": variant,
                        "gmm_delta_p": {"tiles_p1": tiles[0], "tiles_p2": tiles[1], "tiles_p3": tiles[2],

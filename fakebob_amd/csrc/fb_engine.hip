@@ -1225,7 +1225,8 @@ static int run_post_mfcc(fb_engine *e, int B) {
     if (fb_fuse_part(e, 0) && !cm_fused && getenv("FB_VAD_WHOLE") == nullptr &&
         fb_launch_vad_delta_cmvn_p(s, fe, e->mfcc.as<float>(), e->frame_off.as<int>(), B, e->t_max, e->vad_epoch + 1,
                                    e->vad_counter.as<int>(), e->vad_pub.as<unsigned long long>(), e->tv.as<int>(),
-                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>(), e->vad_p_launches)) {
+                                   e->row_off.as<int>(), e->feats.as<float>(), e->vad_part.as<double>(), e->vad_p_launches,
+                                   e->fuse_opt != 0)) {
       e->vad_epoch += 1;
       e->vad_p_launches += 1;
       return FB_OK;
@@ -1853,14 +1854,14 @@ static int ensure_nes_buffers(fb_engine *e, int64_t N, int B, int S = -1) {
 // front-end's k_vad_delta_cmvn(_p), bit 1 k_gmm_finalize_loss, bit 2 the update kernels); read per call
 static bool fb_fuse_part(const fb_engine *e, int part) {
   if (const char *ev = getenv("FB_FUSE_PARTS")) return ((atoi(ev) >> part) & 1) != 0;
-  // fb_set_fused_chain(e, 0) -- three or more attacks per GPU -- keeps ONE fusion: k_update_perturb (momentum step + the
-  // next batch) instead of k_grad_update + k_perturb.  Measured with three attacks in flight, every combination twice
+  // fb_set_fused_chain(e, 0) -- three or more attacks per GPU -- keeps TWO fusions: k_update_perturb (momentum step + the
+  // next batch) instead of k_grad_update + k_perturb  Measured with three attacks in flight, every combination twice
   // (tools/profile/r05_parts.sh): none 11.69 / 11.74 k it/s, this one 11.87 / 11.87, the front-end's 11.52 / 11.50, all
   // three 11.31 / 11.26.  FB_NO_FUSE=1 still means every launch on its own.
-  if (part == 2 && e->fuse_opt == 0 && getenv("FB_NO_FUSE") == nullptr) return true;
-  // (i-vector systems, whose iteration the GMM kernels do not dominate, keep the front-end's fusion as well: 2 225 / 2 227
-  //  -> 2 241 / 2 244 it/s with three attacks in flight, tools/profile/r05_parts_iv.sh)
-  if (part == 0 && e->fuse_opt == 0 && e->kind == 1 && getenv("FB_NO_FUSE") == nullptr) return true;
+  // ... and the front-end's (k_vad_delta_cmvn_p at its own 35 KB of LDS, not padded to a workgroup per CU -- so that it
+  // runs BESIDE the other attacks' k_gmm_fx2w workgroups): 11.66 -> 12.08 k it/s; with the finalisation fused as well
+  // 11.34 (tools/profile/r05_stack.sh; four attacks in flight: 10.7 k, two: 10.5 k).
+  if ((part == 2 || part == 0) && e->fuse_opt == 0 && getenv("FB_NO_FUSE") == nullptr) return true;
   return fb_fuse_on(e);
 }
 static bool fb_fuse_on(const fb_engine *e) {

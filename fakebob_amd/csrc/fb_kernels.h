@@ -153,7 +153,8 @@ bool fb_launch_vad_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const floa
 size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B);
 bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                                 int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                                float *feats, double *part_sum, unsigned slot_set);
+                                float *feats, double *part_sum, unsigned slot_set,
+                                bool spread = true /* pad the LDS request to one workgroup per CU (an attack alone on the GPU) */);
 bool fb_launch_delta_cmvn(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off,
                           const int *vrank, const int *row_off, int B, int t_max, float *feats);
 // add-deltas (one workgroup per 32-frame chunk; chunk_off[B+1] = prefix of ceil(T_b/32)) + per-chunk

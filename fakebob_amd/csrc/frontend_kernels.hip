@@ -1631,7 +1631,7 @@ size_t fb_vad_delta_cmvn_p_lds_bytes(const FbFrontendDev &fe, int t_cap) {
 size_t fb_vad_parts_doubles(const FbFrontendDev &fe, int B) { return (size_t)2 * B * FB_CMVN_PARTS * fe.dim; }
 bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const float *mfcc, const int *frame_off, int B,
                                 int t_max, unsigned epoch, int *ticket, unsigned long long *pub, int *tv, int *row_off,
-                                float *feats, double *part_sum, unsigned slot_set) {
+                                float *feats, double *part_sum, unsigned slot_set, bool spread) {
   if (B <= 0) return true;
   if (t_max > fe.cmn_window || fe.dim > 256) return false;
   size_t shm = fb_vad_delta_cmvn_p_lds_bytes(fe, t_max);
@@ -1640,7 +1640,10 @@ bool fb_launch_vad_delta_cmvn_p(hipStream_t s, const FbFrontendDev &fe, const fl
   // utterance on ONE unit (35 KB of LDS and 256 threads each fit four times) and the split buys nothing -- measured:
   // 39.6 us stacked against 24.7 us for the one-workgroup kernel.  Asking for more than half of a unit's LDS keeps
   // them apart.
-  if (B * FB_CMVN_PARTS <= 256) {
+  // ... when the attack has the GPU to itself (spread).  With three or more attacks in flight the padding is what hurts:
+  // 82 KB keep the workgroup off every CU a k_gmm_fx2w workgroup of another attack (101 KB) sits on; at its own 35 KB it
+  // runs beside them: 11.66 -> 12.08 k it/s (tools/profile/r05_stack.sh; padded, the fused front-end LOSES 1 % there).
+  if (spread && B * FB_CMVN_PARTS <= 256 && getenv("FB_VADP_STACK") == nullptr) {  // (FB_VADP_STACK=1: never pad -- experiments)
     static std::atomic<unsigned long long> optin{0};
     unsigned long long bit = 0;
     bool ok = true;

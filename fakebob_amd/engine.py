@@ -380,7 +380,7 @@ class Engine(object):
         return ms.value, rows.value
 
     def set_fused_chain(self, on):
-        """True: 4 launches per NES iteration (best for one or two attacks per GPU); False: 7 launches, all separate but the update + next batch (better
+        """True: 4 launches per NES iteration (best for one or two attacks per GPU); False: 6 launches, finalisation and loss on their own (better
         with >= 3 engines sharing a GPU); None: library default.  Same trajectories (fb_set_fused_chain)."""
         N.check(self._L.fb_set_fused_chain(self._h, C.c_int(-1 if on is None else (1 if on else 0))))
 

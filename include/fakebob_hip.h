@@ -237,8 +237,9 @@ int fb_attack_ext(fb_engine *e, const fb_nes_params *p, int S, fb_score_cb cb, v
 /* Launch chain of the device-controlled attack loop.  on = 1: 4 launches per NES iteration of a GMM system (MFCC; VAD +
  * deltas + CMVN; GMM log-likelihoods; finalisation + loss + loop control + update of iteration i + perturbation of
  * i + 1 in one) and, for i-vector systems, the five-workgroups-per-matrix posterior solve -- fastest for ONE or TWO
- * attacks per GPU, the reference's own use; on = 0: 7 launches -- every stage on its own except the update + next perturbation --, which interleave better when
- * several engines share a GPU (3 or more attacks in flight: +5 % NES iterations/s, profiles/r05_*; FB_NO_FUSE=1: all 8); -1: default (fused unless
+ * attacks per GPU, the reference's own use; on = 0: 6 launches -- finalisation and loss on their own, the front-end kernel at its own LDS size --, which interleave
+ * better when several engines share a GPU (3 or more attacks in flight: +7 % NES iterations/s, profiles/r05_*;
+ * FB_NO_FUSE=1: all 8); -1: default (fused unless
  * FB_NO_FUSE is set).  Trajectories are bit-identical either way. */
 int fb_set_fused_chain(fb_engine *e, int on);
 
