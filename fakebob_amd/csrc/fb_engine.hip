@@ -1861,7 +1861,9 @@ static bool fb_fuse_part(const fb_engine *e, int part) {
   // ... and the front-end's (k_vad_delta_cmvn_p at its own 35 KB of LDS, not padded to a workgroup per CU -- so that it
   // runs BESIDE the other attacks' k_gmm_fx2w workgroups): 11.66 -> 12.08 k it/s; with the finalisation fused as well
   // 11.34 (tools/profile/r05_stack.sh; four attacks in flight: 10.7 k, two: 10.5 k).
-  if ((part == 2 || part == 0) && e->fuse_opt == 0 && getenv("FB_NO_FUSE") == nullptr) return true;
+  // (Not with the CompressedMatrix round trip on: its phase lives in the one-workgroup-per-utterance kernel, which a
+  //  shared GPU does not take well -- the reference-pipeline secondary fell from 10.6 to 8.7 k it/s with it.)
+  if ((part == 2 || (part == 0 && !e->cfg.compress_feats)) && e->fuse_opt == 0 && getenv("FB_NO_FUSE") == nullptr) return true;
   return fb_fuse_on(e);
 }
 static bool fb_fuse_on(const fb_engine *e) {
