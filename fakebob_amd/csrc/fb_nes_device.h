@@ -99,7 +99,8 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
                                               double *__restrict__ scores, double *__restrict__ loss,
                                               FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                               double *__restrict__ trace, int it, double *__restrict__ s_lv,
-                                              double *__restrict__ s_sc, const int pub_seq = 0) {
+                                              double *__restrict__ s_sc, const int pub_seq = 0,
+                                              const int lv_cap = FB_LOSS_LDS, const int sc_cap = FB_SC_LDS) {
   // pub_seq != 0: workgroups of the SAME launch wait for this body's results (k_gmm_finalize_loss_update's update part):
   // the losses, the step size and the stop flag go out as agent-scope (write-through) stores, and when they are complete
   // ctl->pub_seq = pub_seq tells the pollers -- no device-wide fence
@@ -114,7 +115,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
   // scores while the loss is formed from them (B S <= FB_SC_LDS; otherwise in `scores`) -- LDS of the caller (static
   // arrays in the small kernels, a piece of the dynamic allocation in the solve kernels' tail)
   constexpr int FB_LS_LOCAL = 8;
-  const bool sc_lds = (size_t)B * S <= FB_SC_LDS;
+  const bool sc_lds = (size_t)B * S <= (size_t)sc_cap;
   const double dist_first = (int)threadIdx.x < n_dist_part ? dist_part[threadIdx.x] : 0.0;  // in flight with the rest
   FbCtlDev c = {};
   double lsv[FB_LS_LOCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -225,7 +226,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(loss + b), (unsigned long long)__double_as_longlong(l),
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else loss[b] = l;
-    if (b < FB_LOSS_LDS) s_lv[b] = l;
+    if (b < lv_cap) s_lv[b] = l;
   }
   // (the window of recent losses hangs off a pointer IN the control block: requested here, behind the raw scores, it
   //  arrives during the barrier and the mean below; requested at the top it put a second round trip in front of them)
@@ -259,7 +260,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
   bool stop_now = false, broke = false, window = false;
   if (threadIdx.x == 0) {
     const int spd = B - 1;
-    const bool lds_l = B <= FB_LOSS_LDS;
+    const bool lds_l = B <= lv_cap;
     for (int i = 0; i < (int)((blockDim.x + 63) >> 6) && i < 16; ++i) s_err = s_errw[i] > s_err ? s_errw[i] : s_err;
     al = lds_l ? s_lv[0] : loss[0];
     double lsum;

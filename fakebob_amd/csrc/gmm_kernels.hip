@@ -632,9 +632,12 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
   // the workgroup's threads work out the frame log-likelihoods (four float64 exp and a log each), threads 0 .. 255
   // then add them up in a fixed order: thread t takes frames t, t + 256, ... (the average does not depend on the
   // workgroup size)
-  constexpr int FB_LL_LDS = 2048;
+  // (SMALL -- samples_per_draw <= 128, every NES batch of the recipe --: the buffers at what such a batch needs, 13 KB
+  //  instead of 42: the workgroups are meant to fit beside other attacks' kernels)
+  constexpr int FB_LL_LDS = SMALL ? 1024 : 2048;
+  constexpr int LV_CAP = SMALL ? 136 : FB_LOSS_LDS, SC_CAP = SMALL ? 768 : FB_SC_LDS;
   __shared__ float s_ll[FB_LL_LDS];
-  __shared__ double s_lv[FB_LOSS_LDS], s_sc[FB_SC_LDS];  // the loss body's (one workgroup of the launch runs it)
+  __shared__ double s_lv[LV_CAP], s_sc[SC_CAP];  // the loss body's (one workgroup of the launch runs it)
   const bool wide = r1 - r0 <= FB_LL_LDS;
   double acc = 0.0;
   for (int r = r0 + threadIdx.x; r < r1; r += (wide ? (int)blockDim.x : 256)) {
@@ -696,7 +699,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     }
     FN_STAMP(3);
     if (!consumer) return;
-    double *s_raw = reinterpret_cast<double *>(s_ll);   // FB_LL_LDS floats = 1024 doubles: free now (B M <= 1024, the launcher's condition)
+    double *s_raw = reinterpret_cast<double *>(s_ll);   // FB_LL_LDS floats: free now (B M <= FB_LL_LDS / 2, checked by the caller)
     __syncthreads();                                     // (every thread is past its reads of s_ll)
     // (touching the control block, tv and the distance partials here, ahead of the body's own loads: no gain, measured)
     for (int i = threadIdx.x; i < B * g.M; i += blockDim.x) {
@@ -712,7 +715,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     __syncthreads();
     FN_STAMP(4);
     fb_loss_body<SMALL, false>(s_raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
-                               true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq);
+                               true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq, LV_CAP, SC_CAP);
     FN_STAMP(5);
     return;
   }
@@ -740,7 +743,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
   //  the losses, 0.7 barrier, 0.7 one lane's mean, 0.7 decisions, 0.3 publication.  A rehearsal pass without stores ran
   //  first to see whether cold instruction fetch is behind it: the second pass took 5.4 us, so it is not.)
   fb_loss_body<SMALL, true>(raw, tv, B, g.M, task, 0, attack_type, z_mean, z_std, threshold, adver_thresh, target,
-                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq);
+                            true_label, dist_part, n_dist_part, scores, loss, out, ctl, trace, it, s_lv, s_sc, pub_seq, LV_CAP, SC_CAP);
   FN_STAMP(5);
 }
 #ifdef FB_FIN_STAMP
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, co
   if (lin < n_fin) {
     fb_gmm_finalize_loss_body<SMALL>(g, part_m, part_s, rows_cap, n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean,
                                      z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,
-                                     ctl, trace, it, lin % B, lin / B, n_fin, pub_seq, n_fin <= 1024 ? u.xch : nullptr, lin == n_fin - 1);
+                                     ctl, trace, it, lin % B, lin / B, n_fin, pub_seq, n_fin <= (SMALL ? 512 : 1024) ? u.xch : nullptr, lin == n_fin - 1);
   } else {
     fb_update_perturb_body<SMALL, true>(u.loss, u.N, u.half, u.sigma, u.zbuf, u.momentum, u.one_minus_m, u.epsilon, u.audio, u.grad_m,
                                         u.adver, ctl, u.seed, u.next_iter, u.stream, u.q, u.dist_part, u.qscale, lin - n_fin, pub_seq,
