@@ -215,12 +215,18 @@ def test_update_in_the_finalising_launch_equals_the_separate_launch(monkeypatch,
         ref = run()
         monkeypatch.delenv("FB_FUSE_UPD", raising=False)
         got = run()
+        # ... and with the arrival counter + last arriver instead of the exchange slots + last-indexed workgroup
+        monkeypatch.setenv("FB_FIN_COUNTER", "1")
+        got_counter = run()
+        monkeypatch.delenv("FB_FIN_COUNTER", raising=False)
+        got_again = run()     # (the slots were left clean by the launches before the counter ones)
     finally:
         e.close()
-    for a, b in zip(ref[:3], got[:3]):
-        assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for other in (got, got_counter, got_again):
+        for a, b in zip(ref[:3], other[:3]):
+            assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert ref[3][0] == other[3][0] and np.array_equal(ref[3][1], other[3][1])
     assert ref[0][3].shape[0] == 7 and 1 <= ref[1][3].shape[0] < 40 and ref[1][1] == 1
-    assert ref[3][0] == got[3][0] and np.array_equal(ref[3][1], got[3][1])
 
 
 def test_attack_on_a_site_with_more_than_ten_models_equals_the_oracle(oracle, monkeypatch):
