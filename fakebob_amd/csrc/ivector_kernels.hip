@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_iv_bucket_count(FbIvDev iv, const int *
 // (a) per component: exclusive scan over the partition blocks.  Workgroup = 64 components x 16 block segments: every
 //     thread first sums its segment (all loads independent), the 16 segment sums are scanned through LDS, then the
 //     segment is walked again to write the prefixes -- instead of one thread walking all n_blk blocks of a component.
+template <int PMAX>  // blocks per segment held in registers (0: walk the segment twice)
 __global__ __launch_bounds__(1024) void k_iv_bucket_scan_blocks(int C, int Cpad, int n_blk, const int *__restrict__ cnt,
                                                                 int *__restrict__ pref, int *__restrict__ hist) {
   __shared__ int ssum[16][64];
@@ -228,17 +229,52 @@ __global__ __launch_bounds__(1024) void k_iv_bucket_scan_blocks(int C, int Cpad,
   const int per = (n_blk + 15) / 16;
   const int j0 = seg * per, j1 = min(n_blk, j0 + per);
   const bool kok = k < C;
+  // (a segment of at most PMAX blocks -- configs[2]'s 240 blocks are 15 per segment, configs[4]'s 942 are 59 -- is loaded ONCE, every load in flight
+  //  together, and kept in registers for the second walk: the two run-time loops were eight dependent round trips)
+  int v[PMAX > 0 ? PMAX : 1];
   int tot = 0;
-  if (kok)
-    for (int j = j0; j < j1; ++j) tot += cnt[(size_t)j * Cpad + k];
+  if (PMAX > 0) {
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u) {
+      const int j = min(j0 + u, n_blk - 1);
+      const int x = kok ? cnt[(size_t)j * Cpad + k] : 0;
+      v[u] = j0 + u < j1 ? x : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u) tot += v[u];
+  } else if (kok) {  // (longer segments: sixteen loads in flight per trip, twice)
+    for (int jc = j0; jc < j1; jc += 16) {
+      int x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = cnt[(size_t)min(jc + u, n_blk - 1) * Cpad + k];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tot += jc + u < j1 ? x[u] : 0;
+    }
+  }
   ssum[seg][kk] = tot;
   __syncthreads();
   int run = 0;
   for (int q = 0; q < seg; ++q) run += ssum[q][kk];
   if (kok) {
-    for (int j = j0; j < j1; ++j) {
-      pref[(size_t)j * Cpad + k] = run;
-      run += cnt[(size_t)j * Cpad + k];
+    if (PMAX > 0) {
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u)
+        if (j0 + u < j1) {
+          pref[(size_t)(j0 + u) * Cpad + k] = run;
+          run += v[u];
+        }
+    } else {
+      for (int jc = j0; jc < j1; jc += 16) {
+        int x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = cnt[(size_t)min(jc + u, n_blk - 1) * Cpad + k];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (jc + u < j1) {
+            pref[(size_t)(jc + u) * Cpad + k] = run;
+            run += x[u];
+          }
+      }
     }
     if (seg == 15) hist[k] = run;  // (empty trailing segments included: run = the component's total)
   }
@@ -726,7 +762,12 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
   hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
-  hipLaunchKernelGGL(k_iv_bucket_scan_blocks, dim3((C + 63) / 64), dim3(1024), 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
+  {
+    const int per = (n_blk + 15) / 16;
+    const dim3 grid((C + 63) / 64), blk(1024);
+    if (per <= 16) hipLaunchKernelGGL(k_iv_bucket_scan_blocks<16>, grid, blk, 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
+    else hipLaunchKernelGGL(k_iv_bucket_scan_blocks<0>, grid, blk, 0, s, C, iv.Cpad, n_blk, cnt, pref, hist);
+  }
   hipLaunchKernelGGL(k_iv_bucket_scan, dim3(1), dim3(1024), 0, s, C, hist, bstart, wstart, nz);
   if (4 * lds_c <= 64 * 1024 && getenv("FB_IV_FILL1") == nullptr)
     hipLaunchKernelGGL(k_iv_bucket_fill4, dim3(n_blk), dim3(256), 4 * lds_c, s, iv, n_rows_ptr, sel, pref, bstart, pairs);
