@@ -400,9 +400,23 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
     for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = loss[1 + i];
   }
   const int64_t n = (int64_t)bidx * 256 + threadIdx.x;  // phase 1: threads 0 .. 255
-  for (int e = threadIdx.x; e < half * 256; e += blockDim.x) {
-    const int64_t ns = (int64_t)bidx * 256 + (e & 255);
-    s_z[e] = zbuf[(int64_t)(e >> 8) * N + (ns < N ? ns : N - 1)];
+  {  // this iteration's normals of the block's 256 samples: sixteen loads in flight per trip (a plain copy loop waits for
+     // every load before it issues the next: 12 dependent round trips at samples_per_draw = 50 -- half of k_update_perturb)
+    const int total = half * 256;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 16 * (int)blockDim.x) {
+      float zv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = min(e0 + u * (int)blockDim.x, total - 1);
+        const int64_t ns = (int64_t)bidx * 256 + (e & 255);
+        zv[u] = zbuf[(int64_t)(e >> 8) * N + (ns < N ? ns : N - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = e0 + u * (int)blockDim.x;
+        if (e < total) s_z[e] = zv[u];
+      }
+    }
   }
   const int64_t n4_0 = (int64_t)bidx * 64;  // first sample quad of the block
   // (WAIT: the sample's state is requested before the wait as well -- one memory round trip less behind the release)

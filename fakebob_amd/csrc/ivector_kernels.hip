@@ -368,10 +368,23 @@ __global__ __launch_bounds__(256) void k_iv_bucket_fill4(FbIvDev iv, const int *
   for (int u = 0; u < 16; ++u)
     if (kv[u] >= 0 && kv[u] < C) atomicAdd(&s_h[w * Cpad + kv[u]], 1);
   __syncthreads();
-  for (int k = tid; k < C; k += 256) {
-    const int p0 = bstart[k] + pref[(size_t)blk * Cpad + k];
-    const int c0 = s_h[k], c1 = s_h[Cpad + k], c2 = s_h[2 * Cpad + k];
-    s_h[k] = p0; s_h[Cpad + k] = p0 + c0; s_h[2 * Cpad + k] = p0 + c0 + c1; s_h[3 * Cpad + k] = p0 + c0 + c1 + c2;
+  for (int k0 = tid; k0 < C; k0 += 8 * 256) {  // (eight components' two loads in flight per trip, not one per trip)
+    int pb[8], pp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kc = min(k0 + 256 * u, C - 1);
+      pb[u] = bstart[kc];
+      pp[u] = pref[(size_t)blk * Cpad + kc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 256 * u;
+      if (k < C) {
+        const int p0 = pb[u] + pp[u];
+        const int c0 = s_h[k], c1 = s_h[Cpad + k], c2 = s_h[2 * Cpad + k];
+        s_h[k] = p0; s_h[Cpad + k] = p0 + c0; s_h[2 * Cpad + k] = p0 + c0 + c1; s_h[3 * Cpad + k] = p0 + c0 + c1 + c2;
+      }
+    }
   }
   __syncthreads();
   int *pos = s_h + w * Cpad;

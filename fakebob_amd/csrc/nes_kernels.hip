@@ -226,7 +226,9 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 // then grad = m*pre + (1-m)*grad (:193), adver -= lr*sign(grad), clip (:202-203).
 // The normals come back from the buffer k_perturb wrote (zbuf, float32 [half][N]) or from the
 // caller's float64 tensor (noise_pos [N][half]); products are summed in numpy's pairwise order.
-#define FB_GRAD_LDS_PAIRS 40  // normals of a 256-sample block staged in LDS up to samples_per_draw = 80
+#define FB_GRAD_LDS_PAIRS 150  // normals of a 256-sample block staged in LDS up to samples_per_draw = 300 (past 64 KB of LDS
+                               // from 62 pairs on: opt-in).  Unstaged, every term of the gradient sum is a dependent global load:
+                               // samples_per_draw = 200 took 65 us
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ loss, int64_t N, int half,
                                                      double sigma, const float *__restrict__ zbuf,
@@ -248,7 +250,14 @@ __global__ __launch_bounds__(256) void k_grad_update(const double *__restrict__ 
   const bool lds_z = !noise_pos && half <= FB_GRAD_LDS_PAIRS;
   if (lds_z) {  // every load of the thread is in flight before the first use
     const int64_t nc = n < N ? n : N - 1;
-    for (int j = 0; j < half; ++j) s_z[j * 256 + threadIdx.x] = zbuf[(int64_t)j * N + nc];
+    for (int j0 = 0; j0 < half; j0 += 16) {  // sixteen loads in flight per trip (one per trip: `half` dependent round trips)
+      float zv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) zv[u] = zbuf[(int64_t)min(j0 + u, half - 1) * N + nc];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (j0 + u < half) s_z[(j0 + u) * 256 + threadIdx.x] = zv[u];
+    }
   }
   __syncthreads();
   if (n >= N) return;
@@ -332,6 +341,15 @@ void fb_launch_grad_update(hipStream_t s, const double *loss, int64_t N, int hal
   int blocks = (int)((N + 255) / 256);
   size_t shm = sizeof(double) * (size_t)(2 * half > 0 ? 2 * half : 1);
   if (!noise_pos && half <= FB_GRAD_LDS_PAIRS) shm += sizeof(float) * 256 * (size_t)half;
+  if (shm > 64 * 1024) {
+    static std::atomic<unsigned long long> optin{0};
+    unsigned long long bit = 0;
+    if (fb_device_needs_optin(optin, &bit)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grad_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grad_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      optin.fetch_or(bit, std::memory_order_release);
+    }
+  }
   if (2 * half <= 128)
     hipLaunchKernelGGL(k_grad_update<true>, dim3(blocks), dim3(256), shm, s, loss, N, half, sigma, zbuf, noise_pos,
                        grad_out, do_update, momentum, one_minus_m, lr, epsilon, audio, grad_m, adver, ctl);
