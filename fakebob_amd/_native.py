@@ -64,7 +64,7 @@ EXPORTS = [
     "fb_last_error", "fb_version", "fb_device_count", "fb_engine_create", "fb_engine_destroy",
     "fb_default_frontend", "fb_set_frontend", "fb_load_gmm", "fb_load_ivector", "fb_set_system", "fb_num_speakers",
     "fb_score_i16", "fb_score_f64", "fb_system_scores", "fb_get_grad", "fb_attack", "fb_attack_iter_seconds", "fb_get_grad_ext", "fb_attack_ext",
-    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_gmm_frames", "fb_debug_iv_active", "fb_stats", "fb_gmm_acc_stats", "fb_last_ivectors", "fb_gmm_kernel_mode", "fb_gmm_kernel_variant", "fb_gmm_delta_tiles", "fb_gmm_delta_tiles_f6", "fb_set_fused_chain",
+    "fb_estimate_threshold", "fb_debug_noise", "fb_debug_quantize", "fb_debug_mfcc", "fb_debug_feats", "fb_debug_gmm_frames", "fb_debug_iv_active", "fb_debug_iv_gselect", "fb_stats", "fb_gmm_acc_stats", "fb_last_ivectors", "fb_gmm_kernel_mode", "fb_gmm_kernel_variant", "fb_gmm_delta_tiles", "fb_gmm_delta_tiles_f6", "fb_set_fused_chain",
     "fb_bench_gmm_kernel", "fb_bench_nes",
 ]
 

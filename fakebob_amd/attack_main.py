@@ -219,11 +219,15 @@ def main(argv=None, model_factory=None, bob_factory=None):
     ths = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
     [t.start() for t in ths]
     [t.join() for t in ths]
-    if errors:
-        raise errors[0]
+    if parallel.agree_on_failure(bool(errors), dist):   # every rank learns of it BEFORE the result reduction
+        if errors:
+            raise errors[0]
+        raise RuntimeError("an attack stream of another rank failed: the job's results are incomplete")
     st = [m.engine.stats() if hasattr(m, "engine") else dict(nes_iters=0, scored_utts=0) for m in models]
     succ = sum(1 for f in results.values() if f == 1)
     g = parallel.reduce_counters([succ, len(results), sum(s["nes_iters"] for s in st), sum(s["scored_utts"] for s in st)], dist)
+    if g[1] != total:
+        raise RuntimeError("the work queue handed out %d of %d attacks" % (g[1], total))
     if rank == 0:
         if g[1] > 0:
             print('------ attack successful rate %d ------' % (g[0] * 100 / g[1]))

@@ -102,6 +102,7 @@ struct fb_engine {
   int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
   DevBuf iv_prog, iv_ticket;  // k_iv_solve_rw: progress words, ticket
   DevBuf iv_tail_counter;     // arrivals of the solve kernels' fused tail (fb_iv_tail.h)
+  DevBuf gs_max, gs_tau, gs_list, gs_cnt, gs_flag;  // fb_launch_gsel's workspace (group maxima, thresholds, survivor lists, overflow flag)
   bool tail_loss_req = false, tail_loss_done = false;  // enqueue_get_grad asks run_scoring to take the loss body along / it did
   FbIvTail tail_req = {};
   unsigned iv_rw_epoch = 0;
@@ -245,7 +246,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->gs_max, &e->gs_tau, &e->gs_list, &e->gs_cnt, &e->gs_flag, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -996,6 +997,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.M = M; g.C = C; g.D = D; g.n_tiles = n_tiles; g.n_items = n_items;
   g.mode = mode; g.NK = NK;
   g.text_scores = e->cfg.text_scores;
+  g.only_if = nullptr;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
   g.NKF = NKF;
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
@@ -1342,12 +1344,35 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     FBCHK(e->iv_fail.ensure(sizeof(int)));
     FBCHK(e->iv_active.ensure(sizeof(int) * (size_t)(iv.C + 1)));
     FB_DBG_SYNC(e, "front-end");
-    fb_launch_gmm_dump(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
+    // gmm-gselect: threshold selection in the matrix-core kernel (round 6) with the dump + k_iv_select launches behind
+    // it as its rescue -- they return at once unless a survivor list overflowed --, or the dump alone where the
+    // threshold path does not apply (small models, the bf16 mode, FB_IV_GSEL_DUMP=1)
+    const int *sel_gate = nullptr;
+    FbGmmDev gd = g;
+    const int sel_chunks = fb_gsel_chunks(n_chunks);
+    if (fb_gsel_applies(g, iv.nsel, sel_chunks)) {
+      const int cap = fb_gsel_cap(sel_chunks);
+      FBCHK(e->gs_max.ensure(sizeof(float) * (size_t)total_frames * 2 * g.n_tiles));
+      FBCHK(e->gs_tau.ensure(sizeof(float) * (size_t)total_frames));
+      FBCHK(e->gs_list.ensure(sizeof(unsigned long long) * (size_t)total_frames * sel_chunks * cap));
+      FBCHK(e->gs_cnt.ensure(sizeof(int) * (size_t)total_frames * sel_chunks));
+      if (!e->gs_flag.p) {
+        FBCHK(e->gs_flag.ensure(sizeof(int)));
+        HIPCHK(hipMemsetAsync(e->gs_flag.p, 0, sizeof(int), s));
+      }
+      fb_launch_gsel(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, sel_chunks, iv.nsel, e->gs_max.as<float>(),
+                     e->gs_tau.as<float>(), e->gs_list.as<unsigned long long>(), e->gs_cnt.as<int>(), e->gs_flag.as<int>(),
+                     e->iv_sel.as<int>());
+      FB_DBG_SYNC(e, "gsel");
+      sel_gate = e->gs_flag.as<int>();
+      gd.only_if = sel_gate;
+    }
+    fb_launch_gmm_dump(s, gd, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                        e->iv_ll.as<float>());
     FB_DBG_SYNC(e, "gmm_dump");
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
-                             e->iv_pairs.as<int>(), e->iv_llf.as<float>());
+                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), sel_gate);
     FB_DBG_SYNC(e, "select_post");
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
@@ -1370,7 +1395,9 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
         FBCHK(e->iv_tail_counter.ensure(sizeof(int)));
         HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), s));
       }
-      if (!split) {
+      // (LDA dimension > 512: the tail's 512 threads would take two l each in the PLDA partial sums where k_iv_backend's
+      //  1024 take one -- a different summation grouping; such a system keeps the separate launch and its rounding)
+      if (!split && iv.L <= 512) {
         if (e->tail_loss_req && fb_iv_tail_takes_loss(B)) { tail = e->tail_req; tail.loss = 1; }
         tail.backend = 1;
         tail.llr = e->raw.as<double>();
@@ -1789,6 +1816,36 @@ extern "C" int fb_debug_iv_active(fb_engine *e, int *n_active) {
   return FB_OK;
 }
 
+// gmm-gselect of the last i-vector batch: sel[rows][nsel] (rows = the batch's voiced frames), and what the threshold path
+// did: info[0] = 1 when fb_launch_gsel ran (0: the dump + k_iv_select path), info[1] = its overflow flag (1: the rescue
+// launches redid the batch), info[2] = most survivors in one (row, chunk) list, info[3] = total survivors, info[4] = rows
+extern "C" int fb_debug_iv_gselect(fb_engine *e, int *sel, int64_t sel_cap, int64_t *info) {
+  if (!e || !info) return fb_fail(FB_E_ARG, "bad argument");
+  if (e->kind != 1 || e->last_B <= 0) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
+  HIPCHK(hipSetDevice(e->device));
+  FBCHK(sync_stream(e));
+  int rows = 0;
+  HIPCHK(hipMemcpy(&rows, e->row_off.as<int>() + e->last_B, sizeof(int), hipMemcpyDeviceToHost));
+  const int nsel = e->iv.nsel;
+  if (sel) {
+    if (sel_cap < (int64_t)rows * nsel) return fb_fail(FB_E_ARG, "sel holds %lld ints, the batch needs %lld", (long long)sel_cap, (long long)rows * nsel);
+    HIPCHK(hipMemcpy(sel, e->iv_sel.p, sizeof(int) * (size_t)rows * nsel, hipMemcpyDeviceToHost));
+  }
+  const int n_chunks = fb_gsel_chunks(choose_chunks(e->gmm, e->last_total_frames, false));
+  info[0] = fb_gsel_applies(e->gmm, nsel, n_chunks) ? 1 : 0;
+  info[1] = info[2] = info[3] = 0;
+  info[4] = rows;
+  if (info[0]) {
+    int flag = 0;
+    HIPCHK(hipMemcpy(&flag, e->gs_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+    info[1] = flag;
+    std::vector<int> cnt((size_t)rows * n_chunks);
+    HIPCHK(hipMemcpy(cnt.data(), e->gs_cnt.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+    for (int c : cnt) { info[2] = c > info[2] ? c : info[2]; info[3] += c; }
+  }
+  return FB_OK;
+}
+
 // i-vectors of the last scored batch (enrolment: build_spk_models.py:104-150 keeps the enrolment utterance's
 // i-vector as the speaker identity)
 extern "C" int fb_last_ivectors(fb_engine *e, int B, double *ivecs) {
@@ -1913,10 +1970,16 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
   if (e->tail_loss_done) return FB_OK;
   if (fuse_fin) {
     if (!e->fin_counter.p) {
-      FBCHK(e->fin_counter.ensure(sizeof(int)));
-      HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+      FBCHK(e->fin_counter.ensure(2 * sizeof(int)));   // [0] the arrival counter, [1] the fused launch's role ticket
+      HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, 2 * sizeof(int), e->stream));
     }
     FbUpdArgs ux;
+    if (upd) {
+      static const bool by_index = getenv("FB_FIN_BLOCKIDX") != nullptr;   // (A/B: roles by blockIdx)
+      ux = *upd;
+      ux.role_ticket = by_index ? nullptr : e->fin_counter.as<int>() + 1;
+      upd = &ux;
+    }
     if (upd && getenv("FB_FIN_COUNTER") == nullptr) {  // (FB_FIN_COUNTER=1: the arrival counter instead of the exchange slots, A/B)
       const size_t had = e->fin_xch.cap;
       FBCHK(e->fin_xch.ensure(sizeof(unsigned long long) * (size_t)B * e->gmm.M));
@@ -1924,9 +1987,7 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->fin_xch.p), (int)FB_VAD_SENTINEL32, e->fin_xch.cap / 4, e->stream));
         e->fin_xch_clean = true;
       }
-      ux = *upd;
       ux.xch = e->fin_xch.as<unsigned long long>();
-      upd = &ux;
     }
     fb_launch_gmm_finalize_loss(e->stream, e->gmm, e->part_m.as<float>(), e->part_s.as<float>(), e->last_total_frames,
                                 e->last_chunks, e->row_off.as<int>(), B, e->raw.as<double>(), e->fin_counter.as<int>(),
@@ -1970,7 +2031,7 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
     // that completes; one that was aborted or failed would leave them elsewhere and every later launch would then
     // mis-assign utterances / skip its loss body.  A new attack starts them clean.
     if (e->vad_counter.p) HIPCHK(hipMemsetAsync(e->vad_counter.p, 0, sizeof(int), e->stream));
-    if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, sizeof(int), e->stream));
+    if (e->fin_counter.p) HIPCHK(hipMemsetAsync(e->fin_counter.p, 0, 2 * sizeof(int), e->stream));
     e->fin_xch_clean = false;  // (refilled with sentinels before its next use)
     if (e->iv_tail_counter.p) HIPCHK(hipMemsetAsync(e->iv_tail_counter.p, 0, sizeof(int), e->stream));
     e->vad_part_B = -1;  // ... and k_vad_delta_cmvn_p's exchange slots are refilled with sentinels (run_post_mfcc)

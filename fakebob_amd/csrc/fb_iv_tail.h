@@ -131,7 +131,8 @@ __device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, dou
     const double *tr = iv.train + (size_t)s * L;
     double given = 0.0, without = 0.0;
     // (one l per thread while L <= NT: the same partial sums in the same waves as k_iv_backend's 1024 threads, whose
-    //  upper waves then add zeros)
+    //  upper waves then add zeros.  The host only lets a 512-thread tail run this for L <= 512 -- fb_engine.hip,
+    //  run_scoring --, so "the same bits whichever kernel runs it" holds wherever both can run)
     for (int l = tid; l < L; l += NT) {
       const double psi = iv.plda_psi[l];
       const double mean = psi / (psi + 1.0) * tr[l];

@@ -98,6 +98,7 @@ struct FbUpdArgs {
   double *dist_part;
   double qscale;
   unsigned long long *xch;  // nullable: B x M exchange slots of the finalising workgroups, every one FB_VAD_SENTINEL between launches
+  int *role_ticket;         // nullable: k_gmm_finalize_loss_update's arrival ticket (zero between launches); null = roles by blockIdx
 };
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,
@@ -201,6 +202,7 @@ struct FbGmmDev {
   int pass_lo[4];
   const float *anchor;
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
+  const int *only_if;  // nullable device flag: == 0 -> the DUMP launch does nothing (the gselect rescue: fb_launch_gsel)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
 };
 #define FB_FXW_MAX_PASS 3 // launches of k_gmm_fx2w per batch: 1 + 9 x 3 = 28 models (fb_load_gmm)
@@ -238,6 +240,15 @@ void fb_launch_gmm(hipStream_t s, const FbGmmDev &g, const float *feats, const i
 // single model (g.M == 1): ll[row][n_tiles*32] = every component log-likelihood (gmm-gselect input)
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *row_off_total,
                         int rows_cap, int n_chunks, float *ll);
+// gmm-gselect WITHOUT the dump (round 6; k_gmm_fx2_sel / k_gsel_tau / k_gsel_final, gmm_kernels.hip): single model in
+// the FX2 mode.  Workspace: gmax rows_cap x 2 n_tiles floats, tau rows_cap floats, glist rows_cap x n_chunks x cap 64-bit
+// keys, gcnt rows_cap x n_chunks ints, flag 1 int (set when any row overflowed its lists: the caller then runs the dump +
+// k_iv_select gated on it).  sel[row][nsel] as k_iv_select writes it.  fb_gsel_cap(n_chunks) = list entries per (row, chunk).
+bool fb_gsel_applies(const FbGmmDev &g, int nsel, int n_chunks);
+int fb_gsel_cap(int n_chunks);
+int fb_gsel_chunks(int dump_chunks);   // the selection kernels' own chunk count (a power of two <= 8)
+void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
+                    int nsel, float *gmax, float *tau, unsigned long long *glist, int *gcnt, int *flag, int *sel);
 // k_gmm_finalize + k_loss fused (GMM systems in the NES loop): counter = one int, zero before the first launch
 void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                                  int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
@@ -306,9 +317,11 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
                          double *sim, double *u);
 // bucket_ws: fb_iv_bucket_ws_ints() ints of workspace, zero before the first use; pairs / llf: rows_cap * nsel
 size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap);
+// sel_gate: nullable device flag -- k_iv_select runs only when it is non-zero (sel[] then already holds fb_launch_gsel's
+// selection; the gate is its overflow flag)
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf);
+                              int *pairs, float *llf, const int *sel_gate = nullptr);
 // gammaT [C][Bpad], XT [C*D][Bpad]: utterance-minor, zero-padded to Bpad (multiple of 32)
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);

@@ -42,6 +42,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 #define FB_F32_MEL_CHUNK 12  // weights per mel piece (three 16-byte LDS reads)
 #define FB_F32_PIECES 64     // at most: four per lane of a frame -- mel pieces and DCT half rows alike
+#define FB_F32_MAX_FILTER_PIECES 6  // piece sums k_mfcc_f32 adds per filter (a filter of <= 72 FFT bins)
 struct MfccF32Lds {  // offsets in floats
   int tw, twf, win, melw, pfirst, mp0, mcnt, dctp, lift, wave0;
 };
@@ -65,9 +66,15 @@ __host__ __device__ inline MfccF32Lds fb_mfcc_f32_layout(int L, int nb, int nc, 
   return o;
 }
 // pieces of FB_F32_MEL_CHUNK weights the mel filters split into (k_mfcc_f32 takes at most FB_F32_PIECES)
+// A filter of more than FB_F32_MAX_FILTER_PIECES pieces is reported as FB_F32_PIECES + 1: the kernel adds that many piece
+// sums per filter and no more (round-5 advisor finding: the total alone was checked, the fifth and sixth piece dropped).
 int fb_mfcc_f32_mel_pieces(const int *mel_len, int nb) {
   int np = 0;
-  for (int m = 0; m < nb; ++m) np += mel_len[m] > 0 ? (mel_len[m] + FB_F32_MEL_CHUNK - 1) / FB_F32_MEL_CHUNK : 1;  // (an empty filter: one zero piece)
+  for (int m = 0; m < nb; ++m) {
+    const int cnt = mel_len[m] > 0 ? (mel_len[m] + FB_F32_MEL_CHUNK - 1) / FB_F32_MEL_CHUNK : 1;  // (an empty filter: one zero piece)
+    if (cnt > FB_F32_MAX_FILTER_PIECES) return FB_F32_PIECES + 1;
+    np += cnt;
+  }
   return np;
 }
 
@@ -385,10 +392,16 @@ __global__ __launch_bounds__(64 * FB_F32_WAVES, 1) void k_mfcc_f32(FbFrontendDev
       if (m < nb) {
         const int q0 = s_mp0[m], cnt = s_mcnt[m];
         e = PS[q0];  // (cnt >= 1; an empty filter owns one all-zero piece)
+        // (every piece of the filter, left to right; FB_F32_MAX_FILTER_PIECES is what fb_set_frontend admits: Kaldi's 23
+        //  bins at 16 kHz have filters of 52 bins = 5 pieces, 16 bins 67 = 6)
         const float e1 = PS[q0 + (cnt > 1 ? 1 : 0)], e2 = PS[q0 + (cnt > 2 ? 2 : 0)], e3 = PS[q0 + (cnt > 3 ? 3 : 0)];
+        const float e4 = PS[q0 + (cnt > 4 ? 4 : 0)], e5 = PS[q0 + (cnt > 5 ? 5 : 0)];
+        static_assert(FB_F32_MAX_FILTER_PIECES == 6, "one term per admitted piece");
         if (cnt > 1) e += e1;
         if (cnt > 2) e += e2;
         if (cnt > 3) e += e3;
+        if (cnt > 4) e += e4;
+        if (cnt > 5) e += e5;
       }
       const bool is_energy = half == 1 && t == 15;
       double ed = is_energy ? energy : (double)e;

@@ -326,46 +326,11 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
   if constexpr (ISQ) hq = hi; else pv = hi;
 }
 
-template <int NK, bool DUMP>
-__global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const float *__restrict__ feats,
-                                                    const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
-                                                    int rows_cap, float *__restrict__ part_m,
-                                                    float *__restrict__ part_s, int xcd_map) {
-  if (g.stop && *g.stop) return;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
-  constexpr int NST = (IMG4 + 255) / 256;
-  const int n_rows = *n_rows_ptr;
-  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
-  if (xcd_map) {
-    const int lin = blockIdx.x, per = 8 / xcd_map;
-    const int xcd = lin & 7, idx = lin >> 3;
-    chunk_i = xcd / per;
-    strip_i = idx * per + (xcd % per);
-  } else {
-    strip_i = blockIdx.x;
-    chunk_i = blockIdx.y;
-  }
-  const int strip0 = strip_i * 128;
-  if (strip0 >= n_rows) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int h = lane >> 5, j = lane & 31;
-  const int row = strip0 + w * 32 + j;
-  u32x4 *slot0 = reinterpret_cast<u32x4 *>(lds), *slot1 = slot0 + IMG4;
-  float *st_m = lds + 2 * IMG4 * 4;        // [M][256]
-  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
-
-  // ---- frame fragments: chunk c of this lane = dims 16c + 8h + i, i < 8;  bx = x (1.0 at position D,
-  //      whose residual is 0), bq = fl(x*x), both moved by the load-time powers of two 2^kx / 2^kx2.
-  // Range guard: the load-time scalings assume |x| 2^kx and x^2 2^kx2 below f16's 65504.  Features beyond
-  // that (|x| >= 64 with kx2 = 4: liftered cepstra of tonal audio, unusual front-end configurations) would turn
-  // into inf and the scores into NaN.  Each wave therefore takes the largest scaled operand of its 32 frames
-  // and, when it reaches 2^15, moves ALL its frame operands (x, the 1.0 that multiplies gconst, x^2) down by one
-  // wave-uniform power of two 2^-sh: the accumulators then hold ll 2^(kacc - sh), the logsumexp multiplier and
-  // the final un-scaling take the factor back, and every step stays an exact power-of-two scaling.  Small
-  // operands of such a frame may become f16 subnormals (absolute precision 2^-25 of the scaled operand), which is
-  // below the f32 rounding of the large terms that caused the shift.  sh = 0 for ordinary speech features.
-  u32x4 bx1[NK], bx2[NK], bq1[NK], bq2[NK];
+// The frame operands of a lane of k_gmm_fx2 / k_gmm_fx2_sel (see the comment in k_gmm_fx2): chunk c = dims 16c + 8h + i,
+// two-term f16 splits of x (1.0 at position D) and x^2 under the load-time powers of two; returns the wave's range shift.
+template <int NK>
+__device__ __forceinline__ int fb_fx_frame_frags(const FbGmmDev &g, const float *__restrict__ feats, int row, int n_rows, int h,
+                                                 u32x4 (&bx1)[NK], u32x4 (&bx2)[NK], u32x4 (&bq1)[NK], u32x4 (&bq2)[NK]) {
   int sh = 0;
   {
     const bool ok = row < n_rows;
@@ -414,6 +379,53 @@ __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const fl
       fb_split2_frag(qq[c], bq1[c], bq2[c]);
     }
   }
+  return sh;
+}
+
+template <int NK, bool DUMP>
+__global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const float *__restrict__ feats,
+                                                    const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
+                                                    int rows_cap, float *__restrict__ part_m,
+                                                    float *__restrict__ part_s, int xcd_map) {
+  if (g.stop && *g.stop) return;
+  if constexpr (DUMP) {
+    if (g.only_if && *g.only_if == 0) return;  // the gselect rescue: nothing overflowed
+  }
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
+  constexpr int NST = (IMG4 + 255) / 256;
+  const int n_rows = *n_rows_ptr;
+  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
+  if (xcd_map) {
+    const int lin = blockIdx.x, per = 8 / xcd_map;
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 128;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int row = strip0 + w * 32 + j;
+  u32x4 *slot0 = reinterpret_cast<u32x4 *>(lds), *slot1 = slot0 + IMG4;
+  float *st_m = lds + 2 * IMG4 * 4;        // [M][256]
+  float *st_s = st_m + (size_t)g.M * 256;  // [M][256]
+
+  // ---- frame fragments: chunk c of this lane = dims 16c + 8h + i, i < 8;  bx = x (1.0 at position D,
+  //      whose residual is 0), bq = fl(x*x), both moved by the load-time powers of two 2^kx / 2^kx2.
+  // Range guard: the load-time scalings assume |x| 2^kx and x^2 2^kx2 below f16's 65504.  Features beyond
+  // that (|x| >= 64 with kx2 = 4: liftered cepstra of tonal audio, unusual front-end configurations) would turn
+  // into inf and the scores into NaN.  Each wave therefore takes the largest scaled operand of its 32 frames
+  // and, when it reaches 2^15, moves ALL its frame operands (x, the 1.0 that multiplies gconst, x^2) down by one
+  // wave-uniform power of two 2^-sh: the accumulators then hold ll 2^(kacc - sh), the logsumexp multiplier and
+  // the final un-scaling take the factor back, and every step stays an exact power-of-two scaling.  Small
+  // operands of such a frame may become f16 subnormals (absolute precision 2^-25 of the scaled operand), which is
+  // below the f32 rounding of the large terms that caused the shift.  sh = 0 for ordinary speech features.
+  u32x4 bx1[NK], bx2[NK], bq1[NK], bq2[NK];
+  const int sh = fb_fx_frame_frags<NK>(g, feats, row, n_rows, h, bx1, bx2, bq1, bq2);
   for (int m = 0; m < g.M; ++m) { st_m[m * 256 + tid] = FB_GMM_NEG; st_s[m * 256 + tid] = 0.0f; }
 
   const int tile0 = chunk_i * tiles_per_chunk;
@@ -531,6 +543,258 @@ static void launch_gmm_fx(hipStream_t s, const FbGmmDev &g, const float *feats, 
     case 5: launch_gmm_fx_t<5, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     case 6: launch_gmm_fx_t<6, DUMP>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, tpc, part_m, part_s); break;
     default: break;  // fb_load_gmm only produces the NKF values above
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// gmm-gselect --n=20 WITHOUT the dump (round 6; ivector_PLDA_kaldiHelper.py:197-213).
+// The dump + k_iv_select pair wrote and re-read every one of the C log-likelihoods of every frame (2 x 125 MB at
+// configs[2] size for 1.2 MB of indices).  Here nothing but survivors of a threshold leaves the matrix-core kernel:
+//   pass A  k_gmm_fx2_sel<NK, false>: the k_gmm_fx2 body; a lane (one frame, 16 components of the tile) keeps the MAXIMUM
+//           of its 16 values -> gmax[row][2 n_tiles] (one float per (tile, half): 128 per frame at C = 2048).
+//   tau     k_gsel_tau: tau(row) = the nsel-th largest of the row's group maxima.  nsel distinct groups hold a value
+//           >= tau, so the nsel-th largest log-likelihood is >= tau: NO component below tau can be selected.
+//   pass B  k_gmm_fx2_sel<NK, true>: the same body again (bit-identical values); every value >= tau(row) is appended as a
+//           64-bit key (ordered value bits, component index) to the row's list of this component chunk (LDS, then global).
+//   final   k_gsel_final: the row's survivors (~22 of 2048) ranked by counting (key > key) -- descending (value, index),
+//           std::greater<pair<float,int>> like gmm-gselect and k_iv_select -- ranks < nsel written to sel[].
+// Exact by construction: the selection is a function of the same float values the dump would have stored.  A list that
+// overflows its fb_gsel_cap() entries (never seen on speech; possible with degenerate models) raises `flag`, and the caller's
+// dump + k_iv_select launches -- which return at once while the flag is zero -- redo the batch the old way.
+#define FB_GSEL_MAXC 128   // survivors per row the final kernel ranks (n_chunks x cap)
+int fb_gsel_cap(int n_chunks) {
+  const char *ev = getenv("FB_GSEL_CAP");   // tests: a tiny capacity makes every list overflow (the rescue path)
+  if (ev && atoi(ev) > 0 && atoi(ev) <= 32) return atoi(ev);
+  return n_chunks <= 4 ? 32 : (n_chunks <= 8 ? 16 : 0);
+}
+// component chunks of the selection kernels: the dump's count brought down to a power of two <= 8 (the lists of a row
+// are n_chunks x cap <= FB_GSEL_MAXC entries)
+int fb_gsel_chunks(int n_chunks) { return n_chunks >= 8 ? 8 : (n_chunks >= 4 ? 4 : (n_chunks >= 2 ? 2 : 1)); }
+bool fb_gsel_applies(const FbGmmDev &g, int nsel, int n_chunks) {
+  // (few groups: tau would be -inf and every component a survivor -- the dump is the right tool for small models)
+  const bool off = getenv("FB_IV_GSEL_DUMP") != nullptr;   // A/B and tests: the dump + k_iv_select path (read per batch)
+  return !off && g.mode == FB_GMM_MODE_FX2 && g.M == 1 && g.n_items == 2 && 2 * g.n_tiles >= 4 * nsel && 2 * g.n_tiles <= 256 &&
+         fb_gsel_cap(n_chunks) > 0 && nsel <= 32;
+}
+__device__ __forceinline__ unsigned fb_f32_ordered(float v) {  // monotone map float -> unsigned (total order of the values)
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+template <int NK, bool PICK>
+__global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2_sel(FbGmmDev g, const float *__restrict__ feats,
+                                                        const int *__restrict__ n_rows_ptr, int tiles_per_chunk, int n_chunks,
+                                                        float *__restrict__ gmax, const float *__restrict__ tau, int cap,
+                                                        unsigned long long *__restrict__ glist, int *__restrict__ gcnt,
+                                                        int xcd_map) {
+  if (g.stop && *g.stop) return;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 2 * NK * 64;  // 16-byte units per item
+  constexpr int NST = (IMG4 + 255) / 256;
+  const int n_rows = *n_rows_ptr;
+  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
+  if (xcd_map) {
+    const int lin = blockIdx.x, per = 8 / xcd_map;
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 128;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int row = strip0 + w * 32 + j;
+  u32x4 *slot0 = reinterpret_cast<u32x4 *>(lds), *slot1 = slot0 + IMG4;
+  float *s_mx = lds + 2 * IMG4 * 4;                                                   // pass A: [tiles_per_chunk][256]
+  int *s_cnt = reinterpret_cast<int *>(lds + 2 * IMG4 * 4);                           // pass B: [128]
+  unsigned long long *s_list = reinterpret_cast<unsigned long long *>(s_cnt + 128);  //         [128][cap]
+  u32x4 bx1[NK], bx2[NK], bq1[NK], bq2[NK];
+  const int sh = fb_fx_frame_frags<NK>(g, feats, row, n_rows, h, bx1, bx2, bq1, bq2);
+  float my_tau = FLT_MAX;
+  if constexpr (PICK) {
+    if (row < n_rows) my_tau = tau[row];
+    if (tid < 128) s_cnt[tid] = 0;
+  }
+  const int tile0 = chunk_i * tiles_per_chunk;
+  const int tile1 = min(g.n_tiles, tile0 + tiles_per_chunk);
+  const int total_items = (tile1 - tile0) * 2;   // {quadratic item, the model's item} per tile
+  const u32x4 *gimg = g.images_fx + (size_t)tile0 * 2 * IMG4;
+  u32x4 stage[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    const int q = min(tid + 256 * s, IMG4 - 1);
+    slot0[q] = gimg[q];
+  }
+  __syncthreads();
+  const float unscale = fb_pow2f(sh - g.kacc);
+  f32x16 hq, pv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { hq[r] = 0.0f; pv[r] = 0.0f; }
+  const int rl = w * 32 + j;   // the frame's row inside the strip
+  for (int it = 0; it < total_items; ++it) {
+    u32x4 *cur = (it & 1) ? slot1 : slot0;
+    u32x4 *nxt = (it & 1) ? slot0 : slot1;
+    {
+      const u32x4 *src = gimg + (size_t)min(it + 1, total_items - 1) * IMG4;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) stage[s] = src[min(tid + 256 * s, IMG4 - 1)];
+    }
+    if (!(it & 1)) {
+      fb_fx_step<NK, true>(cur, lane, bq1, bq2, hq, pv);
+    } else {
+      fb_fx_step<NK, false>(cur, lane, bx1, bx2, hq, pv);
+      const int tl = it >> 1, cbase = (tile0 + tl) * 32 + 4 * h;   // accumulator r = component cbase + (r & 3) + 8 (r >> 2)
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = pv[r] * unscale;   // the float the dump stores (exact: a power of two)
+      if (cbase + 27 >= g.C) {   // the last tile of a model whose C is not a multiple of 32: padding never competes
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (cbase + (r & 3) + 8 * (r >> 2) >= g.C) v[r] = -FLT_MAX;
+      }
+      if constexpr (!PICK) {
+        float tm = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, v[r]);
+        s_mx[tl * 256 + tid] = tm;
+      } else {
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n += (v[r] >= my_tau) ? 1 : 0;
+        if (n > 0) {
+          int at = atomicAdd(&s_cnt[rl], n);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (v[r] >= my_tau) {
+              if (at < cap)
+                s_list[rl * cap + at] = ((unsigned long long)fb_f32_ordered(v[r]) << 32) | (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
+              ++at;
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) nxt[min(tid + 256 * s, IMG4 - 1)] = stage[s];
+    __syncthreads();
+  }
+  const int ntl = tile1 - tile0;
+  if constexpr (!PICK) {
+    // whole 8 ntl-byte runs per row: consecutive threads = consecutive (tile, half) positions of one frame
+    const int NG = 2 * g.n_tiles, per_row = 2 * ntl;
+    for (int i = tid; i < 128 * per_row; i += 256) {
+      const int r2 = i / per_row, pos = i - r2 * per_row;
+      const int tl = pos >> 1, hh = pos & 1;
+      const int rg = strip0 + r2;
+      if (rg < n_rows) gmax[(size_t)rg * NG + 2 * tile0 + pos] = s_mx[tl * 256 + (r2 >> 5) * 64 + hh * 32 + (r2 & 31)];
+    }
+  } else {
+    (void)ntl;
+    for (int i = tid; i < 128 * cap; i += 256) {
+      const int r2 = i / cap, k = i - r2 * cap;
+      const int rg = strip0 + r2;
+      if (rg < n_rows && k < min(s_cnt[r2], cap)) glist[((size_t)rg * n_chunks + chunk_i) * cap + k] = s_list[i];
+    }
+    if (tid < 128 && strip0 + tid < n_rows) gcnt[(size_t)(strip0 + tid) * n_chunks + chunk_i] = s_cnt[tid];
+  }
+}
+
+// tau(row) = the nsel-th largest of the row's NG = 16 NV group maxima.  A frame per DPP row (16 lanes, NV values each in
+// registers), four frames per wave; a round = the row maximum (four DPP steps) and its removal.  Equal maxima leave
+// together: after nsel rounds at least nsel groups >= the last maximum have left -- all tau has to promise.
+template <int NV>
+__global__ __launch_bounds__(256) void k_gsel_tau(const float *__restrict__ gmax, int NG, const int *__restrict__ n_rows_ptr,
+                                                 int nsel, float *__restrict__ tau, int *__restrict__ flag) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;   // (the rescue launches of the previous batch are behind us)
+  const int n_rows = *n_rows_ptr;
+  const int l = threadIdx.x & 15, row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool ok = row < n_rows;
+  const float *gr = gmax + (size_t)(ok ? row : 0) * NG;
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (ok && l + 16 * i < NG) ? gr[min(l + 16 * i, NG - 1)] : -FLT_MAX;
+  float t = -FLT_MAX;
+  for (int s = 0; s < nsel; ++s) {
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < NV; ++i) m = fmaxf(m, v[i]);
+#define FB_RMAX(CTRL) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), CTRL, 0xf, 0xf, false)));
+    FB_RMAX(0xb1) FB_RMAX(0x4e) FB_RMAX(0x141) FB_RMAX(0x140)
+#undef FB_RMAX
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = v[i] >= m ? -FLT_MAX : v[i];
+    t = m;
+  }
+  if (ok && l == 0) tau[row] = t;
+}
+
+// the survivors of a row ranked: 16 lanes per frame, 16 frames per workgroup.  rank(key) = number of larger keys; the keys
+// are distinct (the index is part of them), so ranks 0 .. n-1 are a permutation: descending (value, index).
+__global__ __launch_bounds__(256) void k_gsel_final(const unsigned long long *__restrict__ glist, const int *__restrict__ gcnt,
+                                                   int n_chunks, int cap, const int *__restrict__ n_rows_ptr, int nsel, int C,
+                                                   int *__restrict__ sel, int *__restrict__ flag) {
+  __shared__ unsigned long long s_key[16][FB_GSEL_MAXC];
+  const int n_rows = *n_rows_ptr;
+  const int l = threadIdx.x & 15, rw = threadIdx.x >> 4, row = blockIdx.x * 16 + rw;
+  if (row >= n_rows) return;   // (no workgroup barrier below: a frame's 16 lanes sit in one wave)
+  int n = 0;
+  bool over = false;
+  for (int k = 0; k < n_chunks; ++k) {
+    const int c = gcnt[(size_t)row * n_chunks + k];
+    over |= c > cap;
+    const int cc = min(c, cap);
+    const unsigned long long *src = glist + ((size_t)row * n_chunks + k) * cap;
+    for (int e = l; e < cc; e += 16) s_key[rw][n + e] = src[e];
+    n += cc;
+  }
+  if (over || n < min(nsel, C)) { if (l == 0) atomicOr(flag, 1); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = l; i < n; i += 16) {
+    const unsigned long long my = s_key[rw][i];
+    int rank = 0;
+    for (int q = 0; q < n; ++q) rank += s_key[rw][q] > my ? 1 : 0;
+    if (rank < nsel) sel[(size_t)row * nsel + rank] = (int)(unsigned)(my & 0xffffffffull);
+  }
+  for (int s2 = n + l; s2 < nsel; s2 += 16) sel[(size_t)row * nsel + s2] = -1;   // fewer components than nsel
+}
+
+template <int NK>
+static void launch_gsel_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
+                          int nsel, float *gmax, float *tau, unsigned long long *glist, int *gcnt, int *flag, int *sel) {
+  const int strips = (rows_cap + 127) / 128, tpc = (g.n_tiles + n_chunks - 1) / n_chunks, cap = fb_gsel_cap(n_chunks);
+  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  int xcd_map = 0;
+  static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
+  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
+    const int per = 8 / n_chunks;
+    grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
+    xcd_map = n_chunks;
+  }
+  const size_t img = (size_t)2 * 2 * NK * 64 * 16;
+  hipLaunchKernelGGL((k_gmm_fx2_sel<NK, false>), grid, dim3(256), img + sizeof(float) * 256 * (size_t)tpc, s, g, feats, n_rows_ptr, tpc,
+                     n_chunks, gmax, nullptr, cap, nullptr, nullptr, xcd_map);
+  const int NG = 2 * g.n_tiles, tb = (rows_cap + 15) / 16;
+  if (NG <= 64) hipLaunchKernelGGL(k_gsel_tau<4>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  else if (NG <= 128) hipLaunchKernelGGL(k_gsel_tau<8>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  else hipLaunchKernelGGL(k_gsel_tau<16>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  hipLaunchKernelGGL((k_gmm_fx2_sel<NK, true>), grid, dim3(256), img + sizeof(int) * 128 + sizeof(unsigned long long) * 128 * (size_t)cap, s, g,
+                     feats, n_rows_ptr, tpc, n_chunks, nullptr, tau, cap, glist, gcnt, xcd_map);
+  hipLaunchKernelGGL(k_gsel_final, dim3(tb), dim3(256), 0, s, glist, gcnt, n_chunks, cap, n_rows_ptr, nsel, g.C, sel, flag);
+}
+void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
+                    int nsel, float *gmax, float *tau, unsigned long long *glist, int *gcnt, int *flag, int *sel) {
+  if (rows_cap <= 0) return;
+  switch (g.NKF) {
+    case 2: launch_gsel_t<2>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
+    case 3: launch_gsel_t<3>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
+    case 4: launch_gsel_t<4>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
+    case 5: launch_gsel_t<5>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
+    case 6: launch_gsel_t<6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
+    default: break;
   }
 }
 
@@ -773,8 +1037,9 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
 // (fb_update_perturb_body<WAIT>): they stage this iteration's normals and draw the next iteration's while the scores are
 // finalised, then wait for the loss body's publication (ctl->pub_seq, agent-scope stores / loads: no device-wide
 // fence) and go on.  One launch boundary less in a lone attack's chain, and the Philox + Box-Muller work -- most of
-// k_update_perturb -- off its critical path.  Workgroups are dispatched in index order: the finalising ones are running
-// or done before an update workgroup can wait for them.
+// k_update_perturb -- off its critical path.  Roles are drawn from an arrival ticket (u.role_ticket): the finalising
+// workgroups are running or done before an update workgroup can wait for them, whatever order the hardware dispatches in.
+// (u.role_ticket == nullptr -- FB_FIN_BLOCKIDX=1, A/B only -- takes blockIdx and relies on index-order dispatch.)
 template <bool SMALL>
 __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,
@@ -789,7 +1054,23 @@ __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, co
                                                            FbNesDev *__restrict__ out, FbCtlDev *__restrict__ ctl,
                                                            double *__restrict__ trace, int it, int pub_seq, FbUpdArgs u) {
   extern __shared__ double s_dyn_upd[];
-  const int n_fin = B * g.M, lin = (int)blockIdx.x;
+  const int n_fin = B * g.M;
+  int lin = (int)blockIdx.x;
+  if (u.role_ticket) {
+    // Roles by ARRIVAL, not by blockIdx (round-5 advisor finding): the update workgroups spin on the loss body's
+    // publication and the consumer on the finalisers' slots, so a role must never wait for one that is not running yet.
+    // HIP does not promise dispatch in index order; a ticket does: the first B x M arrivals finalise (the last of THEM
+    // is the consumer -- every slot it polls belongs to an earlier ticket), the later ones update.  Every workgroup
+    // draws, stopping launch or not; the last ticket leaves the word at zero for the next launch.
+    __shared__ int s_role;
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(u.role_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (int)gridDim.x - 1) __hip_atomic_store(u.role_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_role = t;
+    }
+    __syncthreads();
+    lin = s_role;
+  }
   if (lin < n_fin) {
     fb_gmm_finalize_loss_body<SMALL>(g, part_m, part_s, rows_cap, n_chunks, row_off, B, raw, counter, tv, task, attack_type, z_mean,
                                      z_std, threshold, adver_thresh, target, true_label, dist_part, n_dist_part, scores, loss, out,

@@ -102,7 +102,9 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 //  84.9 us against 45 -- at 141 registers three waves per SIMD no longer hide the 16 KB a wave waits for.)
 template <int NJ>
 __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__restrict__ ll,
-                                                   const int *__restrict__ n_rows_ptr, int *__restrict__ sel) {
+                                                   const int *__restrict__ n_rows_ptr, int *__restrict__ sel,
+                                                   const int *__restrict__ gate) {
+  if (gate && *gate == 0) return;   // the rescue launch behind fb_launch_gsel: no list overflowed, sel[] is complete
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n_rows = *n_rows_ptr;
   const int row = blockIdx.x * 4 + w;
@@ -757,7 +759,7 @@ size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
 }
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf) {
+                              int *pairs, float *llf, const int *sel_gate) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
   int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *nz = wstart + (C + 1) + C,
@@ -767,11 +769,11 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
   {
     const dim3 grid((rows_cap + 3) / 4), blk(256);
     const int nj = (iv.Cpad + 63) / 64;
-    if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
-    else if (nj <= 8) hipLaunchKernelGGL(k_iv_select<8>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
-    else if (nj <= 16) hipLaunchKernelGGL(k_iv_select<16>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
-    else if (nj <= 32) hipLaunchKernelGGL(k_iv_select<32>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);
-    else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel);  // C <= 4096 (fb_load_ivector)
+    if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);
+    else if (nj <= 8) hipLaunchKernelGGL(k_iv_select<8>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);
+    else if (nj <= 16) hipLaunchKernelGGL(k_iv_select<16>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);
+    else if (nj <= 32) hipLaunchKernelGGL(k_iv_select<32>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);
+    else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);  // C <= 4096 (fb_load_ivector)
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
   hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);

@@ -89,6 +89,7 @@ class Engine(object):
         sy.C, sy.D, sy.R, sy.L, sy.S = system.C, system.D, system.R, system.L, system.S
         sy.lda_cols = system.lda.shape[1]
         sy.num_gselect = system.num_gselect
+        self._iv_nsel = system.num_gselect
         sy.min_post = system.min_post
         sy.prior_offset = system.prior_offset
         keep = []
@@ -171,6 +172,16 @@ class Engine(object):
         n = C.c_int()
         N.check(self._L.fb_debug_iv_active(self._h, C.byref(n)))
         return n.value
+
+    def debug_iv_gselect(self, rows_cap=None):
+        """(sel[rows][num_gselect], info dict) of the last i-vector batch -- fb_debug_iv_gselect."""
+        info = (C.c_int64 * 5)()
+        N.check(self._L.fb_debug_iv_gselect(self._h, None, C.c_int64(0), info))
+        rows, nsel = int(info[4]), int(self._iv_nsel)
+        sel = np.empty((rows, nsel), np.int32)
+        N.check(self._L.fb_debug_iv_gselect(self._h, N.ptr(sel), C.c_int64(sel.size), info))
+        return sel, dict(threshold_path=bool(info[0]), overflow=int(info[1]), max_list=int(info[2]),
+                         survivors=int(info[3]), rows=rows)
 
     def set_system(self, task, z_mean=None, z_std=None):
         zm = None if z_mean is None else np.ascontiguousarray(z_mean, np.float64)

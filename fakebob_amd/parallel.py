@@ -6,7 +6,7 @@ is a plain `for` loop sharing only the read-only model and, for OSI/SV, one pre-
 NO collective inside an attack.  Attack cost varies by two orders of magnitude (early stop at
 FAKEBOB.py:181-191 against max_iter = 1000, attackMain.sh:24), so the attacks are not dealt out in advance: a free
 attack stream DRAWS the next global attack index from a ticket counter (`WorkQueue`) -- a lock-protected counter inside
-one process, an atomic add on the process group's key-value store across ranks (no collective; nccl and gloo alike).
+one process, an atomic add on the job's own key-value store (a TCPStore) across ranks (no collective; nccl and gloo alike).
 Results do not depend on who runs what: the Philox stream of an attack is its global index.  `schedule="static"`
 keeps the round-robin deal of earlier rounds (A/B, bench.py's end_to_end line).  RCCL (torch.distributed backend
 "nccl" on ROCm; "gloo" in the CPU tests) is used only for
@@ -36,12 +36,13 @@ class WorkQueue(object):
 
     world == 1 or schedule == "static": no communication -- static hands rank r the indices r, r + world, ... in
     order (what attack_main did before round 5, per stream as well when `streams` is given: stream k of K takes every
-    K-th of them).  Dynamic with world > 1: `store.add(key, 1)` on the default process group's store is atomic across
-    ranks and returns the new value; every rank constructs its queues in the same order, so queue number q uses the
-    same key everywhere."""
-    _made = 0
+    K-th of them).  Dynamic with world > 1: `store.add(key, 1)` on the job's own store (`job_store()`: the TCPStore this
+    module opened for the rendezvous, under its own prefix) is atomic across ranks and returns the new value; every rank
+    constructs its STORE-BACKED queues in the same order, so queue number q uses the same key everywhere (or pass
+    `name`)."""
+    _made = 0   # store-backed queues constructed so far in this process (the default key's suffix)
 
-    def __init__(self, n_items, dist=None, schedule="dynamic", rank=None, world=None, streams=None):
+    def __init__(self, n_items, dist=None, schedule="dynamic", rank=None, world=None, streams=None, name=None):
         if schedule not in ("dynamic", "static"):
             raise ValueError("schedule must be 'dynamic' or 'static'")
         r, _, w = dist_env() if dist is not None else (0, 0, 1)
@@ -51,12 +52,16 @@ class WorkQueue(object):
         self.schedule = schedule
         self._lock = threading.Lock()
         self._streams = streams
-        self._key = "fakebob/next/%d" % WorkQueue._made
-        WorkQueue._made += 1
         self._store = None
+        self._key = None
         if schedule == "dynamic" and self.world > 1:
-            import torch.distributed as td
-            self._store = td.distributed_c10d._get_default_store()
+            # Only a queue that really goes through the store takes a key number (round-5 advisor finding: local queues
+            # -- bench.py's end_to_end builds seven per call -- advanced it too, so ranks that had built different numbers
+            # of local queues disagreed on the key and each drew the whole list).  `name` pins the key explicitly.
+            self._store = job_store()
+            self._key = "next/%s" % (name if name is not None else WorkQueue._made)
+            if name is None:
+                WorkQueue._made += 1
         mine = list(range(self.rank, self.n, self.world))
         if schedule == "static" and streams:
             self._static = [mine[k::streams] for k in range(streams)]
@@ -84,8 +89,41 @@ class WorkQueue(object):
             return i
 
 
+_STORE = None   # this job's own key-value store (the ticket counters of WorkQueue live in it)
+
+
+def _make_store(rank, world, port=None):
+    """A TCPStore of this job's own on MASTER_ADDR (rank 0 serves), wrapped in a PrefixStore: public torch.distributed
+    API only (round-5 review: the queue used to borrow the process group's store through the private
+    `distributed_c10d._get_default_store()`)."""
+    import datetime
+    import torch.distributed as td
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if port is None:
+        port = int(os.environ.get("MASTER_PORT", "29533"))
+    # (under torchrun the agent already serves a store on MASTER_PORT and says so: every worker is a client of it)
+    agent = port == int(os.environ.get("MASTER_PORT", "-1")) and os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    return td.TCPStore(host, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=1800),
+                       wait_for_workers=False)
+
+
+def job_store():
+    """The store WorkQueue draws tickets from.  Created by init_process_group(); when somebody else initialised
+    torch.distributed (no handle here), a second TCPStore on FAKEBOB_STORE_PORT (default MASTER_PORT + 1)."""
+    global _STORE
+    if _STORE is None:
+        import torch.distributed as td
+        rank, _, world = dist_env()
+        port = int(os.environ.get("FAKEBOB_STORE_PORT", str(int(os.environ.get("MASTER_PORT", "29533")) + 1)))
+        _STORE = td.PrefixStore("fakebob", _make_store(rank, world, port))
+    return _STORE
+
+
 def init_process_group(backend=None):
-    """Initialises torch.distributed when WORLD_SIZE > 1.  Returns the module or None."""
+    """Initialises torch.distributed when WORLD_SIZE > 1.  Returns the module or None.  The rendezvous store is created
+    HERE (a TCPStore on MASTER_ADDR:MASTER_PORT) and handed to init_process_group, and the same handle -- under its own
+    prefix -- serves WorkQueue's tickets."""
+    global _STORE
     rank, local_rank, world = dist_env()
     if world <= 1:
         return None
@@ -101,8 +139,18 @@ def init_process_group(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    tcp = _make_store(rank, world)
+    dist.init_process_group(backend, store=dist.PrefixStore("pg", tcp), rank=rank, world_size=world, **kw)
+    _STORE = dist.PrefixStore("fakebob", tcp)
     return dist
+
+
+def agree_on_failure(failed, dist=None):
+    """True on EVERY rank when any rank reports a failure: one 1 x int64 all-reduce ahead of the result reduction, so a
+    rank whose attack stream raised does not leave the others blocked in the final all-reduce (round-5 advisor finding)."""
+    if dist is None:
+        return bool(failed)
+    return reduce_counters([1 if failed else 0], dist)[0] > 0
 
 
 def _device(dist):
@@ -181,8 +229,10 @@ def run_sharded(items, attack_fn, estimate_fn=None, dist=None, schedule="dynamic
         ths = [threading.Thread(target=worker, args=(k,)) for k in range(streams)]
         [t.start() for t in ths]
         [t.join() for t in ths]
-    if errors:
-        raise errors[0]
+    if agree_on_failure(bool(errors), dist):
+        if errors:
+            raise errors[0]
+        raise RuntimeError("an attack stream of another rank failed: this rank's results are incomplete")
     g = reduce_counters([tot[0], len(local), tot[1], tot[2]], dist)
     if g[1] != len(items):
         raise RuntimeError("work queue handed out %d of %d attacks" % (g[1], len(items)))

@@ -54,6 +54,9 @@ int fb_debug_gmm_frames(fb_engine *e, const float *feats, int T, double *out);
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
 int fb_debug_iv_active(fb_engine *e, int *n_active);
+/* gmm-gselect of the last i-vector batch: sel[rows * num_gselect] (nullable), info[5] = {threshold path ran, its overflow
+ * flag, most survivors in one (row, chunk) list, total survivors, rows} */
+int fb_debug_iv_gselect(fb_engine *e, int *sel, int64_t sel_cap, int64_t *info);
 /* time `reps` back-to-back launches of the GMM log-likelihood kernel on the
  * engine's stream with HIP events over the current device feature buffer
  * (filled by the last score/get_grad call). ms_avg out. */

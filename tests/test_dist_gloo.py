@@ -152,3 +152,54 @@ def test_world_size_2_dynamic_queue_balances_skewed_attack_costs(tmp_path):
     # both ranks busy to the end: they finish within one expensive attack (0.1 s of ~0.55 s) of each other
     assert abs(d[0] - d[1]) <= 0.12 + 0.05 * max(d), busy
     assert max(s) >= 1.5 * max(d), busy                      # what the static deal costs on this list
+
+
+HARDEN_WORKER = textwrap.dedent('''
+    import sys, json, time
+    sys.path.insert(0, %r)
+    from fakebob_amd import parallel as P
+    dist = P.init_process_group("gloo")
+    rank, _, world = P.dist_env()
+    # (1) ranks that built DIFFERENT numbers of local queues first still agree on the distributed queue's key
+    for _ in range(3 if rank == 0 else 7):
+        P.WorkQueue(5, None, "dynamic")
+        P.WorkQueue(5, dist, "static")
+    g = P.run_sharded(list(range(13)), lambda it, thr: (1, 1, 51), None, dist)
+    assert g[:2] == (13, 13), g[:4]
+    # (2) the job's own store (public API), not the process group's private default store
+    assert P._STORE is not None and P.job_store() is P._STORE
+    # (3) a stream that raises on ONE rank fails the job on EVERY rank instead of leaving the others in the all-reduce
+    def attack(item, thr):
+        if rank == 1 and item >= 0:
+            raise ValueError("boom on rank 1")
+        time.sleep(0.1)                             # (rank 1 gets to draw before rank 0 has emptied the queue)
+        return 1, 1, 51
+    dist.barrier()
+    try:
+        P.run_sharded(list(range(12)), attack, None, dist)
+        outcome = "returned"
+    except ValueError as ex:
+        outcome = "ValueError"
+    except RuntimeError as ex:
+        outcome = "RuntimeError"
+    with open(sys.argv[1] + "/h_rank%%d.json" %% rank, "w") as w:
+        json.dump({"rank": rank, "outcome": outcome}, w)
+    dist.barrier()
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_world_size_2_queue_keys_own_store_and_failure_propagation(tmp_path):
+    """Round-5 advisor / review items on parallel.py: key numbering counts store-backed queues only, the store is this
+    module's own TCPStore, and a failing rank is seen by every rank before the result reduction."""
+    import json
+    script = tmp_path / "harden_worker.py"
+    script.write_text(HARDEN_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29623", str(script), str(tmp_path)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    rows = [json.load(open(str(tmp_path / ("h_rank%d.json" % k)))) for k in range(2)]
+    assert rows[1]["outcome"] == "ValueError"       # the rank that failed re-raises its own error
+    assert rows[0]["outcome"] == "RuntimeError"     # the other learns of it and raises too -- nobody blocks

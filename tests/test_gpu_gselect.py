@@ -1,0 +1,95 @@
+"""gmm-gselect --n=20 (ivector_PLDA_kaldiHelper.py:197-213) without the dump (round 6): the threshold selection in the
+matrix-core kernel (k_gmm_fx2_sel pass A -> k_gsel_tau -> pass B -> k_gsel_final) against the path it replaces (every
+log-likelihood dumped, k_iv_select) -- the SAME selection, slot for slot, and bit-identical i-vectors; the rescue behind
+it (lists too small for the survivors -> the dump + k_iv_select launches redo the batch); a model whose component count
+is not a multiple of the 32-component tile."""
+import numpy as np
+import pytest
+
+from fakebob_amd.engine import Engine
+from fakebob_amd.models import synthetic_audio, synthetic_ivector_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _wav(utt, n):
+    return (synthetic_audio(utt, n) * 32768.0).astype(np.int16)
+
+
+@pytest.fixture(scope="module")
+def full_iv():
+    return synthetic_ivector_system(C=2048, D=72, R=400, L=200, n_speakers=2)
+
+
+def _run(engine, system, wavs, monkeypatch, **env):
+    for k in ("FB_IV_GSEL_DUMP", "FB_GSEL_CAP"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    llr, tv = engine.score_raw(wavs)
+    sel, info = engine.debug_iv_gselect()
+    ivs = engine.debug_ivectors(len(wavs), system.R)
+    return llr, tv, sel, info, ivs
+
+
+def test_threshold_selection_equals_the_dump_selection_at_full_size(full_iv, monkeypatch):
+    e = Engine(0)
+    try:
+        e.load_ivector(full_iv, "OSI")
+        rng = np.random.default_rng(11)
+        batches = [[_wav(0, 48000), _wav(1, 31000), _wav(2, 11200), _wav(3, 72000), _wav(4, 16000), _wav(5, 52345)],
+                   [_wav(7, 4000)],                                                    # one strip, eight chunks
+                   [(rng.normal(size=20000) * 6000).astype(np.int16), _wav(9, 1700)]]  # noise: flat posteriors
+        for wavs in batches:
+            llr_d, tv_d, sel_d, info_d, ivs_d = _run(e, full_iv, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+            llr_t, tv_t, sel_t, info_t, ivs_t = _run(e, full_iv, wavs, monkeypatch)
+            assert not info_d["threshold_path"] and info_t["threshold_path"]
+            assert info_t["overflow"] == 0
+            assert info_t["rows"] == int(np.sum(tv_t)) == sel_t.shape[0]
+            assert np.array_equal(sel_d, sel_t)                           # the same 20 components in the same order
+            assert sel_t.min() >= 0 and sel_t.max() < full_iv.C
+            assert np.array_equal(ivs_d.view(np.uint64), ivs_t.view(np.uint64))
+            assert np.array_equal(llr_d.view(np.uint64), llr_t.view(np.uint64))
+            per_row = info_t["survivors"] / info_t["rows"]
+            print("threshold gselect: %d rows, %.1f survivors per row, longest (row, chunk) list %d"
+                  % (info_t["rows"], per_row, info_t["max_list"]))
+            assert 20.0 <= per_row <= 40.0 and info_t["max_list"] <= 32
+    finally:
+        e.close()
+
+
+def test_overflowing_lists_take_the_rescue_launches(full_iv, monkeypatch):
+    """FB_GSEL_CAP=2: two entries per (row, chunk) list -- nearly every row overflows, the flag goes up and the gated dump +
+    k_iv_select launches redo the batch: the same selection as the dump path, and the flag is down again after a batch
+    that fits."""
+    e = Engine(0)
+    try:
+        e.load_ivector(full_iv, "SV" if False else "OSI")
+        wavs = [_wav(0, 30000), _wav(1, 9000)]
+        _, _, sel_d, _, ivs_d = _run(e, full_iv, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+        _, _, sel_r, info_r, ivs_r = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_CAP="2")
+        assert info_r["threshold_path"] and info_r["overflow"] == 1 and info_r["max_list"] > 2
+        assert np.array_equal(sel_d, sel_r)
+        assert np.array_equal(ivs_d.view(np.uint64), ivs_r.view(np.uint64))
+        _, _, sel_t, info_t, _ = _run(e, full_iv, wavs, monkeypatch)
+        assert info_t["overflow"] == 0 and np.array_equal(sel_d, sel_t)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("C", [1300, 2560])
+def test_threshold_selection_with_a_padded_last_tile_and_other_group_counts(C, monkeypatch):
+    """C = 1300: 41 tiles, the last with 20 real components (padding must never be selected), 82 groups (k_gsel_tau<8>);
+    C = 2560: 160 groups (k_gsel_tau<16>)."""
+    sy = synthetic_ivector_system(C=C, D=72, R=64, L=32, n_speakers=1)
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        wavs = [_wav(20 + u, 16000 + 3000 * u) for u in range(5)]
+        _, _, sel_d, info_d, ivs_d = _run(e, sy, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+        _, _, sel_t, info_t, ivs_t = _run(e, sy, wavs, monkeypatch)
+        assert info_t["threshold_path"] and info_t["overflow"] == 0 and not info_d["threshold_path"]
+        assert np.array_equal(sel_d, sel_t) and sel_t.max() < C
+        assert np.array_equal(ivs_d.view(np.uint64), ivs_t.view(np.uint64))
+    finally:
+        e.close()

@@ -143,3 +143,39 @@ def test_mfcc_f32_is_refused_for_shapes_the_kernel_does_not_take():
             e.set_frontend(mfcc_f32=1, raw_energy=0)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("bins,ceps", [(23, 13), (16, 13), (20, 20), (26, 24)])
+def test_mfcc_f32_other_mel_bin_counts_are_bit_identical(oracle, bins, ceps):
+    """Round-5 advisor finding: with fewer mel bins the filters are wider than 48 FFT bins (Kaldi's default 23 bins at
+    16 kHz: 52 = five pieces of 12 weights; 20 bins: 58; 16 bins: 67 = six) and the kernel added four piece sums per
+    filter at most.  Every piece is summed now; the matrix must equal the oracle twin's bit for bit."""
+    e = Engine(0)
+    try:
+        e.set_frontend(mfcc_f32=1, num_mel_bins=bins, num_ceps=ceps)
+        cfg32 = oracle.default_cfg(mfcc_f32=1, num_mel_bins=bins, num_ceps=ceps)
+        rng = np.random.default_rng(bins)
+        for w in [_wav(0), _wav(1, 16000), (rng.normal(size=30000) * 4000).astype(np.int16),
+                  rng.integers(-32768, 32767, size=12345).astype(np.int16), _wav(3, 400)]:
+            mg = e.debug_mfcc(w)
+            mo = oracle.mfcc(cfg32, w)
+            assert mg.shape == mo.shape
+            same = mg.view(np.uint32) == mo.view(np.uint32)
+            zero = (mg == 0.0) & (mo == 0.0)
+            assert np.all(same | zero), (bins, w.size, int((~(same | zero)).sum()), np.abs(mg - mo).max())
+    finally:
+        e.close()
+
+
+def test_mfcc_f32_refuses_filters_wider_than_it_sums():
+    """8 mel bins over 20 - 8000 Hz: filters of more than 72 FFT bins (> 6 pieces) -- the float32 mode must be refused
+    (the drop-in classes then fall back to the float64 kernel), never computed with pieces dropped."""
+    from fakebob_amd._native import NativeError
+    e = Engine(0)
+    try:
+        with pytest.raises(NativeError):
+            e.set_frontend(mfcc_f32=1, num_mel_bins=8, num_ceps=8)
+        assert e.cfg.mfcc_f32 == 0 and e.cfg.num_mel_bins != 8      # the mirror kept the previous configuration
+        e.set_frontend(num_mel_bins=8, num_ceps=8)                  # the float64 kernel takes it
+    finally:
+        e.close()
