@@ -206,10 +206,59 @@ def timed_region(args, torch, dist, workers, K, after_window=None):
     return dts
 
 
+def windows_fields(dts):
+    """the timed windows in the forms a record keeps: the list, a short string (a parser that drops lists keeps it), min / max"""
+    ms = [1e3 * x for x in dts]
+    return {"repeats": len(ms), "windows_ms": ms, "windows_ms_str": " ".join("%.3f" % x for x in ms),
+            "windows_ms_min": min(ms), "windows_ms_max": max(ms)}
+
+
 def median(xs):
     ys = sorted(xs)
     n = len(ys)
     return ys[n // 2] if n % 2 else 0.5 * (ys[n // 2 - 1] + ys[n // 2])
+
+
+def iv_rooflines(B, n_active, con_ms, solve_ms, R=400):
+    """(contraction, solve) roofline objects of an i-vector NES batch of B utterances: the T-matrix contraction against
+    HBM (and its float64-MFMA utilisation), the posterior solve against the float64 MFMA peak."""
+    tri = R * (R + 1) // 2
+    n_bgroups = (B + 63) // 64                                          # utterance groups of 64 -> passes over the rows
+    # ALGORITHMIC bytes of the T-matrix contraction: the float64 rows of Sigma^-1 M and U of every component with
+    # posterior mass, read once per launch pair -- Kaldi's own loop skips gamma == 0 components
+    # (IvectorExtractor::GetIvectorDistMean/Prior, SURVEY.md A.9); the kernels stream exactly these rows once per
+    # 64-utterance group
+    bytes_alg = 8.0 * n_active * (D_FEAT * R + tri)
+    bytes_all = 8.0 * (C_GAUSS * D_FEAT * R + C_GAUSS * tri)
+    bytes_exec = bytes_alg * n_bgroups
+    flops_alg = 2.0 * B * n_active * (D_FEAT * R + tri)
+    flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * R + tri)   # 64-row MFMA tiles
+    gbps = bytes_alg / (con_ms * 1e-3) / 1e9 if con_ms else 0.0
+    contraction = {"kernel": "k_iv_contract_both = k_iv_contract_dma<lin> + <quad> in one launch (T-matrix contraction: LDS-DMA ring, float64 MFMA "
+                             "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
+                   "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                   "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
+                   "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
+                   "executed_gbps": bytes_exec / (con_ms * 1e-3) / 1e9 if con_ms else 0.0,
+                   "all_components_bytes": bytes_all,
+                   "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
+                           "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the "
+                           "contraction launch, HIP events on the attack's stream (with several attacks in flight "
+                           "it includes time shared with other attacks' kernels)",
+                   "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
+                                "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12 if con_ms else 0.0,
+                                "peak_tflops": PEAK_F64_MFMA_TFLOPS,
+                                "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS if con_ms else 0.0}}
+    # the posterior solve: B Cholesky factorisations + two triangular solves of R x R (SURVEY.md 8(d): R^3/3 + 2 R^2
+    # flops per utterance) on the float64 matrix cores
+    solve_flops = B * (R ** 3 / 3.0 + 2.0 * R * R)
+    solve_tf = solve_flops / (solve_ms * 1e-3) / 1e12 if solve_ms else 0.0
+    solve = {"kernel": "k_iv_solve_rw / k_iv_solve_ll (batched blocked Cholesky + substitutions of the R x R posterior "
+                       "precision, v_mfma_f64_16x16x4; the launch includes the back-end and the loss body)", "bound": "mfma", "achieved": solve_tf,
+             "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": solve_tf / PEAK_F64_MFMA_TFLOPS,
+             "traffic": None, "avg_launch_ms": solve_ms, "algorithmic_flops_per_launch": solve_flops,
+             "note": "HIP events around every launch of an extra one-attack pass of the same step count"}
+    return contraction, solve
 
 
 def bench_ivector(args, torch):
@@ -276,52 +325,19 @@ def bench_ivector(args, torch):
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
         solve_ms = r1[1] / args.steps
+        if os.environ.get("FB_BENCH_VERBOSE"):
+            print("bench.py: one-attack pass %.3f ms/step (solve launches %.3f ms)" % (1e3 * d1 / args.steps, solve_ms), file=sys.stderr)
         if K > 1 and not args.no_single:
             single = {"value": args.steps / d1, "unit": "NES iterations/s", "ms_per_step": 1e3 * d1 / args.steps,
                       "note": "one attack in flight (a single launch chain), same workload"}
     workers.close()
     if rank == 0:
-        R = 400
-        tri = R * (R + 1) // 2
         n_active = eng.debug_iv_active()
-        n_bgroups = (B + 63) // 64                                          # utterance groups of 64 -> passes over the rows
-        # ALGORITHMIC bytes of the T-matrix contraction: the float64 rows of Sigma^-1 M and U of every component with
-        # posterior mass, read once per launch pair -- Kaldi's own loop skips gamma == 0 components
-        # (IvectorExtractor::GetIvectorDistMean/Prior); the kernels stream exactly these rows once per
-        # 64-utterance group
-        bytes_alg = 8.0 * n_active * (D_FEAT * R + tri)
-        bytes_all = 8.0 * (C_GAUSS * D_FEAT * R + C_GAUSS * tri)
-        bytes_exec = bytes_alg * n_bgroups
-        flops_alg = 2.0 * B * n_active * (D_FEAT * R + tri)
-        flops_exec = 2.0 * 64 * n_bgroups * n_active * (D_FEAT * R + tri)   # 64-row MFMA tiles
         con_ms = ms_con / args.steps
-        gbps = bytes_alg / (con_ms * 1e-3) / 1e9
-        contraction = {"kernel": "k_iv_contract_both = k_iv_contract_dma<lin> + <quad> in one launch (T-matrix contraction: LDS-DMA ring, float64 MFMA "
-                                 "v_mfma_f64_16x16x4, rows of components with posterior mass only)", "bound": "hbm",
-                       "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                       "traffic": None, "avg_launch_ms": con_ms, "algorithmic_bytes_per_launch": bytes_alg,
-                       "active_components": n_active, "executed_bytes_per_launch": bytes_exec,
-                       "all_components_bytes": bytes_all,
-                       "note": "algorithmic bytes = float64 rows of Sigma^-1 M and U of the components with posterior "
-                               "mass (the reference's Kaldi loop skips gamma == 0 components too); launch time = the "
-                               "contraction launch, HIP events on the attack's stream (with several attacks in flight "
-                               "it includes time shared with other attacks' kernels)",
-                       "mfma_f64": {"algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": flops_exec,
-                                    "executed_tflops": flops_exec / (con_ms * 1e-3) / 1e12,
-                                    "peak_tflops": PEAK_F64_MFMA_TFLOPS,
-                                    "frac": flops_exec / (con_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+        contraction, solve = iv_rooflines(B, n_active, con_ms, solve_ms)
         tr, prov = committed_traffic("k_iv_contract_dma<lin>+<quad>")   # HBM bytes per launch (both kernels), PMC passes
         contraction["traffic"] = tr
         contraction.update(prov)
-        # k_iv_solve_ll: B Cholesky factorisations + two triangular solves of R x R (R^3/3 + 2 R^2
-        # flops per utterance) on the float64 matrix cores
-        solve_flops = B * (R ** 3 / 3.0 + 2.0 * R * R)
-        solve_tf = solve_flops / (solve_ms * 1e-3) / 1e12 if solve_ms else 0.0
-        solve = {"kernel": "k_iv_solve_ll (batched left-looking blocked Cholesky + substitutions of the R x R posterior "
-                           "precision, v_mfma_f64_16x16x4)", "bound": "mfma", "achieved": solve_tf,
-                 "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": solve_tf / PEAK_F64_MFMA_TFLOPS,
-                 "traffic": None, "avg_launch_ms": solve_ms, "algorithmic_flops_per_launch": solve_flops,
-                 "note": "HIP events around every launch of an extra one-attack pass of the same step count"}
         dominant = solve if (solve_ms or 0.0) >= con_ms else contraction
         out = {"metric": "NES iterations/sec (i-vector-PLDA %s, samples_per_draw=%d, 3 s@16 kHz)" % (task, spd), "value": its,
                "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -334,7 +350,7 @@ def bench_ivector(args, torch):
                                       % (task, n_spk, spd, B, K), "attacks_in_flight_per_gpu": K,
                           "voiced_rows_per_iter": rows, "model_load_s": t_load,
                           "launch_chain": "fused" if fused else "unfused",
-                          "repeats": len(dts), "windows_ms": [1e3 * x for x in dts],
+                          **windows_fields(dts),
                           "timing": "median of `repeats` consecutive windows of `steps` steps each"},
                "roofline": dominant, "roofline_contraction": contraction, "roofline_solve": solve}
         if world == 1 and not args.no_cpu_baseline:
@@ -654,7 +670,7 @@ def main():
                        "frontend_precision": {"f32": "float32 MFCC (Kaldi's BaseFloat; C0 from the exact integer energy), float64 "
                                                      "deltas / CMVN sums", "f64": "float64 between Kaldi's float32 storage points"}[args.frontend],
                        "attacks_in_flight_per_gpu": K, "precondition_steps": max(2, args.precondition),
-                       "repeats": len(dts), "windows_ms": [1e3 * x for x in dts],
+                       **windows_fields(dts),
                        "timing": "value / ms_per_step: the MEDIAN of `repeats` consecutive windows of exactly `steps` steps, each "
                                  "between (barrier + device synchronize) pairs and max over ranks; windows_ms lists them all",
                        "launch_chain": "4 launches per iteration (fused)" if fused else "6 launches per iteration (mfcc; vad + deltas + cmvn; gmm; finalize; loss; update + next batch)",
@@ -883,7 +899,16 @@ def secondary_ivector(torch, dev_index, K, mfcc_f32=1):
                          [synthetic_audio(k, N_SAMPLES) for k in range(K)])
         try:
             r = quick_measure(torch, aset, steps, 4, chain_fused=(K < 3), time_kernel=2)
-            r["kernel_timed"] = "k_iv_solve_ll"
+            r["kernel_timed"] = "the posterior solve launch (k_iv_solve_rw / k_iv_solve_ll + back-end + loss)"
+            torch.cuda.synchronize()
+            rc = engs[0].bench_nes(aset.prms[0], aset.auds[0], -1, steps, time_gmm=1)   # one attack: the contraction's launches
+            torch.cuda.synchronize()
+            con, sol = iv_rooflines(2 * (spd // 2) + 1, engs[0].debug_iv_active(), rc[1] / steps, r["single_attack"]["kernel_launch_ms"])
+            r["roofline"] = {"solve": {k_: sol[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                             "contraction": dict({k_: con[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                                         "executed_gbps", "active_components")},
+                                                 mfma_f64_frac=con["mfma_f64"]["frac"]),
+                             "note": "one attack in flight, HIP events around each launch (bench.iv_rooflines; --arch iv is the full line)"}
             r["note"] = "i-vector-PLDA %s, %d enrolled, spd=%d (%d utterances per NES batch), C=2048, R=400" % (task, n_spk, spd, 2 * (spd // 2) + 1)
             sec[name] = r
         finally:

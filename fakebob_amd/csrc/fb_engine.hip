@@ -102,7 +102,8 @@ struct fb_engine {
   int iv_A_B = -1;    // batch size the zero row behind iv_A was laid out for
   DevBuf iv_prog, iv_ticket;  // k_iv_solve_rw: progress words, ticket
   DevBuf iv_tail_counter;     // arrivals of the solve kernels' fused tail (fb_iv_tail.h)
-  DevBuf gs_max, gs_tau, gs_list, gs_cnt, gs_flag;  // fb_launch_gsel's workspace (group maxima, thresholds, survivor lists, overflow flag)
+  DevBuf gs_max, gs_tau, gs_list, gs_cnt, gs_flag, gs_gid;  // fb_launch_gsel's workspace (group maxima, thresholds, survivor lists, overflow flag; wide form: group ids)
+  int gs_last_chunks = 0, gs_last_path = 0;  // the last i-vector batch: chunk count of the selection kernels, 0 dump / 1 k_gmm_fx2_sel / 2 k_gsel_w
   bool tail_loss_req = false, tail_loss_done = false;  // enqueue_get_grad asks run_scoring to take the loss body along / it did
   FbIvTail tail_req = {};
   unsigned iv_rw_epoch = 0;
@@ -246,7 +247,7 @@ extern "C" int fb_engine_destroy(fb_engine *e) {
                     &e->part_m, &e->part_s, &e->raw, &e->audio, &e->adver, &e->grad_m, &e->grad, &e->noise, &e->zbuf,
                     &e->scores, &e->loss, &e->dist_part, &e->nes_out, &e->stage_f64, &e->ext_x, &e->ext_z, &e->iv_fg, &e->iv_fg64, &e->iv_fgL, &e->iv_tri,
                     &e->iv_sim, &e->iv_u, &e->iv_backend, &e->iv_ll, &e->iv_sel, &e->iv_post, &e->iv_gamma,
-                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->gs_max, &e->gs_tau, &e->gs_list, &e->gs_cnt, &e->gs_flag, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
+                    &e->iv_X, &e->iv_linp, &e->iv_quad, &e->iv_A, &e->iv_linv, &e->iv_prog, &e->iv_ticket, &e->iv_tail_counter, &e->gs_max, &e->gs_tau, &e->gs_list, &e->gs_cnt, &e->gs_flag, &e->gs_gid, &e->iv_bws, &e->iv_pairs, &e->iv_llf, &e->iv_ivec, &e->iv_fail, &e->iv_active};
   for (DevBuf *b : bufs) b->release();
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->h_tv) (void)hipHostFree(e->h_tv);
@@ -1350,29 +1351,49 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     const int *sel_gate = nullptr;
     FbGmmDev gd = g;
     const int sel_chunks = fb_gsel_chunks(n_chunks);
-    if (fb_gsel_applies(g, iv.nsel, sel_chunks)) {
-      const int cap = fb_gsel_cap(sel_chunks);
+    const int wide_chunks = fb_gsel_wide_chunks(g, iv.nsel, total_frames);
+    e->gs_last_path = 0;
+    e->gs_last_chunks = 0;
+    if (!e->gs_flag.p && (wide_chunks > 0 || fb_gsel_applies(g, iv.nsel, sel_chunks))) {
+      FBCHK(e->gs_flag.ensure(sizeof(int)));
+      HIPCHK(hipMemsetAsync(e->gs_flag.p, 0, sizeof(int), s));
+    }
+    if (wide_chunks > 0) {
+      // k_gsel_w (gmm_wide_kernel.hip): the records of pass B go where the dump's values would (rows x C floats, sparsely
+      // written); nothing can overflow, so neither the dump nor k_iv_select is launched at all
       FBCHK(e->gs_max.ensure(sizeof(float) * (size_t)total_frames * 2 * g.n_tiles));
       FBCHK(e->gs_tau.ensure(sizeof(float) * (size_t)total_frames));
-      FBCHK(e->gs_list.ensure(sizeof(unsigned long long) * (size_t)total_frames * sel_chunks * cap));
-      FBCHK(e->gs_cnt.ensure(sizeof(int) * (size_t)total_frames * sel_chunks));
-      if (!e->gs_flag.p) {
-        FBCHK(e->gs_flag.ensure(sizeof(int)));
-        HIPCHK(hipMemsetAsync(e->gs_flag.p, 0, sizeof(int), s));
+      FBCHK(e->gs_cnt.ensure(sizeof(int) * (size_t)total_frames * wide_chunks));
+      FBCHK(e->gs_gid.ensure((size_t)total_frames * 2 * g.n_tiles));
+      fb_launch_gsel_wide(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, wide_chunks, iv.nsel, e->gs_max.as<float>(),
+                          e->gs_tau.as<float>(), e->iv_ll.as<float>(), e->gs_gid.as<unsigned char>(), e->gs_cnt.as<int>(),
+                          e->gs_flag.as<int>(), e->iv_sel.as<int>());
+      FB_DBG_SYNC(e, "gsel_wide");
+      e->gs_last_path = 2;
+      e->gs_last_chunks = wide_chunks;
+    } else {
+      if (fb_gsel_applies(g, iv.nsel, sel_chunks)) {
+        const int cap = fb_gsel_cap(sel_chunks);
+        FBCHK(e->gs_max.ensure(sizeof(float) * (size_t)total_frames * 2 * g.n_tiles));
+        FBCHK(e->gs_tau.ensure(sizeof(float) * (size_t)total_frames));
+        FBCHK(e->gs_list.ensure(sizeof(unsigned long long) * (size_t)total_frames * sel_chunks * cap));
+        FBCHK(e->gs_cnt.ensure(sizeof(int) * (size_t)total_frames * sel_chunks));
+        fb_launch_gsel(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, sel_chunks, iv.nsel, e->gs_max.as<float>(),
+                       e->gs_tau.as<float>(), e->gs_list.as<unsigned long long>(), e->gs_cnt.as<int>(), e->gs_flag.as<int>(),
+                       e->iv_sel.as<int>());
+        FB_DBG_SYNC(e, "gsel");
+        sel_gate = e->gs_flag.as<int>();
+        gd.only_if = sel_gate;
+        e->gs_last_path = 1;
+        e->gs_last_chunks = sel_chunks;
       }
-      fb_launch_gsel(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, sel_chunks, iv.nsel, e->gs_max.as<float>(),
-                     e->gs_tau.as<float>(), e->gs_list.as<unsigned long long>(), e->gs_cnt.as<int>(), e->gs_flag.as<int>(),
-                     e->iv_sel.as<int>());
-      FB_DBG_SYNC(e, "gsel");
-      sel_gate = e->gs_flag.as<int>();
-      gd.only_if = sel_gate;
+      fb_launch_gmm_dump(s, gd, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
+                         e->iv_ll.as<float>());
+      FB_DBG_SYNC(e, "gmm_dump");
     }
-    fb_launch_gmm_dump(s, gd, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
-                       e->iv_ll.as<float>());
-    FB_DBG_SYNC(e, "gmm_dump");
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
-                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), sel_gate);
+                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), sel_gate, wide_chunks == 0);
     FB_DBG_SYNC(e, "select_post");
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());
@@ -1817,8 +1838,10 @@ extern "C" int fb_debug_iv_active(fb_engine *e, int *n_active) {
 }
 
 // gmm-gselect of the last i-vector batch: sel[rows][nsel] (rows = the batch's voiced frames), and what the threshold path
-// did: info[0] = 1 when fb_launch_gsel ran (0: the dump + k_iv_select path), info[1] = its overflow flag (1: the rescue
-// launches redid the batch), info[2] = most survivors in one (row, chunk) list, info[3] = total survivors, info[4] = rows
+// did: info[0] = 2 when fb_launch_gsel_wide ran (k_gsel_w), 1 when fb_launch_gsel did (k_gmm_fx2_sel), 0: the dump +
+// k_iv_select path; info[1] = the flag (path 1: a list overflowed and the rescue launches redid the batch); info[2] = most
+// entries in one (row, chunk) list, info[3] = entries in total (path 1: survivors; path 2: 16-value records of the groups that
+// reach the threshold), info[4] = rows
 extern "C" int fb_debug_iv_gselect(fb_engine *e, int *sel, int64_t sel_cap, int64_t *info) {
   if (!e || !info) return fb_fail(FB_E_ARG, "bad argument");
   if (e->kind != 1 || e->last_B <= 0) return fb_fail(FB_E_STATE, "score a batch with an i-vector system first");
@@ -1831,8 +1854,8 @@ extern "C" int fb_debug_iv_gselect(fb_engine *e, int *sel, int64_t sel_cap, int6
     if (sel_cap < (int64_t)rows * nsel) return fb_fail(FB_E_ARG, "sel holds %lld ints, the batch needs %lld", (long long)sel_cap, (long long)rows * nsel);
     HIPCHK(hipMemcpy(sel, e->iv_sel.p, sizeof(int) * (size_t)rows * nsel, hipMemcpyDeviceToHost));
   }
-  const int n_chunks = fb_gsel_chunks(choose_chunks(e->gmm, e->last_total_frames, false));
-  info[0] = fb_gsel_applies(e->gmm, nsel, n_chunks) ? 1 : 0;
+  const int n_chunks = e->gs_last_chunks;
+  info[0] = e->gs_last_path;   // 0: dump + k_iv_select, 1: k_gmm_fx2_sel (lists of survivors), 2: k_gsel_w (records of groups)
   info[1] = info[2] = info[3] = 0;
   info[4] = rows;
   if (info[0]) {

@@ -249,6 +249,12 @@ int fb_gsel_cap(int n_chunks);
 int fb_gsel_chunks(int dump_chunks);   // the selection kernels' own chunk count (a power of two <= 8)
 void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
                     int nsel, float *gmax, float *tau, unsigned long long *glist, int *gcnt, int *flag, int *sel);
+// the wide form (k_gsel_w / k_gsel_final_w): fb_gsel_wide_chunks() > 0 = it applies, with that many component chunks.  gval:
+// rows_cap x 32 n_tiles floats (the dump's buffer serves), gid: rows_cap x 2 n_tiles bytes, gcnt: rows_cap x n_chunks ints.
+// No overflow and no rescue: sel[] is final (flag is raised by NaN features only).
+int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap);
+void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
+                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel);
 // k_gmm_finalize + k_loss fused (GMM systems in the NES loop): counter = one int, zero before the first launch
 void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                                  int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
@@ -321,7 +327,7 @@ size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap);
 // selection; the gate is its overflow flag)
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, const int *sel_gate = nullptr);
+                              int *pairs, float *llf, const int *sel_gate = nullptr, bool run_select = true);
 // gammaT [C][Bpad], XT [C*D][Bpad]: utterance-minor, zero-padded to Bpad (multiple of 32)
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);

@@ -326,62 +326,7 @@ __device__ __forceinline__ void fb_fx_step(const u32x4 *__restrict__ cur4, int l
   if constexpr (ISQ) hq = hi; else pv = hi;
 }
 
-// The frame operands of a lane of k_gmm_fx2 / k_gmm_fx2_sel (see the comment in k_gmm_fx2): chunk c = dims 16c + 8h + i,
-// two-term f16 splits of x (1.0 at position D) and x^2 under the load-time powers of two; returns the wave's range shift.
-template <int NK>
-__device__ __forceinline__ int fb_fx_frame_frags(const FbGmmDev &g, const float *__restrict__ feats, int row, int n_rows, int h,
-                                                 u32x4 (&bx1)[NK], u32x4 (&bx2)[NK], u32x4 (&bq1)[NK], u32x4 (&bq2)[NK]) {
-  int sh = 0;
-  {
-    const bool ok = row < n_rows;
-    const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
-    const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);  // exact power-of-two operand scalings
-    float vv[NK][8], qq[NK][8];
-    float amax = xs;
-#pragma unroll
-    for (int c = 0; c < NK; ++c) {
-      const int d0 = 16 * c + 8 * h;
-      float *v = vv[c], *q = qq[c];
-      if ((g.D & 3) == 0) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int d = d0 + 4 * u;
-          const float4 t = *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
-          const bool in = ok && d < g.D;
-          v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
-          v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fmaxf(fabsf(v[i]), q[i]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (amax >= 32768.0f) {  // wave-uniform; finite features only (the front-end produces nothing else)
-      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;  // amax in [2^ex, 2^(ex+1))
-      sh = min(ex - 14, 100);
-    }
-    const float down = fb_pow2f(-sh);
-#pragma unroll
-    for (int c = 0; c < NK; ++c) {
-      if (sh) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { vv[c][i] = __fmul_rn(vv[c][i], down); qq[c][i] = __fmul_rn(qq[c][i], down); }
-      }
-      fb_split2_frag(vv[c], bx1[c], bx2[c]);
-      fb_split2_frag(qq[c], bq1[c], bq2[c]);
-    }
-  }
-  return sh;
-}
-
+// (fb_fx_frame_frags -- the frame operands of a lane -- lives in gmm_split.h: k_gsel_w of gmm_wide_kernel.hip shares it)
 template <int NK, bool DUMP>
 __global__ __launch_bounds__(256, FB_FX_OCC) void k_gmm_fx2(FbGmmDev g, const float *__restrict__ feats,
                                                     const int *__restrict__ n_rows_ptr, int tiles_per_chunk,
@@ -796,6 +741,140 @@ void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const 
     case 6: launch_gsel_t<6>(s, g, feats, n_rows_ptr, rows_cap, n_chunks, nsel, gmax, tau, glist, gcnt, flag, sel); break;
     default: break;
   }
+}
+
+
+// ---- the wide form (k_gsel_w, gmm_wide_kernel.hip): pass A -> k_gsel_tau -> pass B -> k_gsel_final_w.  Pass B leaves, per
+// (row, chunk), the 16-value records of the groups whose maximum reaches tau -- every group has a place, nothing overflows,
+// so no rescue launches follow.  The final kernel ranks the values >= tau of a row's records (16 lanes per frame, 16 frames
+// per workgroup); the keys are (ordered value bits, component index) as in k_gsel_final, in the accumulators' own scale.
+bool fb_gsel_w_applies(const FbGmmDev &g, int n_chunks);   // gmm_wide_kernel.hip
+void fb_launch_gsel_w(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks, int pick,
+                      float *gmax, const float *tau, float *gval, unsigned char *gid, int *gcnt, int tiles_a);
+int fb_gsel_w_tiles_a(const FbGmmDev &g, int n_chunks, int nsel);
+int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap) {
+  if (getenv("FB_IV_GSEL_DUMP") != nullptr) return 0;
+  if (!(g.mode == FB_GMM_MODE_FX2 && g.M == 1 && g.n_items == 2 && 2 * g.n_tiles >= 4 * nsel && 2 * g.n_tiles <= 256 && nsel <= 32)) return 0;
+  const int strips = (rows_cap + 255) / 256;
+  int want = 256 / (strips > 0 ? strips : 1);
+  int n = 8;
+  while (n > 1 && (n > want || !fb_gsel_w_applies(g, n))) n >>= 1;
+  return fb_gsel_w_applies(g, n) ? n : 0;
+}
+__global__ __launch_bounds__(256) void k_gsel_final_w(const float *__restrict__ gval, const unsigned char *__restrict__ gid,
+                                                     const int *__restrict__ gcnt, const float *__restrict__ tau, int n_chunks, int tpc,
+                                                     const int *__restrict__ n_rows_ptr, int nsel, int C, int *__restrict__ sel,
+                                                     int *__restrict__ flag) {
+  __shared__ unsigned long long s_key[16][FB_GSEL_MAXC];
+  __shared__ int s_n[16];
+  const int n_rows = *n_rows_ptr;
+  const int l = threadIdx.x & 15, rw = threadIdx.x >> 4, row = blockIdx.x * 16 + rw;
+  if (row >= n_rows) return;   // (no workgroup barrier below: a frame's 16 lanes sit in one wave)
+  const int capc = 2 * tpc;
+  if (l == 0) s_n[rw] = 0;
+  const float t = tau[row];
+  int pre[9];   // records of the chunks before chunk k (n_chunks <= 8)
+  pre[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pre[k + 1] = pre[k] + (k < n_chunks ? min(gcnt[(size_t)row * n_chunks + k], capc) : 0);
+  const int total = pre[8];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // record e of the row: (chunk, index in the chunk) -> its 16 values and the component of value 0
+  auto record = [&](int e, const float4 *&src, int &cbase) {
+    int k = 0, first = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+      if (e >= pre[q]) { k = q; first = pre[q]; }
+    const size_t at = ((size_t)row * n_chunks + k) * capc + (e - first);
+    const int gl = gid[at];
+    src = reinterpret_cast<const float4 *>(gval) + at * 4;
+    cbase = (k * tpc + (gl >> 1)) * 32 + 4 * (gl & 1);   // value r = component cbase + (r & 3) + 8 (r >> 2)
+  };
+  // four records per lane at a time: their ids first, then all their values in flight together; a lane reserves the places of
+  // its values >= tau with ONE addition to the row's counter
+  for (int e0 = 0; e0 < total; e0 += 64) {
+    const float4 *src[4]; int cbase[4]; bool have[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + l + 16 * q;
+      have[q] = e < total;
+      record(have[q] ? e : 0, src[q], cbase[q]);
+    }
+    float4 f[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f[q][u] = src[q][u];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        mine += have[q] ? ((f[q][u].x >= t ? 1 : 0) + (f[q][u].y >= t ? 1 : 0) + (f[q][u].z >= t ? 1 : 0) + (f[q][u].w >= t ? 1 : 0)) : 0;
+    int pos = mine > 0 ? atomicAdd(&s_n[rw], mine) : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v4[4] = {f[q][u].x, f[q][u].y, f[q][u].z, f[q][u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (have[q] && v4[i] >= t) {   // value r = 4 u + i = component cbase + (r & 3) + 8 (r >> 2)
+            if (pos < FB_GSEL_MAXC) s_key[rw][pos] = ((unsigned long long)fb_f32_ordered(v4[i]) << 32) | (unsigned)(cbase[q] + i + 8 * u);
+            ++pos;
+          }
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int n = s_n[rw];
+  if (n < min(nsel, C)) { if (l == 0) atomicOr(flag, 1); }   // (NaN features only: tau is the nsel-th largest group maximum)
+  if (n <= FB_GSEL_MAXC) {
+    for (int i = l; i < n; i += 16) {
+      const unsigned long long my = s_key[rw][i];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) rank += s_key[rw][q] > my ? 1 : 0;
+      if (rank < nsel) sel[(size_t)row * nsel + rank] = (int)(unsigned)(my & 0xffffffffull);
+    }
+  } else {
+    // more values at or above tau than the key list holds (ties by the hundred: degenerate models, constant features): rank
+    // straight from the records -- quadratic in their number, never taken on speech
+    for (int i = l; i < total * 16; i += 16) {
+      const float4 *src; int cbase;
+      record(i >> 4, src, cbase);
+      const int r = i & 15;
+      const float vi = reinterpret_cast<const float *>(src)[r];
+      if (!(vi >= t)) continue;
+      const unsigned long long my = ((unsigned long long)fb_f32_ordered(vi) << 32) | (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
+      int rank = 0;
+      for (int q = 0; q < total * 16 && rank < nsel; ++q) {
+        const float4 *s2; int cb2;
+        record(q >> 4, s2, cb2);
+        const int r2 = q & 15;
+        const float vq = reinterpret_cast<const float *>(s2)[r2];
+        const unsigned long long kq = ((unsigned long long)fb_f32_ordered(vq) << 32) | (unsigned)(cb2 + (r2 & 3) + 8 * (r2 >> 2));
+        rank += kq > my ? 1 : 0;
+      }
+      if (rank < nsel) sel[(size_t)row * nsel + rank] = (int)(unsigned)(my & 0xffffffffull);
+    }
+  }
+  for (int s2 = n + l; s2 < nsel; s2 += 16) sel[(size_t)row * nsel + s2] = s2 % C;   // (NaN features: any valid index)
+}
+void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
+                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel) {
+  if (rows_cap <= 0) return;
+  const int tiles_a = fb_gsel_w_tiles_a(g, n_chunks, nsel);
+  const int NG = 2 * n_chunks * tiles_a, tb = (rows_cap + 15) / 16;
+  fb_launch_gsel_w(s, g, feats, n_rows_ptr, rows_cap, n_chunks, 0, gmax, nullptr, nullptr, nullptr, nullptr, tiles_a);
+  if (NG <= 64) hipLaunchKernelGGL(k_gsel_tau<4>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  else if (NG <= 128) hipLaunchKernelGGL(k_gsel_tau<8>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  else hipLaunchKernelGGL(k_gsel_tau<16>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
+  fb_launch_gsel_w(s, g, feats, n_rows_ptr, rows_cap, n_chunks, 1, nullptr, tau, gval, gid, gcnt, tiles_a);
+  hipLaunchKernelGGL(k_gsel_final_w, dim3(tb), dim3(256), 0, s, gval, gid, gcnt, tau, n_chunks, g.n_tiles / n_chunks, n_rows_ptr, nsel, g.C, sel,
+                     flag);
 }
 
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,

@@ -2,6 +2,7 @@
 // two-term f16 split of f32 operands and the online logsumexp in the log2 domain.
 #pragma once
 #include "fb_device.h"
+#include "fb_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -26,6 +27,79 @@ __device__ __forceinline__ void fb_split2_frag(const float (&v)[8], u32x4 &f1, u
     f1[i] = a;
     f2[i] = b;
   }
+}
+
+// The frame operands of a lane of k_gmm_fx2 / k_gmm_fx2_sel / k_gsel_w (see the comment in k_gmm_fx2, gmm_kernels.hip): chunk c = dims 16c + 8h + i,
+// two-term f16 splits of x (1.0 at position D) and x^2 under the load-time powers of two; returns the wave's range shift.
+// (two steps, so that a kernel with several frames per lane can have every row's loads in flight before the first is used:
+//  fb_fx_frame_load -- D a multiple of 4 -- and fb_fx_frame_make; fb_fx_frame_frags is both for one frame, any D)
+template <int NK>
+__device__ __forceinline__ void fb_fx_frame_load(const FbGmmDev &g, const float *__restrict__ feats, int row, int n_rows, int h,
+                                                 float4 (&ft)[NK][2]) {
+  const float *fr = feats + (size_t)(row < n_rows ? row : 0) * g.D;
+#pragma unroll
+  for (int c = 0; c < NK; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) ft[c][u] = *reinterpret_cast<const float4 *>(fr + min(16 * c + 8 * h + 4 * u, g.D - 4));
+}
+template <int NK, bool PRELOADED>
+__device__ __forceinline__ int fb_fx_frame_make(const FbGmmDev &g, const float *__restrict__ feats, const float4 (&ft)[NK][2], int row,
+                                                int n_rows, int h, u32x4 (&bx1)[NK], u32x4 (&bx2)[NK], u32x4 (&bq1)[NK], u32x4 (&bq2)[NK]) {
+  int sh = 0;
+  {
+    const bool ok = row < n_rows;
+    const float *fr = feats + (size_t)(ok ? row : 0) * g.D;
+    const float qs = fb_pow2f(g.kx2), xs = fb_pow2f(g.kx);  // exact power-of-two operand scalings
+    float vv[NK][8], qq[NK][8];
+    float amax = xs;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      const int d0 = 16 * c + 8 * h;
+      float *v = vv[c], *q = qq[c];
+      if (PRELOADED || (g.D & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d = d0 + 4 * u;
+          const float4 t = PRELOADED ? ft[c][u] : *reinterpret_cast<const float4 *>(fr + min(d, g.D - 4));
+          const bool in = ok && d < g.D;
+          v[4 * u + 0] = in ? t.x : 0.0f; v[4 * u + 1] = in ? t.y : 0.0f;
+          v[4 * u + 2] = in ? t.z : 0.0f; v[4 * u + 3] = in ? t.w : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (ok && d0 + i < g.D) ? fr[min(d0 + i, g.D - 1)] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __fmul_rn(__fmul_rn(v[i], v[i]), qs);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (d0 + i == g.D) ? xs : __fmul_rn(v[i], xs);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fmaxf(fabsf(v[i]), q[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (amax >= 32768.0f) {  // wave-uniform; finite features only (the front-end produces nothing else)
+      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;  // amax in [2^ex, 2^(ex+1))
+      sh = min(ex - 14, 100);
+    }
+    const float down = fb_pow2f(-sh);
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      if (sh) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { vv[c][i] = __fmul_rn(vv[c][i], down); qq[c][i] = __fmul_rn(qq[c][i], down); }
+      }
+      fb_split2_frag(vv[c], bx1[c], bx2[c]);
+      fb_split2_frag(qq[c], bq1[c], bq2[c]);
+    }
+  }
+  return sh;
+}
+template <int NK>
+__device__ __forceinline__ int fb_fx_frame_frags(const FbGmmDev &g, const float *__restrict__ feats, int row, int n_rows, int h,
+                                                 u32x4 (&bx1)[NK], u32x4 (&bx2)[NK], u32x4 (&bq1)[NK], u32x4 (&bq2)[NK]) {
+  float4 none[NK][2];
+  return fb_fx_frame_make<NK, false>(g, feats, none, row, n_rows, h, bx1, bx2, bq1, bq2);
 }
 
 #define FB_FX_MFMA(A, B, ACC) \

@@ -934,6 +934,249 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   FXW_STAMP(7);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_gsel_w: the matrix-core passes of the threshold gselect (gmm_kernels.hip, above fb_launch_gsel; round 6) in this file's
+// form -- one wave per SIMD, 64 frames per wave as two independent 32-frame chains that share every parameter fragment,
+// the parameter items by LDS-DMA into two slots of TS = 2 tiles each (one workgroup barrier per two tiles), the frame
+// operands' second terms parked in accumulation registers.  k_gmm_fx2_sel (four waves of 32 frames, a barrier and a pass
+// through staging registers per item) took 39 + 43 us for the two passes at configs[2] size against ~16 us of MFMA time
+// each.  The MFMAs of a half run on the same operands in the same order as fb_fx_step's (a2 b1, a1 b2, a1 b1 per K chunk, the
+// base item continuing the quadratic one's accumulator), so a value has the bits the dump would have stored -- in the
+// accumulators' own scale: a frame's values all carry the same power of two 2^(kacc - sh), which no maximum, comparison or
+// ranking cares about, so nothing is un-scaled anywhere.
+//   PICK = false  pass A: a lane's maximum of its 16 values -> gmax[row][2 n_tiles] (through LDS, whole 128-byte runs)
+//   PICK = true   pass B: a lane whose maximum reaches tau(row) stores its 16 values as one 64-byte record
+//                 gval[((row n_chunks + chunk) capc + k) 16 ..], k from the row's counter in LDS, and the group's id
+//                 (2 tile_in_chunk + h) beside it; capc = 2 tiles_per_chunk records per (row, chunk): every group fits, there
+//                 is no overflow and no rescue.  k_gsel_final_w ranks the values >= tau of those records.
+// Shapes: NK = 5 (D = 72), C a multiple of 32, tiles per chunk a multiple of 4 and at most 128; everything else stays on
+// k_gmm_fx2_sel.
+template <int NK, bool PICK>
+__global__ __launch_bounds__(256, 1) void k_gsel_w(FbGmmDev g, const float *__restrict__ feats, const int *__restrict__ n_rows_ptr,
+                                                   int tiles_per_chunk, int n_chunks, float *__restrict__ gmax,
+                                                   const float *__restrict__ tau, float *__restrict__ gval,
+                                                   unsigned char *__restrict__ gid, int *__restrict__ gcnt, int xcd_map,
+                                                   int tiles_a) {
+  if (g.stop && *g.stop) return;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int IMG4 = 2 * NK * 64;      // 16-byte units per item
+  constexpr int TS = 2, NIG = 2 * TS;    // tiles / items per slot
+  constexpr int SLOT4 = NIG * IMG4;      // 16-byte units per slot
+  constexpr int NPIECE = IMG4 / 64;      // 1 KB pieces per item
+  constexpr int PW = NIG * NPIECE / 4;   // pieces per wave and slot
+  static_assert((NIG * NPIECE) % 4 == 0, "a slot is dealt over four waves");
+  FXW_STAMP(8);
+  const int n_rows = *n_rows_ptr;
+  int strip_i, chunk_i;
+  if (xcd_map) {
+    const int lin = blockIdx.x, per = 8 / xcd_map;
+    const int xcd = lin & 7, idx = lin >> 3;
+    chunk_i = xcd / per;
+    strip_i = idx * per + (xcd % per);
+  } else {
+    strip_i = blockIdx.x;
+    chunk_i = blockIdx.y;
+  }
+  const int strip0 = strip_i * 256;
+  if (strip0 >= n_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const u32x4 *slot0 = reinterpret_cast<const u32x4 *>(lds);
+  float *s_mx = lds + 2 * SLOT4 * 4;                                  // pass A: [4 waves][16 tiles][2 halves][64 lanes]
+  int *s_cnt = reinterpret_cast<int *>(lds + 2 * SLOT4 * 4);          // pass B: [256 rows]
+  unsigned char *s_gid = reinterpret_cast<unsigned char *>(s_cnt + 256);  //   [256 rows][capc]
+  const int capc = 2 * tiles_per_chunk;
+
+  u32x4 bx1[2][NK], bx2[2][NK], bq1[2][NK], bq2[2][NK];
+  int rows[2];
+  float4 ft[2][NK][2];   // both frames' loads go out before the first is used
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    rows[hf] = strip0 + w * 64 + hf * 32 + j;
+    fb_fx_frame_load<NK>(g, feats, rows[hf], n_rows, h, ft[hf]);
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    (void)fb_fx_frame_make<NK, true>(g, feats, ft[hf], rows[hf], n_rows, h, bx1[hf], bx2[hf], bq1[hf], bq2[hf]);
+#pragma unroll
+    for (int c = 0; c < NK; ++c) asm volatile("" : "+a"(bx2[hf][c]), "+a"(bq1[hf][c]), "+a"(bq2[hf][c]));
+    __builtin_amdgcn_sched_barrier(0);  // one half at a time
+  }
+  FXW_STAMP(9);
+  float tauv[2] = {FLT_MAX, FLT_MAX};
+  float4 *gb[2] = {nullptr, nullptr};
+  if constexpr (PICK) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (rows[hf] < n_rows) tauv[hf] = tau[rows[hf]];
+      gb[hf] = reinterpret_cast<float4 *>(gval) + ((size_t)(rows[hf] < n_rows ? rows[hf] : 0) * n_chunks + chunk_i) * capc * 4;
+    }
+    s_cnt[tid] = 0;
+  }
+  const int tile0 = chunk_i * tiles_per_chunk;
+  // pass A may look at the first tiles_a tiles of the chunk only (a multiple of 4, like tiles_per_chunk): the nsel-th largest
+  // group maximum of ANY subset of the components is a lower bound of the row's nsel-th largest value -- half the components
+  // give a tau near the 2 nsel-th largest value, twice the records in pass B and half of pass A's matrix work
+  const int n_tiles_run = PICK ? tiles_per_chunk : tiles_a;
+  const int n_grp = n_tiles_run / TS;                                     // slot contents of this pass (even: the launcher)
+  const u32x4 *gimg = g.images_fx + (size_t)tile0 * 2 * IMG4;
+  const int wv = __builtin_amdgcn_readfirstlane(w);
+  const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)lds;
+  auto publish = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // two accumulator sets, tiles alternate: what a tile leaves is looked at (epilogue) behind the NEXT tile's quadratic step --
+  // its values are long complete there, and the vector work runs while the matrix pipe finishes that step's last products
+  f32x16 hq[2][2], zero;   // [tile parity][frame half]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { hq[0][0][r] = 0.f; hq[0][1][r] = 0.f; hq[1][0][r] = 0.f; hq[1][1][r] = 0.f; zero[r] = 0.f; }
+  FbFxwUpd uu;
+  FXW_STAMP(10);
+  fb_fxw_fetch<NIG, NPIECE>(gimg + lane, ring_lds, wv);
+  publish();
+  FXW_STAMP(11);
+  u32x4 z1, z2;
+  // the tile's epilogue: what leaves the accumulators (tl = tile within the chunk)
+  auto epilogue = [&](const int tl, const int par) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const f32x16 &v = hq[par][hf];
+      float m = fmaxf(fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, v[r]), v[r + 1]);
+      m = fmaxf(m, v[15]);
+      if constexpr (!PICK) {
+        s_mx[((w * 16 + (tl & 15)) * 2 + hf) * 64 + lane] = m;
+      } else {
+        if (m >= tauv[hf]) {
+          const int rl = w * 64 + hf * 32 + j;
+          const int k = atomicAdd(&s_cnt[rl], 1);   // < capc: a (tile, h) group arrives once
+          float4 *dst = gb[hf] + (size_t)k * 4;
+          dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+          dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+          dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+          dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+          s_gid[rl * capc + k] = (unsigned char)(2 * tl + h);
+        }
+      }
+    }
+    if constexpr (!PICK) {
+      if ((tl & 15) == 15 || tl == tiles_a - 1) {
+        // this wave's 64 rows x (up to) 16 tiles x 2 groups, written as whole runs of the rows of gmax
+        const int nt = (tl & 15) + 1, per_row = 2 * nt, NGr = 2 * n_chunks * tiles_a, pos0 = 2 * (chunk_i * tiles_a + (tl & ~15));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < 64 * per_row; i += 64) {
+          const int r2 = i / per_row, pos = i - r2 * per_row;
+          const int rg = strip0 + w * 64 + r2;
+          if (rg < n_rows) gmax[(size_t)rg * NGr + pos0 + pos] = s_mx[((w * 16 + (pos >> 1)) * 2 + (r2 >> 5)) * 64 + (pos & 1) * 32 + (r2 & 31)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  };
+  for (int gp = 0; gp < n_grp; gp += 2) {   // slot A = group gp, slot B = group gp + 1
+    const u32x4 *srcB = gimg + (size_t)min(gp + 1, n_grp - 1) * SLOT4 + (size_t)wv * (PW * 64) + lane;
+    const u32x4 *srcA = gimg + (size_t)min(gp + 2, n_grp - 1) * SLOT4 + (size_t)wv * (PW * 64) + lane;
+    const unsigned dstB = ring_lds + SLOT4 * 16 + (unsigned)wv * (PW * 1024), dstA = ring_lds + (unsigned)wv * (PW * 1024);
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < 2 * NIG; ++jj) {
+      const bool in_b = jj >= NIG;
+      const int gs = jj % NIG;   // step within the slot
+      const u32x4 *cur4 = slot0 + (in_b ? SLOT4 : 0) + gs * IMG4;
+      const u32x4 *nxt4 = slot0 + (in_b ? SLOT4 : 0) + (gs + 1 < NIG ? gs + 1 : 0) * IMG4;
+      const bool pf0 = gs + 1 < NIG;
+      if (gs == 0) {
+        z1 = cur4[(0 * NK + 0) * 64 + lane];
+        z2 = cur4[(1 * NK + 0) * 64 + lane];
+      }
+      const u32x4 *dsrc = in_b ? srcA : srcB;
+      const unsigned ddst = in_b ? dstA : dstB;
+      const int dq0 = 5 * gs;
+      int dn = dq0 < PW ? (PW - dq0 < 5 ? PW - dq0 : 5) : 0;
+      if (gs == 0) {
+#pragma unroll
+        for (int q = 0; q < dn; ++q) fb_glds16(dsrc + q * 64, ddst + (unsigned)q * 1024u);
+        dn = 0;
+      }
+      constexpr int dummy = 0; (void)dummy;
+      const int par = (jj >> 1) & 1;                       // this tile's accumulator set (TS = 2: tiles per loop pass = 4)
+      const int tl = gp * TS + (jj >> 1);                  // tile within the chunk
+      if (!(jj & 1)) {
+        fb_fxw_step<NK, 3, false, true>(cur4, nxt4, pf0, lane, z1, z2, bq1, bq2, zero, zero, hq[par][0], hq[par][1], zero, zero, lds, 1.f, 1.f,
+                                        uu, dsrc, ddst, dq0, dn);
+        if (tl > 0) epilogue(tl - 1, par ^ 1);             // the previous tile (its base step is one step back)
+      } else {
+        fb_fxw_step<NK, 3, false, false>(cur4, nxt4, pf0, lane, z1, z2, bx1, bx2, hq[par][0], hq[par][1], hq[par][0], hq[par][1], zero, zero, lds,
+                                         1.f, 1.f, uu, dsrc, ddst, dq0, dn);
+      }
+      if (gs == NIG - 1) publish();
+    }
+  }
+  epilogue(n_tiles_run - 1, 1);   // the last tile (a multiple of 4 tiles: odd parity)
+  FXW_STAMP(12);
+  if constexpr (PICK) {
+    __syncthreads();   // every wave's last append
+    for (int i = tid; i < 256 * (capc / 4); i += 256) {   // the group ids, 4 at a time (capc is a multiple of 8)
+      const int r2 = i / (capc / 4), q = i - r2 * (capc / 4);
+      const int rg = strip0 + r2;
+      if (rg < n_rows)
+        reinterpret_cast<unsigned *>(gid + ((size_t)rg * n_chunks + chunk_i) * capc)[q] = reinterpret_cast<const unsigned *>(s_gid + r2 * capc)[q];
+    }
+    if (strip0 + tid < n_rows) gcnt[(size_t)(strip0 + tid) * n_chunks + chunk_i] = s_cnt[tid];
+  }
+  FXW_STAMP(13);
+}
+
+bool fb_gsel_w_applies(const FbGmmDev &g, int n_chunks) {
+  const bool off = getenv("FB_GSEL_NARROW") != nullptr;   // A/B and tests: k_gmm_fx2_sel (read per batch)
+  if (off || g.NKF != 5 || (g.C & 31) != 0 || (g.D & 3) != 0 || g.n_tiles % n_chunks != 0) return false;
+  const int tpc = g.n_tiles / n_chunks;
+  return (tpc & 3) == 0 && tpc <= 128;
+}
+// one pass of the wide threshold gselect (pick = 0: group maxima, 1: the records of the groups that reach tau)
+// tiles per chunk pass A looks at (fb_launch_gsel_w with pick = 0 writes gmax rows of 2 n_chunks fb_gsel_w_tiles_a() floats):
+// all of them; FB_GSEL_A_HALF=1: half of them when that is still a multiple of 4 and leaves at least 3 nsel groups -- measured at
+// configs[2] size: pass A 34.2 -> 22.0 us, k_gsel_tau 7.8 -> 6.1, but 42 records per row instead of 20: pass B 32.8 -> 36.5,
+// k_gsel_final_w 10.3 -> 20.6 (it reads the records back): 85.2 against 85.1 us -- not the default
+int fb_gsel_w_tiles_a(const FbGmmDev &g, int n_chunks, int nsel) {
+  const int tpc = g.n_tiles / n_chunks;
+  const bool full = getenv("FB_GSEL_A_HALF") == nullptr;
+  if (!full && (tpc & 7) == 0 && n_chunks * tpc >= 3 * nsel) return tpc / 2;   // (2 groups per tile: n_chunks tpc groups)
+  return tpc;
+}
+void fb_launch_gsel_w(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks, int pick,
+                      float *gmax, const float *tau, float *gval, unsigned char *gid, int *gcnt, int tiles_a) {
+  constexpr int NK = 5;
+  const int strips = (rows_cap + 255) / 256, tpc = g.n_tiles / n_chunks;
+  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  int xcd_map = 0;
+  static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
+  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
+    const int per = 8 / n_chunks;
+    grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
+    xcd_map = n_chunks;
+  }
+  const size_t slots = (size_t)2 * 4 * (2 * NK * 64) * 16;
+  const size_t ldsb = slots + (pick ? sizeof(int) * 256 + (size_t)256 * 2 * tpc : sizeof(float) * 4 * 16 * 2 * 64);
+  static std::atomic<unsigned long long> optin{0};
+  unsigned long long bit = 0;
+  if (ldsb > 64 * 1024 && fb_device_needs_optin(optin, &bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gsel_w<NK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_gsel_w<NK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+      optin.fetch_or(bit, std::memory_order_release);
+  }
+  if (pick)
+    hipLaunchKernelGGL((k_gsel_w<NK, true>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, n_chunks, gmax, tau, gval, gid, gcnt, xcd_map, tiles_a);
+  else
+    hipLaunchKernelGGL((k_gsel_w<NK, false>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, tpc, n_chunks, gmax, tau, gval, gid, gcnt, xcd_map, tiles_a);
+}
+
 template <int NK, int M>
 static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                              int rows_cap, int n_chunks, float *part_m, float *part_s) {

@@ -759,14 +759,14 @@ size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
 }
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, const int *sel_gate) {
+                              int *pairs, float *llf, const int *sel_gate, bool run_select) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
   int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *nz = wstart + (C + 1) + C,
       *cnt = nz + (C + 1);
   const int n_blk = (rows_cap + FB_IV_FB - 1) / FB_IV_FB;
   int *pref = cnt + (size_t)n_blk * iv.Cpad;
-  {
+  if (run_select) {   // (false: sel[] already holds the selection -- fb_launch_gsel_wide)
     const dim3 grid((rows_cap + 3) / 4), blk(256);
     const int nj = (iv.Cpad + 63) / 64;
     if (nj <= 4) hipLaunchKernelGGL(k_iv_select<4>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);

@@ -180,7 +180,7 @@ class Engine(object):
         rows, nsel = int(info[4]), int(self._iv_nsel)
         sel = np.empty((rows, nsel), np.int32)
         N.check(self._L.fb_debug_iv_gselect(self._h, N.ptr(sel), C.c_int64(sel.size), info))
-        return sel, dict(threshold_path=bool(info[0]), overflow=int(info[1]), max_list=int(info[2]),
+        return sel, dict(threshold_path=bool(info[0]), path=int(info[0]), overflow=int(info[1]), max_list=int(info[2]),
                          survivors=int(info[3]), rows=rows)
 
     def set_system(self, task, z_mean=None, z_std=None):

@@ -1,8 +1,9 @@
 """gmm-gselect --n=20 (ivector_PLDA_kaldiHelper.py:197-213) without the dump (round 6): the threshold selection in the
-matrix-core kernel (k_gmm_fx2_sel pass A -> k_gsel_tau -> pass B -> k_gsel_final) against the path it replaces (every
-log-likelihood dumped, k_iv_select) -- the SAME selection, slot for slot, and bit-identical i-vectors; the rescue behind
-it (lists too small for the survivors -> the dump + k_iv_select launches redo the batch); a model whose component count
-is not a multiple of the 32-component tile."""
+matrix-core kernels -- the wide form (k_gsel_w pass A -> k_gsel_tau -> pass B -> k_gsel_final_w: records of the groups that
+reach the threshold, no overflow, no rescue) and the general form (k_gmm_fx2_sel ... k_gsel_final: lists of survivors) --
+against the path they replace (every log-likelihood dumped, k_iv_select): the SAME selection, slot for slot, and
+bit-identical i-vectors; the general form's rescue (lists too small for the survivors -> the dump + k_iv_select launches
+redo the batch); a model whose component count is not a multiple of the 32-component tile."""
 import numpy as np
 import pytest
 
@@ -22,7 +23,7 @@ def full_iv():
 
 
 def _run(engine, system, wavs, monkeypatch, **env):
-    for k in ("FB_IV_GSEL_DUMP", "FB_GSEL_CAP"):
+    for k in ("FB_IV_GSEL_DUMP", "FB_GSEL_CAP", "FB_GSEL_NARROW", "FB_GSEL_A_HALF"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -42,18 +43,25 @@ def test_threshold_selection_equals_the_dump_selection_at_full_size(full_iv, mon
                    [(rng.normal(size=20000) * 6000).astype(np.int16), _wav(9, 1700)]]  # noise: flat posteriors
         for wavs in batches:
             llr_d, tv_d, sel_d, info_d, ivs_d = _run(e, full_iv, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+            llr_n, tv_n, sel_n, info_n, ivs_n = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_NARROW="1")
+            assert info_n["path"] == 1 and info_n["overflow"] == 0 and np.array_equal(sel_d, sel_n)
+            assert np.array_equal(ivs_d.view(np.uint64), ivs_n.view(np.uint64))
             llr_t, tv_t, sel_t, info_t, ivs_t = _run(e, full_iv, wavs, monkeypatch)
-            assert not info_d["threshold_path"] and info_t["threshold_path"]
+            assert not info_d["threshold_path"] and info_t["path"] == 2
             assert info_t["overflow"] == 0
             assert info_t["rows"] == int(np.sum(tv_t)) == sel_t.shape[0]
             assert np.array_equal(sel_d, sel_t)                           # the same 20 components in the same order
             assert sel_t.min() >= 0 and sel_t.max() < full_iv.C
             assert np.array_equal(ivs_d.view(np.uint64), ivs_t.view(np.uint64))
             assert np.array_equal(llr_d.view(np.uint64), llr_t.view(np.uint64))
+            _, _, sel_f, info_f, ivs_f = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_A_HALF="1")   # pass A over half the tiles
+            assert info_f["path"] == 2 and np.array_equal(sel_d, sel_f) and np.array_equal(ivs_d.view(np.uint64), ivs_f.view(np.uint64))
+            assert 20.0 <= info_f["survivors"] / info_f["rows"] <= 64.0
             per_row = info_t["survivors"] / info_t["rows"]
-            print("threshold gselect: %d rows, %.1f survivors per row, longest (row, chunk) list %d"
-                  % (info_t["rows"], per_row, info_t["max_list"]))
-            assert 20.0 <= per_row <= 40.0 and info_t["max_list"] <= 32
+            print("threshold gselect: %d rows, %.1f records (wide; pass A over half the tiles: %.1f) / %.1f survivors (general) per row, most "
+                  "records of a (row, chunk) %d" % (info_t["rows"], per_row, info_f["survivors"] / info_f["rows"],
+                                                    info_n["survivors"] / info_n["rows"], info_t["max_list"]))
+            assert 20.0 <= per_row <= 21.0 and info_t["max_list"] <= 32
     finally:
         e.close()
 
@@ -67,11 +75,11 @@ def test_overflowing_lists_take_the_rescue_launches(full_iv, monkeypatch):
         e.load_ivector(full_iv, "SV" if False else "OSI")
         wavs = [_wav(0, 30000), _wav(1, 9000)]
         _, _, sel_d, _, ivs_d = _run(e, full_iv, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
-        _, _, sel_r, info_r, ivs_r = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_CAP="2")
-        assert info_r["threshold_path"] and info_r["overflow"] == 1 and info_r["max_list"] > 2
+        _, _, sel_r, info_r, ivs_r = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_CAP="2", FB_GSEL_NARROW="1")
+        assert info_r["path"] == 1 and info_r["overflow"] == 1 and info_r["max_list"] > 2
         assert np.array_equal(sel_d, sel_r)
         assert np.array_equal(ivs_d.view(np.uint64), ivs_r.view(np.uint64))
-        _, _, sel_t, info_t, _ = _run(e, full_iv, wavs, monkeypatch)
+        _, _, sel_t, info_t, _ = _run(e, full_iv, wavs, monkeypatch, FB_GSEL_NARROW="1")
         assert info_t["overflow"] == 0 and np.array_equal(sel_d, sel_t)
     finally:
         e.close()
@@ -79,8 +87,8 @@ def test_overflowing_lists_take_the_rescue_launches(full_iv, monkeypatch):
 
 @pytest.mark.parametrize("C", [1300, 2560])
 def test_threshold_selection_with_a_padded_last_tile_and_other_group_counts(C, monkeypatch):
-    """C = 1300: 41 tiles, the last with 20 real components (padding must never be selected), 82 groups (k_gsel_tau<8>);
-    C = 2560: 160 groups (k_gsel_tau<16>)."""
+    """C = 1300: 41 tiles, the last with 20 real components (padding must never be selected), 82 groups (k_gsel_tau<8>) --
+    the general form; C = 2560: 160 groups (k_gsel_tau<16>), the wide form with 20 tiles per chunk."""
     sy = synthetic_ivector_system(C=C, D=72, R=64, L=32, n_speakers=1)
     e = Engine(0)
     try:
@@ -88,8 +96,9 @@ def test_threshold_selection_with_a_padded_last_tile_and_other_group_counts(C, m
         wavs = [_wav(20 + u, 16000 + 3000 * u) for u in range(5)]
         _, _, sel_d, info_d, ivs_d = _run(e, sy, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
         _, _, sel_t, info_t, ivs_t = _run(e, sy, wavs, monkeypatch)
-        assert info_t["threshold_path"] and info_t["overflow"] == 0 and not info_d["threshold_path"]
+        assert info_t["path"] == (2 if C == 2560 else 1) and info_t["overflow"] == 0 and not info_d["threshold_path"]
         assert np.array_equal(sel_d, sel_t) and sel_t.max() < C
         assert np.array_equal(ivs_d.view(np.uint64), ivs_t.view(np.uint64))
     finally:
         e.close()
+
