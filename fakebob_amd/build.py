@@ -47,6 +47,45 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
+# variants of the library next to the product build: name -> (extra flags, sources they change; the other objects are the
+# product build's).  "fenced": every cross-workgroup exchange with release / acquire semantics (csrc/fb_device.h, FB_FENCED) --
+# tests/test_gpu_fenced.py runs it against the product build and asserts identical bits.
+VARIANTS = {"fenced": (["-DFB_FENCED"], ["nes_kernels.hip", "frontend_kernels.hip", "gmm_kernels.hip", "ivector_solve.hip", "ivector_kernels.hip"])}
+
+
+def variant_path(name):
+    return os.path.join(LIBDIR, "libfakebob_hip_%s.so" % name)
+
+
+def build_variant(name, force=False):
+    """the product build first (its objects are reused), then the variant's own objects and library"""
+    build()
+    flags, own = VARIANTS[name]
+    lib = variant_path(name)
+    if not force and os.path.exists(lib) and not any(os.path.getmtime(f) > os.path.getmtime(lib) for f in _deps()):
+        return lib
+    hipcc = _hipcc()
+    odir = os.path.join(OBJDIR, name)
+    os.makedirs(odir, exist_ok=True)
+
+    def comp(src):
+        obj = os.path.join(odir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s (%s):\n%s" % (src, name, r.stdout))
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=len(own)) as ex:
+        objs = list(ex.map(comp, own))
+    objs += [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES if s not in own]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed (%s):\n%s" % (name, r.stdout))
+    return lib
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

@@ -12,6 +12,23 @@
 
 #define FB_WAVE 64
 
+// Memory order of every word that crosses workgroups inside a launch (agent-scope atomic stores and
+// loads whose "ready" travels in the data word itself, no fences -- gfx950 hardware behaviour, not what the HIP memory model
+// promises for neighbouring plain stores).  -DFB_FENCED builds the same kernels with release stores / acquire loads /
+// acq_rel read-modify-writes at agent scope -- the compiler then writes back / invalidates the L2 path around each of them,
+// which is what the memory model asks for and what costs microseconds per workgroup on the eight-XCD part.  Both builds
+// must give the same bits (tests/test_gpu_fenced.py: fakebob_amd/lib/libfakebob_hip_fenced.so): a race in the fence-free
+// protocol would show as a difference there.
+#ifdef FB_FENCED
+#define FB_XCH_ST __ATOMIC_RELEASE
+#define FB_XCH_LD __ATOMIC_ACQUIRE
+#define FB_XCH_RMW __ATOMIC_ACQ_REL
+#else
+#define FB_XCH_ST __ATOMIC_RELAXED
+#define FB_XCH_LD __ATOMIC_RELAXED
+#define FB_XCH_RMW __ATOMIC_RELAXED
+#endif
+
 __device__ __forceinline__ void fb_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                   uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll

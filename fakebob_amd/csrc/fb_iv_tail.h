@@ -148,7 +148,7 @@ __device__ __forceinline__ void fb_iv_backend_body(const FbIvDev &iv, int b, dou
       if (iv.text_scores) sc_ = fb_round6(sc_);  // ivector-plda-scoring writes text
       if (agent)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(llr + (size_t)b * S + s), (unsigned long long)__double_as_longlong(sc_),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                           FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
       else
         llr[(size_t)b * S + s] = sc_;
     }
@@ -181,7 +181,7 @@ __device__ __forceinline__ void fb_iv_tail_run(const FbIvDev &iv, const FbIvTail
   }
   __syncthreads();
   if (!s_ivt_last) return;
-  if (tid == 0) __hip_atomic_store(tl.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(tl.counter, 0, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
   if (tl.ctl && tl.ctl->stop) return;   // queued behind the stopping iteration (k_loss's first line)
   double *s_lv = scr + fb_ivt_backend_doubles(R, iv.L), *s_sc = s_lv + FB_LOSS_LDS;
   fb_loss_body<true, true>(tl.llr, tl.tv, B, iv.S, tl.task, 1, tl.attack_type, tl.z_mean, tl.z_std, tl.threshold, tl.adver_thresh,

@@ -5,7 +5,7 @@
 #include "fb_kernels.h"
 
 __device__ __forceinline__ double fb_ld_agent_f64(const double *p) {
-  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), FB_XCH_LD,
                                                  __HIP_MEMORY_SCOPE_AGENT);
   return __longlong_as_double((long long)u);
 }
@@ -224,7 +224,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
       }
     }
     if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(loss + b), (unsigned long long)__double_as_longlong(l),
-                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     else loss[b] = l;
     if (b < lv_cap) s_lv[b] = l;
   }
@@ -316,7 +316,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
               const double l2 = __ddiv_rn(lr, c.plateau_drop);
               lr = l2 > c.min_lr ? l2 : c.min_lr;
               if (pub_seq) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->lr), (unsigned long long)__double_as_longlong(lr),
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                              FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
               else ctl->lr = lr;
             }
             n = 0;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
         }
       }
       if (stop_now) {
-        if (pub_seq) __hip_atomic_store(&ctl->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pub_seq) __hip_atomic_store(&ctl->stop, 1, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
         else ctl->stop = 1;
       }
     }
@@ -336,7 +336,7 @@ __device__ __forceinline__ void fb_loss_body(const double *__restrict__ raw, con
     __builtin_amdgcn_s_waitcnt(0);
     FN_STAMP(10);
     __syncthreads();
-    if (threadIdx.x == 0 && ctl) __hip_atomic_store(&ctl->pub_seq, pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && ctl) __hip_atomic_store(&ctl->pub_seq, pub_seq, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x == 0) {  // the bookkeeping
     out->adver_loss = al;
@@ -433,17 +433,17 @@ __device__ __forceinline__ void fb_update_perturb_body(const double *__restrict_
     if (threadIdx.x == 0) {
       int st;
       for (;;) {
-        st = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st || __hip_atomic_load(&ctl->pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_seq) break;
+        st = __hip_atomic_load(&ctl->stop, FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
+        if (st || __hip_atomic_load(&ctl->pub_seq, FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT) >= wait_seq) break;
         __builtin_amdgcn_s_sleep(4);
       }
       // (a stop raised by THIS launch's loss body is published before pub_seq: look again behind it)
-      s_stop = st | __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_stop = st | __hip_atomic_load(&ctl->stop, FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
     }
     FN_STAMP(2);
     __syncthreads();
     if (s_stop) return;
-    lr = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->lr), __ATOMIC_RELAXED,
+    lr = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->lr), FB_XCH_LD,
                                                            __HIP_MEMORY_SCOPE_AGENT));
     for (int i = threadIdx.x; i < spd; i += blockDim.x) s_loss[i] = fb_ld_agent_f64(loss + 1 + i);
   }

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__re
   }
   __shared__ int s_last;
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&tv[b], s_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&tv[b], s_run, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     // (agent-scope store, agent-scope counter, agent-scope loads below: only this thread's store has to be complete
     //  before its increment -- no device-wide fences, see k_gmm_finalize_loss)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__re
   const int lo = threadIdx.x * per, hi = min(B, lo + per);
   int sum = 0;
   for (int i = lo; i < hi; ++i) {
-    const int v = __hip_atomic_load(&tv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v = __hip_atomic_load(&tv[i], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
     sum += v > 0 ? v : 0;
   }
   int inc = sum;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_vad(FbFrontendDev fe, const float *__re
   for (int i = 0; i < w; ++i) run += s_wtot[i];
   if (threadIdx.x == 255) { row_off[B] = run + sum; *counter = 0; }
   for (int i = lo; i < hi; ++i) {
-    const int v = __hip_atomic_load(&tv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v = __hip_atomic_load(&tv[i], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
     row_off[i] = run;
     run += v > 0 ? v : 0;
   }
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
   const int lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
     const int tk = atomicAdd(ticket, 1);
-    if (tk == B - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else will draw
+    if (tk == B - 1) __hip_atomic_store(ticket, 0, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);  // nobody else will draw
     s_b = tk;
     s_run = 0;
   }
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
   const int n_voiced = s_run;
   if (tid == 0) {
     tv[b] = n_voiced;
-    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELAXED,
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, FB_XCH_ST,
                        __HIP_MEMORY_SCOPE_AGENT);   // (epoch and count in one word: nothing else to order, no fence)
   }
   double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(1024) void k_vad_delta_cmvn(FbFrontendDev fe, const
       for (int i = tid - first; i < b; i += nth) {
         unsigned long long v;
         do {
-          v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = __hip_atomic_load(&pub[i], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
         } while ((unsigned)(v >> 32) != epoch);
         const int c = (int)(unsigned)v;
         mine += c > 0 ? c : 0;
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontend
     // sentinel back into the i-th (utterance, part) slot of that set (any bijection does).
     unsigned long long *nxt = reinterpret_cast<unsigned long long *>(part_sum) + (size_t)((slot_set + 1u) & 1u) * B * FB_CMVN_PARTS * fe.dim;
     for (int d = threadIdx.x; d < fe.dim; d += FB_VADP_THREADS)
-      __hip_atomic_store(&nxt[(size_t)blockIdx.x * fe.dim + d], FB_VAD_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&nxt[(size_t)blockIdx.x * fe.dim + d], FB_VAD_SENTINEL, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   VD_STAMP(0);
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontend
   VD_STAMP(4);
   if (tid == 0 && part == 0) {
     tv[b] = n_voiced;
-    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, __ATOMIC_RELAXED,
+    __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)n_voiced, FB_XCH_ST,
                        __HIP_MEMORY_SCOPE_AGENT);   // (epoch and count in one word: nothing else to order)
   }
   double creg[ORDER > 0 ? ORDER + 1 : 1][ORDER > 0 ? 2 * ORDER * WIN + 1 : 1];
@@ -1560,8 +1560,8 @@ __global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontend
     own = acc;
     unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
     if (acc != acc) bits = 0x7ff8000000000001ull;
-    __hip_atomic_store(&cur[((size_t)b * NP + part) * dim + d], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&nxt[((size_t)b * NP + part) * dim + d], SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&cur[((size_t)b * NP + part) * dim + d], bits, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&nxt[((size_t)b * NP + part) * dim + d], SENT, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
   }
   VD_STAMP(6);
   // ---- row offset: voiced counts of the utterances before this one (the count travels IN the polled word)
@@ -1570,7 +1570,7 @@ __global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontend
     for (int i = tid; i < b; i += NT) {
       unsigned long long v;
       do {
-        v = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(&pub[i], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
       } while ((unsigned)(v >> 32) != epoch);
       const int c = (int)(unsigned)v;
       mine += c > 0 ? c : 0;
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(FB_VADP_THREADS) void k_vad_delta_cmvn_p(FbFrontend
       if (p != part) {
         unsigned long long bits;
         do {
-          bits = __hip_atomic_load(&cur[((size_t)b * NP + p) * dim + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bits = __hip_atomic_load(&cur[((size_t)b * NP + p) * dim + d], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
         } while (bits == SENT);
         v = __longlong_as_double((long long)bits);
       }

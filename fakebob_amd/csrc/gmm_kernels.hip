@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
       raw[(size_t)b * g.M + m] = avg;
       unsigned long long bits = (unsigned long long)__double_as_longlong(avg);
       if (avg != avg) bits = 0x7ff8000000000000ull;   // (never the sentinel)
-      __hip_atomic_store(xch + (size_t)b * g.M + m, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xch + (size_t)b * g.M + m, bits, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     }
     FN_STAMP(3);
     if (!consumer) return;
@@ -1048,12 +1048,12 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     for (int i = threadIdx.x; i < B * g.M; i += blockDim.x) {
       unsigned long long v;
       for (;;) {
-        v = __hip_atomic_load(xch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(xch + i, FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
         if (v != FB_VAD_SENTINEL) break;
         __builtin_amdgcn_s_sleep(1);
       }
       s_raw[i] = __longlong_as_double((long long)v);
-      __hip_atomic_store(xch + i, FB_VAD_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xch + i, FB_VAD_SENTINEL, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     FN_STAMP(4);
@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
     double avg = tvb > 0 ? red[0] / (double)tvb : __longlong_as_double(0x7ff8000000000000ll);
     if (g.text_scores && tvb > 0) avg = fb_round6(avg);
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(raw + (size_t)b * g.M + m),
-                       (unsigned long long)__double_as_longlong(avg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       (unsigned long long)__double_as_longlong(avg), FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     // The score was stored with an agent-scope (write-through) atomic, the arrival counter is an agent-scope atomic and
     // the last arriver reads the scores with agent-scope loads: what has to be ordered is only this thread's store
     // before its own increment -- wait for the store to complete.  (A device-wide release fence here writes back the
@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void fb_gmm_finalize_loss_body(const FbGmmDev &g, con
   __syncthreads();
   if (!s_last) return;
   FN_STAMP(4);
-  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
   // (stamps, tools/profile/fin_instrumented.sh: the body takes ~6 us -- 1.5 until the raw scores are there, ~2.5 forming
   //  the losses, 0.7 barrier, 0.7 one lane's mean, 0.7 decisions, 0.3 publication.  A rehearsal pass without stores ran
   //  first to see whether cold instruction fetch is behind it: the second pass took 5.4 us, so it is not.)
@@ -1143,8 +1143,8 @@ __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, co
     // draws, stopping launch or not; the last ticket leaves the word at zero for the next launch.
     __shared__ int s_role;
     if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(u.role_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (int)gridDim.x - 1) __hip_atomic_store(u.role_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = __hip_atomic_fetch_add(u.role_ticket, 1, FB_XCH_RMW, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (int)gridDim.x - 1) __hip_atomic_store(u.role_ticket, 0, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
       s_role = t;
     }
     __syncthreads();

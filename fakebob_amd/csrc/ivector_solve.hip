@@ -496,11 +496,11 @@ extern "C" int fb_debug_rw_stamps(unsigned long long *out) {
 #define RW_STAMP(row, k) do { } while (0)
 #endif
 __device__ __forceinline__ double fb_rw_ld(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), FB_XCH_LD,
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void fb_rw_st(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), FB_XCH_ST,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int G>
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
   const int l15 = lane & 15, l4 = lane >> 4;
   if (tid == 0) {
     const int tk = atomicAdd(ticket, 1);
-    if (tk == B * G - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == B * G - 1) __hip_atomic_store(ticket, 0, FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     s_tk = tk;
   }
   __syncthreads();
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     if (tid == 0) {
       unsigned v;
       do {
-        v = __hip_atomic_load(&pg[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(&pg[row], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
       } while ((v >> 8) != (epoch & 0xffffffu) || (v & 0xffu) < need);
     }
     __syncthreads();
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_max(&pg[row], ((epoch & 0xffffffu) << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_max(&pg[row], ((epoch & 0xffffffu) << 8) | n, FB_XCH_RMW, __HIP_MEMORY_SCOPE_AGENT);
   };
   // acc(sub-tile st) = sum over the panels q = kh, kh + 2, .. < nq of Lrow[rows 16 th .., q] L[rows c0 + 16 tc .., q]^T:
   // the own rows from LDS, the other block row's from memory -- ALL its fragments requested before the first multiply
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     if (has_diag) {  // the other slot set's inverse of this row: sentinel again for the launch after next
       for (int i = tid; i < FB_SV_NB * FB_SV_NB; i += nt)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(Lnxt + (size_t)rb * FB_SV_NB * FB_SV_NB + i), FB_RW_SENT,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                           FB_XCH_ST, __HIP_MEMORY_SCOPE_AGENT);
     }
     fb_d4 dacc = {0.0, 0.0, 0.0, 0.0};   // this wave's share of sum_q L[rb,q] L[rb,q]^T (sub-tile st, K half kh of every block)
     double av[4], avd[4] = {0.0, 0.0, 0.0, 0.0};
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
     if (tid == 0) {
       unsigned pv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pv[i] = i < ncol ? __hip_atomic_load(&pg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      for (int i = 0; i < 16; ++i) pv[i] = i < ncol ? __hip_atomic_load(&pg[i], FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       int ready = 0;
 #pragma unroll
       for (int i = 0; i < 16; ++i)
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         dst[u] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + tid + u * 512),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                   FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
     };
     unsigned long long dvn[2] = {FB_RW_SENT, FB_RW_SENT};
     if (ncol > 0 && 0 < ready) ld_inv(0, dvn);
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
         unsigned long long bits = c < ready ? dvc[u] : FB_RW_SENT;
         while (bits == FB_RW_SENT)
           bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(Lcur + (size_t)c * FB_SV_NB * FB_SV_NB + i),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                   FB_XCH_LD, __HIP_MEMORY_SCOPE_AGENT);
         Di[(i >> 5) * FB_SV_LD + (i & 31)] = __longlong_as_double((long long)bits);
       }
       __syncthreads();
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
         n_pub += 1;
         while (__hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * n_pub) { }
         // (fetch_max: wave 0's "complete" below may overtake this one; within an epoch the word only grows)
-        __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)ncol, FB_XCH_RMW, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (has_diag) {
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(512) void k_iv_solve_rw(FbIvDev iv, double *__restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0)
-          __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)(rb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(&pg[rb], ((epoch & 0xffffffu) << 8) | (unsigned)(rb + 1), FB_XCH_RMW, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       RW_STAMP(rb, 5);
