@@ -539,6 +539,9 @@ def main():
                     help="skip the secondary measurements of the default line (forced three products, realistic enrolment, "
                          "reference-pipeline mode, GMM CSI, i-vector SV / OSI)")
     ap.add_argument("--arch", default="gmm", choices=["gmm", "iv"], help="gmm = headline (configs[1]); iv = configs[2]")
+    ap.add_argument("--e2e-only", action="store_true",
+                    help="only the whole-attack measurement (secondary.end_to_end) -- with --gpus N: one list of attacks for the "
+                         "whole job, dealt or drawn across ranks (parallel.WorkQueue's cross-rank ticket)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (plumbing test)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
@@ -612,6 +615,19 @@ def main():
         print("bench.py: WARNING: this system is scored by the general kernel %s, not k_gmm_fx2w (more than %d models, "
               "several variance groups or partial tiles)" % (variant, 10), file=sys.stderr)
 
+    if args.e2e_only:
+        r = end_to_end(torch, engs, kw_common, dist=dist, dist_backend=args.dist_backend)
+        if rank == 0:
+            emit({"metric": "whole attacks with the early stop on (bench.end_to_end)", "n_gpus": world, "end_to_end": r,
+                  "value": r["dynamic"]["nes_iterations_per_s"], "unit": "NES iterations/s", "data": "synthetic",
+                  "config": {"workload": "24 attacks against the headline system, %d attacks in flight per rank, %d ranks%s"
+                             % (K, world, " on ONE device (plumbing run)" if args.same_device else "")}})
+        for e in engs:
+            e.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # outside everything: module load, first-touch allocations, the clock ramp of a cold GPU, and the same GMM
     # launch with the chip to itself
     aset = AttackSet(engs, prms, auds)
@@ -765,6 +781,7 @@ def main():
             #      and the headline kernel timed solo once more -- at the clocks everything above has left
             reload(models, "OSI", (None, None), kw, "targeted")
             sec["end_to_end"] = end_to_end(torch, engs, kw_common)
+            sec["end_to_end_two_ranks"] = two_rank_end_to_end(K)
             aset.restart()
             aset.run(4, False)
             solo_end, _rows_end = engs[0].bench_gmm_kernel(20)
@@ -793,14 +810,17 @@ def main():
         dist.destroy_process_group()
 
 
-def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
+def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3, dist=None, dist_backend="nccl"):
     """Whole attacks with the early stop ON (FAKEBOB.py:181-191), as attackMain.py:324-409 runs them: `n_utts` synthetic
     utterances against the headline system, each with the speaker it already scores highest for as the target and the
     system threshold calibrated (untimed pass) so that the attack stops at a seeded iteration between 8 and 60.  The K engines of the GPU take them from fakebob_amd.parallel.WorkQueue --
     dealt in advance (`static`: stream k takes every K-th, what rounds 1 - 4 did) or drawn when a stream is free
     (`dynamic`) --, alternating, `reps` times each: wall-clock attacks/s and NES iterations/s, the median run of each.
     (trace rows = iterations run: the stopping iteration included.)
-    Upload of the audio, read-back of the adversarial audio and trace included (fb_attack)."""
+    Upload of the audio, read-back of the adversarial audio and trace included (fb_attack).
+    With `dist` (several ranks): ONE list of attacks for the whole job -- dealt rank by rank and stream by stream, or drawn
+    from the job's ticket (parallel.WorkQueue: `store.add` across ranks) --, a barrier on both sides of each run, the wall
+    time the maximum over ranks, the row counts all-reduced (every attack runs on exactly one rank)."""
     import threading
     import numpy as np
     from fakebob_amd import parallel
@@ -831,8 +851,19 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
         items.append((a, nes_params("OSI", "targeted", seed=42, stream=1000 + u, **kw)))
     rows, flags = [0] * n_utts, [0] * n_utts
 
+    world = 1
+    if dist is not None:
+        world = dist.get_world_size()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     def run(schedule):
-        q = parallel.WorkQueue(n_utts, None, schedule, streams=K)
+        for i in range(n_utts):
+            rows[i], flags[i] = 0, 0
+        q = parallel.WorkQueue(n_utts, dist, schedule, streams=K)
         busy, err = [0.0] * K, []
 
         def worker(k):
@@ -846,15 +877,27 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
                 busy[k] = time.perf_counter() - t0
             except BaseException as ex:  # noqa: BLE001
                 err.append(ex)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         ths = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
         [t.start() for t in ths]
         [t.join() for t in ths]
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
+        if dist is not None:
+            # (a failing rank is seen by every rank: the counters below would not add up)
+            tdev = "cuda" if dist_backend == "nccl" else "cpu"
+            t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            both = parallel.reduce_counters(list(rows) + list(flags) + [q.drawn, 1 if err else 0], dist)
+            assert both[-1] == 0, "an attack stream failed on some rank"
+            assert both[-2] == n_utts, ("attacks drawn over all ranks", both[-2], n_utts)
+            for i in range(n_utts):
+                rows[i], flags[i] = int(both[i]), int(both[n_utts + i])
         if err:
             raise err[0]
+        assert all(r > 0 for r in rows), "every attack of the list ran exactly once"
         return dt, busy
 
     run("dynamic")                                          # untimed: first-touch allocations of the attack path
@@ -862,7 +905,7 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
     for _ in range(reps):
         for sch in ("static", "dynamic"):
             res[sch].append(run(sch))
-    out = {"attacks": n_utts, "attacks_in_flight": K, "max_iter": max_iter, "early_stop": True,
+    out = {"attacks": n_utts, "attacks_in_flight": K, "ranks": world, "max_iter": max_iter, "early_stop": True,
            "iterations_per_attack": list(rows), "calibrated_stop_iterations": wanted,
            "successes": int(sum(1 for f in flags if f == 1)),
            "iterations_total": int(sum(rows)),
@@ -875,6 +918,33 @@ def end_to_end(torch, engs, kw_common, n_utts=24, max_iter=100, reps=3):
                     "stream_busy_s": busy, "runs_wall_s": [r[0] for r in res[sch]]}
     out["dynamic_over_static"] = out["static"]["wall_s"] / out["dynamic"]["wall_s"]
     return out
+
+
+def two_rank_end_to_end(K):
+    """The same measurement as a TWO-rank job on this one device (`--gpus 2 --same-device --dist-backend gloo --e2e-only` in
+    a child process): the self-launch under torch.distributed.run, the job's own key-value store, the cross-rank ticket
+    (`store.add`) that hands attacks to whichever stream of whichever rank is free, the all-reduced counters.  Not a
+    scaling number -- both ranks share the chip --: it puts the N > 1 attack distribution on the GPU box in every run."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--e2e-only",
+           "--streams", str(max(1, K // 2 + K % 2)), "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or len(lines) != 1:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[0])["end_to_end"]
+        return {"ranks": d["ranks"], "attacks": d["attacks"], "attacks_in_flight_per_rank": d["attacks_in_flight"],
+                "iterations_total": d["iterations_total"], "successes": d["successes"],
+                "static": {k_: d["static"][k_] for k_ in ("wall_s", "attacks_per_s", "nes_iterations_per_s")},
+                "dynamic": {k_: d["dynamic"][k_] for k_ in ("wall_s", "attacks_per_s", "nes_iterations_per_s")},
+                "dynamic_over_static": d["dynamic_over_static"],
+                "note": "two ranks (gloo) on this one device: attacks dealt in advance or drawn from the job's cross-rank ticket"}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:300]}
 
 
 def secondary_ivector(torch, dev_index, K, mfcc_f32=1):
