@@ -1232,7 +1232,17 @@ __global__ __launch_bounds__(256) void k_iv_contract_both(FbIvDev iv, const doub
   const int n_lin = n_lin_x * n_kchunks * (int)gridDim.y;
   int idx = blockIdx.x;
   if (idx < n_lin_x * n_kchunks) {
-    fb_contract_dma_body<true>(iv, XT, ldA, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp, idx % n_lin_x, idx / n_lin_x,
+    // The column tiles of one K chunk read the SAME coefficient rows (X^T: 13 MB over all chunks at configs[2] size).
+    // Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own: with tile = idx % n_lin_x the four
+    // tiles of a chunk sat on four XCDs and each fetched the rows again.  Here a chunk's tiles are the workgroups idx,
+    // idx + 8, idx + 16, ... -- one XCD (chunk counts that are not a multiple of 8 keep the plain order).
+    int tile = idx % n_lin_x, chunk = idx / n_lin_x;
+    if ((n_kchunks & 7) == 0) {
+      const int grp = idx / (8 * n_lin_x), in = idx - grp * 8 * n_lin_x;
+      chunk = grp * 8 + (in & 7);
+      tile = in >> 3;
+    }
+    fb_contract_dma_body<true>(iv, XT, ldA, (size_t)iv.C * iv.D, active, n_active, B, n_kchunks, linp, tile, chunk,
                                blockIdx.y, sA, sB);
   } else {
     idx -= n_lin_x * n_kchunks;
