@@ -375,7 +375,7 @@ def bench_ivector(args, torch):
 
 GMM_MODE = os.environ.get("FB_GMM_MODE", "fx2") or "fx2"
 GMM_TRAFFIC_KEY = {"fx2": "k_gmm_fx2w<5, 6>", "bx3": "k_gmm_bx3<5, false>"}[GMM_MODE]
-TRAFFIC_FILE = "r05_traffic.json"
+TRAFFIC_FILE = "r06_traffic.json"
 # bf16 32x32x16 chain on random operands, this chip (tools/probes/bx_probe.hip, a round-1 PROBE, not a specification):
 # the clock drops to ~1.6 GHz under a saturated matrix pipe (DVFS), which bounds any real kernel below the 2.5 PF peak
 MFMA16_POWER_LIMITED_TFLOPS_PROBE = 1660.0
@@ -405,7 +405,7 @@ def committed_traffic(key):
         now = kernel_source_hash()
         if tj.get("kernel_source_sha16") != now:
             print("bench.py: profiles/%s was taken on kernel sources %s, this build is %s -- roofline.traffic is NOT "
-                  "reported (re-run tools/profile/prof_r05.sh)" % (TRAFFIC_FILE, tj.get("kernel_source_sha16"), now),
+                  "reported (re-run tools/profile/prof_r06.sh)" % (TRAFFIC_FILE, tj.get("kernel_source_sha16"), now),
                   file=sys.stderr)
             return None, {"traffic_stale": True, "traffic_profiled_on": tj.get("kernel_source_sha16"), "kernel_source_sha16": now}
         return tj["kernels"][key]["hbm_bytes_per_launch"], {

@@ -1367,7 +1367,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
       FBCHK(e->gs_gid.ensure((size_t)total_frames * 2 * g.n_tiles));
       fb_launch_gsel_wide(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, wide_chunks, iv.nsel, e->gs_max.as<float>(),
                           e->gs_tau.as<float>(), e->iv_ll.as<float>(), e->gs_gid.as<unsigned char>(), e->gs_cnt.as<int>(),
-                          e->gs_flag.as<int>(), e->iv_sel.as<int>());
+                          e->gs_flag.as<int>(), e->iv_sel.as<int>(), fb_iv_bucket_cnt(iv, e->iv_bws.as<int>()), iv.Cpad);
       FB_DBG_SYNC(e, "gsel_wide");
       e->gs_last_path = 2;
       e->gs_last_chunks = wide_chunks;
@@ -1393,7 +1393,7 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
     }
     fb_launch_iv_select_post(s, iv, e->iv_ll.as<float>(), e->feats.as<float>(), e->row_off.as<int>() + B,
                              total_frames, e->iv_sel.as<int>(), e->iv_post.as<float>(), e->iv_bws.as<int>(),
-                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), sel_gate, wide_chunks == 0);
+                             e->iv_pairs.as<int>(), e->iv_llf.as<float>(), sel_gate, wide_chunks == 0, wide_chunks == 0);
     FB_DBG_SYNC(e, "select_post");
     fb_launch_iv_stats(s, iv, e->feats.as<float>(), e->row_off.as<int>(), e->iv_pairs.as<int>(), e->iv_bws.as<int>(),
                        e->iv_post.as<float>(), B, Bpad, e->iv_gamma.as<double>(), e->iv_X.as<double>());

@@ -254,7 +254,8 @@ void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const 
 // No overflow and no rescue: sel[] is final (flag is raised by NaN features only).
 int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap);
 void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
-                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel);
+                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel,
+                         int *cnt /* nullable: fb_iv_bucket_cnt() -- the bucket sort's per-block counts, made here */, int Cpad);
 // k_gmm_finalize + k_loss fused (GMM systems in the NES loop): counter = one int, zero before the first launch
 void fb_launch_gmm_finalize_loss(hipStream_t s, const FbGmmDev &g, const float *part_m, const float *part_s,
                                  int rows_cap, int n_chunks, const int *row_off, int B, double *raw, int *counter,
@@ -325,9 +326,11 @@ void fb_launch_iv_derive(hipStream_t s, int C, int D, int R, const double *M, co
 size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap);
 // sel_gate: nullable device flag -- k_iv_select runs only when it is non-zero (sel[] then already holds fb_launch_gsel's
 // selection; the gate is its overflow flag)
+#define FB_IV_FB 64  // frames per partition block of the bucket sort (k_iv_bucket_count / _fill; k_gsel_final_w's workgroup)
+int *fb_iv_bucket_cnt(const FbIvDev &iv, int *bucket_ws);   // where the per-block counts live inside bucket_ws
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, const int *sel_gate = nullptr, bool run_select = true);
+                              int *pairs, float *llf, const int *sel_gate = nullptr, bool run_select = true, bool run_count = true);
 // gammaT [C][Bpad], XT [C*D][Bpad]: utterance-minor, zero-padded to Bpad (multiple of 32)
 void fb_launch_iv_stats(hipStream_t s, const FbIvDev &iv, const float *feats, const int *row_off, const int *pairs,
                         const int *bucket_ws, const float *post, int B, int Bpad, double *gammaT, double *XT);

@@ -761,15 +761,25 @@ int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap) {
   while (n > 1 && (n > want || !fb_gsel_w_applies(g, n))) n >>= 1;
   return fb_gsel_w_applies(g, n) ? n : 0;
 }
-__global__ __launch_bounds__(256) void k_gsel_final_w(const float *__restrict__ gval, const unsigned char *__restrict__ gid,
-                                                     const int *__restrict__ gcnt, const float *__restrict__ tau, int n_chunks, int tpc,
-                                                     const int *__restrict__ n_rows_ptr, int nsel, int C, int *__restrict__ sel,
-                                                     int *__restrict__ flag) {
-  __shared__ unsigned long long s_key[16][FB_GSEL_MAXC];
-  __shared__ int s_n[16];
+// A workgroup = FB_GSEL_FB = 64 frames (1024 threads) = one partition block of the bucket sort that follows: the counts
+// k_iv_bucket_count would make of sel[] (ivector_kernels.hip: per-component counts of the block) are taken here from the
+// selections as they are written -- cnt[block][Cpad], nullable -- and that launch is not made.
+#define FB_GSEL_FB FB_IV_FB
+#define FB_GSEL_MAXW 64   // values at or above tau a frame ranks through LDS (more: straight from the records)
+__global__ __launch_bounds__(1024) void k_gsel_final_w(const float *__restrict__ gval, const unsigned char *__restrict__ gid,
+                                                      const int *__restrict__ gcnt, const float *__restrict__ tau, int n_chunks, int tpc,
+                                                      const int *__restrict__ n_rows_ptr, int nsel, int C, int *__restrict__ sel,
+                                                      int *__restrict__ flag, int *__restrict__ cnt, int Cpad) {
+  __shared__ unsigned long long s_key[FB_GSEL_FB][FB_GSEL_MAXW];
+  __shared__ int s_n[FB_GSEL_FB];
+  extern __shared__ int s_hist[];   // [Cpad] when cnt
+  if (cnt) {
+    for (int i = threadIdx.x; i < Cpad; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+  }
   const int n_rows = *n_rows_ptr;
-  const int l = threadIdx.x & 15, rw = threadIdx.x >> 4, row = blockIdx.x * 16 + rw;
-  if (row >= n_rows) return;   // (no workgroup barrier below: a frame's 16 lanes sit in one wave)
+  const int l = threadIdx.x & 15, rw = threadIdx.x >> 4, row = blockIdx.x * FB_GSEL_FB + rw;
+  if (row < n_rows) {   // (no workgroup barrier inside: a frame's 16 lanes sit in one wave)
   const int capc = 2 * tpc;
   if (l == 0) s_n[rw] = 0;
   const float t = tau[row];
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(256) void k_gsel_final_w(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (have[q] && v4[i] >= t) {   // value r = 4 u + i = component cbase + (r & 3) + 8 (r >> 2)
-            if (pos < FB_GSEL_MAXC) s_key[rw][pos] = ((unsigned long long)fb_f32_ordered(v4[i]) << 32) | (unsigned)(cbase[q] + i + 8 * u);
+            if (pos < FB_GSEL_MAXW) s_key[rw][pos] = ((unsigned long long)fb_f32_ordered(v4[i]) << 32) | (unsigned)(cbase[q] + i + 8 * u);
             ++pos;
           }
       }
@@ -832,12 +842,16 @@ __global__ __launch_bounds__(256) void k_gsel_final_w(const float *__restrict__ 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int n = s_n[rw];
   if (n < min(nsel, C)) { if (l == 0) atomicOr(flag, 1); }   // (NaN features only: tau is the nsel-th largest group maximum)
-  if (n <= FB_GSEL_MAXC) {
+  if (n <= FB_GSEL_MAXW) {
     for (int i = l; i < n; i += 16) {
       const unsigned long long my = s_key[rw][i];
       int rank = 0;
       for (int q = 0; q < n; ++q) rank += s_key[rw][q] > my ? 1 : 0;
-      if (rank < nsel) sel[(size_t)row * nsel + rank] = (int)(unsigned)(my & 0xffffffffull);
+      if (rank < nsel) {
+        const int comp = (int)(unsigned)(my & 0xffffffffull);
+        sel[(size_t)row * nsel + rank] = comp;
+        if (cnt) atomicAdd(&s_hist[comp], 1);
+      }
     }
   } else {
     // more values at or above tau than the key list holds (ties by the hundred: degenerate models, constant features): rank
@@ -858,13 +872,26 @@ __global__ __launch_bounds__(256) void k_gsel_final_w(const float *__restrict__ 
         const unsigned long long kq = ((unsigned long long)fb_f32_ordered(vq) << 32) | (unsigned)(cb2 + (r2 & 3) + 8 * (r2 >> 2));
         rank += kq > my ? 1 : 0;
       }
-      if (rank < nsel) sel[(size_t)row * nsel + rank] = (int)(unsigned)(my & 0xffffffffull);
+      if (rank < nsel) {
+        const int comp = (int)(unsigned)(my & 0xffffffffull);
+        sel[(size_t)row * nsel + rank] = comp;
+        if (cnt) atomicAdd(&s_hist[comp], 1);
+      }
     }
   }
-  for (int s2 = n + l; s2 < nsel; s2 += 16) sel[(size_t)row * nsel + s2] = s2 % C;   // (NaN features: any valid index)
+  for (int s2 = n + l; s2 < nsel; s2 += 16) {   // (NaN features: any valid index)
+    sel[(size_t)row * nsel + s2] = s2 % C;
+    if (cnt) atomicAdd(&s_hist[s2 % C], 1);
+  }
+  }
+  if (cnt) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cpad; i += 1024) cnt[(size_t)blockIdx.x * Cpad + i] = s_hist[i];
+  }
 }
 void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
-                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel) {
+                         int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel, int *cnt,
+                         int Cpad) {
   if (rows_cap <= 0) return;
   const int tiles_a = fb_gsel_w_tiles_a(g, n_chunks, nsel);
   const int NG = 2 * n_chunks * tiles_a, tb = (rows_cap + 15) / 16;
@@ -873,8 +900,8 @@ void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, c
   else if (NG <= 128) hipLaunchKernelGGL(k_gsel_tau<8>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
   else hipLaunchKernelGGL(k_gsel_tau<16>, dim3(tb), dim3(256), 0, s, gmax, NG, n_rows_ptr, nsel, tau, flag);
   fb_launch_gsel_w(s, g, feats, n_rows_ptr, rows_cap, n_chunks, 1, nullptr, tau, gval, gid, gcnt, tiles_a);
-  hipLaunchKernelGGL(k_gsel_final_w, dim3(tb), dim3(256), 0, s, gval, gid, gcnt, tau, n_chunks, g.n_tiles / n_chunks, n_rows_ptr, nsel, g.C, sel,
-                     flag);
+  hipLaunchKernelGGL(k_gsel_final_w, dim3((rows_cap + FB_GSEL_FB - 1) / FB_GSEL_FB), dim3(1024), cnt ? sizeof(int) * (size_t)Cpad : 0, s, gval, gid,
+                     gcnt, tau, n_chunks, g.n_tiles / n_chunks, n_rows_ptr, nsel, g.C, sel, flag, cnt, Cpad);
 }
 
 void fb_launch_gmm_dump(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,

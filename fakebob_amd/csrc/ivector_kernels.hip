@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_iv_select(FbIvDev iv, const float *__re
 //   k_iv_bucket_fill   block = the same frames, walked in order by one wave: pairs[] ends up sorted by
 //                      (component, frame), i.e. utterance-major and in time order inside every bucket --
 //                      which is what lets k_iv_stats accumulate deterministically straight from the buckets.
-#define FB_IV_FB 64  // frames per partition block
+// (FB_IV_FB = 64 frames per partition block: fb_kernels.h)
 __global__ __launch_bounds__(256) void k_iv_bucket_count(FbIvDev iv, const int *__restrict__ n_rows_ptr,
                                                          const int *__restrict__ sel, int *__restrict__ cnt) {
   extern __shared__ int s_cnt[];  // [Cpad]
@@ -757,9 +757,13 @@ __global__ __launch_bounds__(256) void k_iv_post2(FbIvDev iv, const int *__restr
 size_t fb_iv_bucket_ws_ints(const FbIvDev &iv, int rows_cap) {
   return (size_t)5 * iv.C + 3 + (size_t)2 * ((rows_cap + FB_IV_FB - 1) / FB_IV_FB) * iv.Cpad;
 }
+int *fb_iv_bucket_cnt(const FbIvDev &iv, int *bucket_ws) {   // (the layout fb_launch_iv_select_post carves out below)
+  const int C = iv.C;
+  return bucket_ws + C + (C + 1) + (C + 1) + C + (C + 1);
+}
 void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll, const float *feats,
                               const int *n_rows_ptr, int rows_cap, int *sel, float *post, int *bucket_ws,
-                              int *pairs, float *llf, const int *sel_gate, bool run_select) {
+                              int *pairs, float *llf, const int *sel_gate, bool run_select, bool run_count) {
   if (rows_cap <= 0) return;
   const int C = iv.C;
   int *hist = bucket_ws, *bstart = hist + C, *wstart = bstart + (C + 1), *nz = wstart + (C + 1) + C,
@@ -776,7 +780,8 @@ void fb_launch_iv_select_post(hipStream_t s, const FbIvDev &iv, const float *ll,
     else hipLaunchKernelGGL(k_iv_select<64>, grid, blk, 0, s, iv, ll, n_rows_ptr, sel, sel_gate);  // C <= 4096 (fb_load_ivector)
   }
   const size_t lds_c = sizeof(int) * (size_t)iv.Cpad;
-  hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
+  if (run_count)   // (false: k_gsel_final_w has made the counts -- fb_launch_gsel_wide)
+    hipLaunchKernelGGL(k_iv_bucket_count, dim3(n_blk), dim3(256), lds_c, s, iv, n_rows_ptr, sel, cnt);
   {
     const int per = (n_blk + 15) / 16;
     const dim3 grid((C + 63) / 64), blk(1024);
