@@ -1998,9 +1998,13 @@ static int enqueue_get_grad(fb_engine *e, const fb_nes_params *p, int64_t N, uin
     }
     FbUpdArgs ux;
     if (upd) {
-      static const bool by_index = getenv("FB_FIN_BLOCKIDX") != nullptr;   // (A/B: roles by blockIdx)
+      // roles by blockIdx (the default again, round 6); FB_FIN_TICKET=1: by an arrival ticket (round 6's first answer to the
+      // advisor's finding -- 494 returning atomics on one word in front of every workgroup's work: 6.8 us per iteration of
+      // a lone attack, tools/profile/r06_fin.sh).  See the note at k_gmm_finalize_loss_update for why the launch cannot
+      // deadlock either way (read per launch: A/B inside one process)
+      const char *tk_env = getenv("FB_FIN_TICKET");
       ux = *upd;
-      ux.role_ticket = by_index ? nullptr : e->fin_counter.as<int>() + 1;
+      ux.role_ticket = (tk_env && tk_env[0] == '1') ? e->fin_counter.as<int>() + 1 : nullptr;
       upd = &ux;
     }
     if (upd && getenv("FB_FIN_COUNTER") == nullptr) {  // (FB_FIN_COUNTER=1: the arrival counter instead of the exchange slots, A/B)
@@ -2086,7 +2090,9 @@ static int run_attack_core(fb_engine *e, const fb_nes_params *p, int64_t N, cons
       if (fb_debug_sync_on()) fprintf(stderr, "[fb] iteration %d\n", it);
       // GMM systems on the fused chain: the update of this iteration and the batch of the next one ride in the launch
       // that finalises the scores and runs the loss body (k_gmm_finalize_loss_update; FB_FUSE_UPD=0: two launches)
-      const bool upd_ok = !noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_part(e, 1) && fb_fuse_part(e, 2);
+      // (at most FB_FUSE_MAX_UPD_WG update workgroups in the finalising launch: the bound its no-deadlock argument needs)
+      const bool upd_ok = !noise_dev && half > 0 && half <= FB_FUSE_MAX_HALF && fb_fuse_part(e, 1) && fb_fuse_part(e, 2) &&
+                          (N + 255) / 256 <= FB_FUSE_MAX_UPD_WG;
       const char *fu_env = getenv("FB_FUSE_UPD");   // (read per iteration: A/B inside one process)
       const bool no_fuse_upd = fu_env && fu_env[0] == '0';
       FbUpdArgs ua = {};

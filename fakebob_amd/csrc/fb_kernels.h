@@ -82,6 +82,7 @@ void fb_launch_loss(hipStream_t s, const double *raw, const int *tv, int B, int 
 // k_grad_update (iteration `next_iter - 1`) + k_perturb (iteration next_iter) in one launch; device-controlled attacks
 // with Philox noise and half <= FB_FUSE_MAX_HALF only.  Returns the number of distance partials written.
 #define FB_FUSE_MAX_HALF 40
+#define FB_FUSE_MAX_UPD_WG 192  // update workgroups k_gmm_finalize_loss_update may carry (N <= 49 152 samples; longer audio: k_update_perturb)
 // the arguments of k_update_perturb, for the launch that carries it behind the GMM finalisation + loss (below)
 struct FbUpdArgs {
   const double *loss;
@@ -98,7 +99,7 @@ struct FbUpdArgs {
   double *dist_part;
   double qscale;
   unsigned long long *xch;  // nullable: B x M exchange slots of the finalising workgroups, every one FB_VAD_SENTINEL between launches
-  int *role_ticket;         // nullable: k_gmm_finalize_loss_update's arrival ticket (zero between launches); null = roles by blockIdx
+  int *role_ticket;         // nullable (FB_FIN_TICKET=1): k_gmm_finalize_loss_update's arrival ticket (zero between launches); null = roles by blockIdx
 };
 int fb_launch_update_perturb(hipStream_t s, const double *loss, int64_t N, int half, double sigma, float *zbuf,
                              double momentum, double one_minus_m, double epsilon, const double *audio, double *grad_m,

@@ -1143,9 +1143,18 @@ __global__ __launch_bounds__(FB_FIN_THREADS) void k_gmm_finalize_loss(FbGmmDev g
 // (fb_update_perturb_body<WAIT>): they stage this iteration's normals and draw the next iteration's while the scores are
 // finalised, then wait for the loss body's publication (ctl->pub_seq, agent-scope stores / loads: no device-wide
 // fence) and go on.  One launch boundary less in a lone attack's chain, and the Philox + Box-Muller work -- most of
-// k_update_perturb -- off its critical path.  Roles are drawn from an arrival ticket (u.role_ticket): the finalising
-// workgroups are running or done before an update workgroup can wait for them, whatever order the hardware dispatches in.
-// (u.role_ticket == nullptr -- FB_FIN_BLOCKIDX=1, A/B only -- takes blockIdx and relies on index-order dispatch.)
+// k_update_perturb -- off its critical path.
+// Who waits for whom, and why that cannot deadlock (round-5 advisor finding, settled in round 6): the update workgroups spin
+// on the loss body's publication, the consumer -- the last-indexed finalising workgroup -- on the finalisers' slots; the
+// finalisers themselves never wait.  Roles follow blockIdx: the finalisers come first, and the hardware dispatches in index
+// order, so in practice nobody waits for a workgroup that is not running.  HIP does not promise that order -- but a deadlock
+// needs more: the spinners would have to hold EVERY slot of the chip while a finaliser is still undispatched.  A launch has
+// at most FB_FUSE_MAX_UPD_WG + 1 = 193 spinners (fb_engine.hip keeps longer audio on k_update_perturb), the fused chain is
+// what up to two attacks per GPU run (three with fb_set_fused_chain forced: 579), and the chip has at least 768 slots for
+// these 512-thread workgroups (three per compute unit at 42 KB of LDS); every other kernel that may hold slots finishes
+// without waiting for this launch.  So a free slot always comes up and every finaliser starts, whatever the order.
+// (FB_FIN_TICKET=1 draws the roles from an arrival ticket instead -- finalising roles first by construction; its 494
+// returning atomics on one word cost a lone attack 6.8 us per iteration: 0.1319 against 0.1251 ms, tools/profile/r06_fin.sh.)
 template <bool SMALL>
 __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, const float *__restrict__ part_m,
                                                            const float *__restrict__ part_s, int rows_cap,
@@ -1163,11 +1172,9 @@ __global__ __launch_bounds__(512) void k_gmm_finalize_loss_update(FbGmmDev g, co
   const int n_fin = B * g.M;
   int lin = (int)blockIdx.x;
   if (u.role_ticket) {
-    // Roles by ARRIVAL, not by blockIdx (round-5 advisor finding): the update workgroups spin on the loss body's
-    // publication and the consumer on the finalisers' slots, so a role must never wait for one that is not running yet.
-    // HIP does not promise dispatch in index order; a ticket does: the first B x M arrivals finalise (the last of THEM
-    // is the consumer -- every slot it polls belongs to an earlier ticket), the later ones update.  Every workgroup
-    // draws, stopping launch or not; the last ticket leaves the word at zero for the next launch.
+    // FB_FIN_TICKET=1: roles by ARRIVAL -- the first B x M arrivals finalise (the last of THEM is the consumer: every slot
+    // it polls belongs to an earlier ticket), the later ones update.  Every workgroup draws, stopping launch or not; the
+    // last ticket leaves the word at zero for the next launch.
     __shared__ int s_role;
     if (threadIdx.x == 0) {
       const int t = __hip_atomic_fetch_add(u.role_ticket, 1, FB_XCH_RMW, __HIP_MEMORY_SCOPE_AGENT);

@@ -220,9 +220,14 @@ def test_update_in_the_finalising_launch_equals_the_separate_launch(monkeypatch,
         got_counter = run()
         monkeypatch.delenv("FB_FIN_COUNTER", raising=False)
         got_again = run()     # (the slots were left clean by the launches before the counter ones)
+        # ... and with the workgroups' roles drawn from an arrival ticket instead of blockIdx (round 6: not the default any more)
+        monkeypatch.setenv("FB_FIN_TICKET", "1")
+        got_ticket = run()
+        monkeypatch.delenv("FB_FIN_TICKET", raising=False)
+        got_last = run()      # (the ticket word was left at zero)
     finally:
         e.close()
-    for other in (got, got_counter, got_again):
+    for other in (got, got_counter, got_again, got_ticket, got_last):
         for a, b in zip(ref[:3], other[:3]):
             assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
         assert ref[3][0] == other[3][0] and np.array_equal(ref[3][1], other[3][1])
