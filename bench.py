@@ -338,6 +338,9 @@ def bench_ivector(args, torch):
         tr, prov = committed_traffic("k_iv_contract_dma<lin>+<quad>")   # HBM bytes per launch (both kernels), PMC passes
         contraction["traffic"] = tr
         contraction.update(prov)
+        if tr and con_ms:   # the PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, committed profile) over this run's launch time
+            contraction["traffic_gbps"] = tr / (con_ms * 1e-3) / 1e9
+            contraction["traffic_frac_of_hbm_peak"] = contraction["traffic_gbps"] / PEAK_HBM_GBPS
         dominant = solve if (solve_ms or 0.0) >= con_ms else contraction
         out = {"metric": "NES iterations/sec (i-vector-PLDA %s, samples_per_draw=%d, 3 s@16 kHz)" % (task, spd), "value": its,
                "unit": "NES iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
