@@ -102,3 +102,36 @@ def test_threshold_selection_with_a_padded_last_tile_and_other_group_counts(C, m
     finally:
         e.close()
 
+
+
+def test_ties_by_the_hundred_take_the_final_kernels_record_path(monkeypatch):
+    """A degenerate UBM: components 0 .. 99 are copies of one component, so wherever that component is among a frame's best,
+    a hundred values tie at or above the threshold -- more than k_gsel_final_w ranks through LDS (64): it ranks them straight
+    from the records.  Equal values are ordered by component index, descending (std::greater<pair<float,int>>, as gmm-gselect
+    and k_iv_select do): the same selection as the dump path, slot for slot."""
+    from fakebob_amd.models import IvectorSystem
+    sy = synthetic_ivector_system(C=2048, D=72, R=64, L=32, n_speakers=1)
+    w, mic, icv = sy.fg_weights.copy(), sy.fg_means_invcovars.copy(), sy.fg_inv_covars.copy()
+    e = Engine(0)
+    try:
+        e.load_ivector(sy, "OSI")
+        wavs = [_wav(30 + u, 24000) for u in range(4)]
+        _, _, sel0, _, _ = _run(e, sy, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+        src = int(np.bincount(sel0.ravel(), minlength=2048).argmax())         # the component most frames select
+        w[:100], mic[:100], icv[:100] = w[src], mic[src], icv[src]
+        dup = IvectorSystem(w, mic, icv, sy.ie_M, sy.ie_sigma_inv, sy.prior_offset, sy.mean_vec, sy.lda, sy.plda_mean,
+                            sy.plda_transform, sy.plda_psi, sy.enrolled, sy.z_mean, sy.z_std, sy.num_gselect, sy.min_post)
+        e.load_ivector(dup, "OSI")
+        _, _, sel_d, info_d, ivs_d = _run(e, dup, wavs, monkeypatch, FB_IV_GSEL_DUMP="1")
+        _, _, sel_t, info_t, ivs_t = _run(e, dup, wavs, monkeypatch)
+        assert info_t["path"] == 2 and not info_d["threshold_path"] and info_t["overflow"] == 0
+        tied_rows = int(np.sum(np.sum(sel_d < 100, axis=1) >= 2))
+        assert tied_rows > 0                                                   # rows whose best 20 contain copies: >= 100 values tie
+        assert np.array_equal(sel_d, sel_t)
+        assert np.array_equal(ivs_d.view(np.uint64), ivs_t.view(np.uint64))
+        rows20 = sel_d[np.sum(sel_d < 100, axis=1) == 20]
+        if rows20.size:                                                        # all twenty are copies: the highest indices, descending
+            assert np.array_equal(rows20[0], np.arange(99, 79, -1))
+        print("degenerate UBM: %d of %d rows with tied copies among their best 20" % (tied_rows, sel_d.shape[0]))
+    finally:
+        e.close()
