@@ -54,8 +54,10 @@ int fb_debug_gmm_frames(fb_engine *e, const float *feats, int T, double *out);
 /* number of UBM components that received posterior mass in the last i-vector batch (only their
  * rows of Sigma^-1 M / U are streamed by the contraction kernels) */
 int fb_debug_iv_active(fb_engine *e, int *n_active);
-/* gmm-gselect of the last i-vector batch: sel[rows * num_gselect] (nullable), info[5] = {threshold path ran, its overflow
- * flag, most survivors in one (row, chunk) list, total survivors, rows} */
+/* gmm-gselect of the last i-vector batch: sel[rows * num_gselect] (nullable), info[5] = {which path ran -- 0: every
+ * log-likelihood dumped + k_iv_select, 1: the threshold selection's general form (k_gmm_fx2_sel: lists of survivors), 2: its
+ * wide form (k_gsel_w: 16-value records of the groups that reach the threshold) --, the flag (path 1: a list overflowed and
+ * the dump redid the batch), most entries of one (row, chunk) list, entries in total, rows} */
 int fb_debug_iv_gselect(fb_engine *e, int *sel, int64_t sel_cap, int64_t *info);
 /* time `reps` back-to-back launches of the GMM log-likelihood kernel on the
  * engine's stream with HIP events over the current device feature buffer
