@@ -999,6 +999,7 @@ extern "C" int fb_load_gmm(fb_engine *e, int M, int C, int D, const float *gcons
   g.mode = mode; g.NK = NK;
   g.text_scores = e->cfg.text_scores;
   g.only_if = nullptr;
+  g.fxw_sub = 0;
   g.images_bx = reinterpret_cast<decltype(g.images_bx)>(e->gmm_images_bx.p);
   g.NKF = NKF;
   g.kx = kx; g.kx2 = kx2; g.kacc = kacc;
@@ -1279,6 +1280,17 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
                    e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());
   FBCHK(run_post_mfcc(e, B));
   if (e->kind == 0) {
+    // A GPU shared by three or more attacks (fb_set_fused_chain(e, 0)): k_gmm_fx2w takes a whole compute unit per workgroup (one
+    // wave per SIMD with the full register file), and so does k_mfcc_f32 (four waves per SIMD at 122 registers) -- with a
+    // workgroup on nearly every unit nothing of the other attacks' front-ends runs while it does, and the chip alternated
+    // between one attack's k_gmm_fx2w and the others' k_mfcc_f32 / VAD (kernel trace, round 6: 62 + 19 us per iteration).
+    // With HALF as many workgroups, each scoring two component chunks one after the other (the same partial sums, bit for
+    // bit), the kernel alone is slower -- 92 us against 60 -- but the other half of the chip carries the other attacks'
+    // front-ends meanwhile: 12 319 -> 12 800 - 13 000 it/s (tools/profile/r06_fewer_wg.sh).  FB_GMM_SUB=1 | 2 forces either.
+    {
+      const char *sv = getenv("FB_GMM_SUB");
+      e->gmm.fxw_sub = sv ? atoi(sv) : (e->fuse_opt == 0 ? 2 : 1);
+    }
     FBCHK(time_begin(e));
     fb_launch_gmm(s, g, e->feats.as<float>(), e->row_off.as<int>() + B, total_frames, n_chunks,
                   e->part_m.as<float>(), e->part_s.as<float>());
@@ -2697,11 +2709,13 @@ extern "C" int fb_bench_gmm_kernel(fb_engine *e, int reps, double *ms_avg, int64
   HIPCHK(hipSetDevice(e->device));
   const int B = e->last_B, tf = e->last_total_frames;
   FBCHK(sync_stream(e));
-  fb_launch_gmm(e->stream, e->gmm, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
+  FbGmmDev gb = e->gmm;   // the launch shape of the last batch (FB_GMM_SUB: the other one -- bench.py times both)
+  if (const char *sv = getenv("FB_GMM_SUB")) gb.fxw_sub = atoi(sv);
+  fb_launch_gmm(e->stream, gb, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
                 e->part_m.as<float>(), e->part_s.as<float>());
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   for (int r = 0; r < reps; ++r)
-    fb_launch_gmm(e->stream, e->gmm, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
+    fb_launch_gmm(e->stream, gb, e->feats.as<float>(), e->row_off.as<int>() + B, tf, e->last_chunks,
                   e->part_m.as<float>(), e->part_s.as<float>());
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));

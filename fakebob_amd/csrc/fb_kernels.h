@@ -205,6 +205,8 @@ struct FbGmmDev {
   const int *stop;  // nullable device flag: != 0 -> the launch does nothing (attack already stopped)
   const int *only_if;  // nullable device flag: == 0 -> the DUMP launch does nothing (the gselect rescue: fb_launch_gsel)
   int text_scores;  // fb_frontend_cfg.text_scores: raw scores through Kaldi's 6-significant-digit text output
+  int fxw_sub;      // k_gmm_fx2w: component chunks ONE workgroup scores one after the other (0 / 1: one; 2: the launch of a GPU shared
+                    // by three or more attacks -- half as many workgroups as compute units, the same partial sums bit for bit)
 };
 #define FB_FXW_MAX_PASS 3 // launches of k_gmm_fx2w per batch: 1 + 9 x 3 = 28 models (fb_load_gmm)
 #define FB_FXW_MAX_M 10   // models ONE launch of k_gmm_fx2w takes: (1 + M) 10 KB items + the state of 2 M x 256 frames = 156 KB of LDS at M = 10

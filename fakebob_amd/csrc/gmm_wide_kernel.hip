@@ -434,16 +434,21 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
   constexpr int GA = (NI + 1) / 2, GB = NI - GA;  // a tile's items live in two LDS slots: A = items 0 .. GA-1, B = the rest
   FXW_STAMP(0);
   const int n_rows = *n_rows_ptr;
-  int strip_i, chunk_i;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
+  // A workgroup scores g.fxw_sub (1 or 2) of the n_chunks component chunks of its strip, one after the other: gchunk,
+  // gchunk + n_chunks / fxw_sub -- each exactly as a workgroup of its own would (same tiles in the same order from the same
+  // fresh state: the same partial sums, bit for bit), behind ONE prologue.  fxw_sub = 2 is the launch of a GPU shared by three or
+  // more attacks: half as many workgroups as compute units (fb_engine.hip, run_scoring).
+  int strip_i, gchunk;  // XCD-aware (strip, chunk) mapping, as in k_gmm_bx3
   if (xcd_map) {
     const int lin = blockIdx.x, per = 8 / xcd_map;
     const int xcd = lin & 7, idx = lin >> 3;
-    chunk_i = xcd / per;
+    gchunk = xcd / per;
     strip_i = idx * per + (xcd % per);
   } else {
     strip_i = blockIdx.x;
-    chunk_i = blockIdx.y;
+    gchunk = blockIdx.y;
   }
+  const int n_sub = g.fxw_sub > 1 ? g.fxw_sub : 1, grid_chunks = n_chunks / n_sub;
   const int strip0 = strip_i * 256;
   if (strip0 >= n_rows) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -633,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
     rn[hf] = rc[hf];
     set_ref(hf, rc[hf]);
   }
+  const float r_init[2] = {rc[0], rc[1]};   // (what every component chunk of this workgroup starts from)
 #pragma unroll
   for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = rc[m & 1]; st_s[m * 256 + tid] = 0.0f; }
 
@@ -696,6 +702,17 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
 #pragma unroll
     for (int b = 0; b < 3; ++b) asm volatile("" : "+a"(fq[hf][b]));  // parked beside the other frame operands
 
+  for (int sub = 0; sub < n_sub; ++sub) {
+  const int chunk_i = gchunk + sub * grid_chunks;
+  if (sub > 0) {   // the state of a workgroup that has not seen a tile yet
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      rc[hf] = r_init[hf]; rp[hf] = r_init[hf]; rn[hf] = r_init[hf];
+      set_ref(hf, rc[hf]);
+    }
+#pragma unroll
+    for (int m = 0; m < 2 * M; ++m) { st_m[m * 256 + tid] = rc[m & 1]; st_s[m * 256 + tid] = 0.0f; }
+  }
   // Component tiles of this chunk: chunk_i, chunk_i + n_chunks, ... (strided, so that every chunk gets the same mix of
   // the tile classes below).  fb_load_gmm stores the components SORTED by how far the other models moved them from
   // the base model (the order is free under logsumexp), so the products per K chunk a delta item needs (P, above
@@ -931,6 +948,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_fx2w(FbGmmDev g, const float *__
         part_s[o] = sx;
       }
     }
+  }
   FXW_STAMP(7);
 }
 
@@ -1181,13 +1199,17 @@ template <int NK, int M>
 static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr,
                              int rows_cap, int n_chunks, float *part_m, float *part_s) {
   const int strips = (rows_cap + 255) / 256;
-  dim3 grid((unsigned)strips, (unsigned)n_chunks);
+  // (component chunks a workgroup scores one after the other: FbGmmDev::fxw_sub when it divides the chunk count)
+  FbGmmDev gl = g;
+  gl.fxw_sub = (g.fxw_sub > 1 && n_chunks % g.fxw_sub == 0) ? g.fxw_sub : 1;
+  const int gchunks = n_chunks / gl.fxw_sub;
+  dim3 grid((unsigned)strips, (unsigned)gchunks);
   int xcd_map = 0;
   static const bool no_xcd_map = getenv("FB_GMM_NO_XCD_MAP") != nullptr;
-  if ((n_chunks == 1 || n_chunks == 2 || n_chunks == 4 || n_chunks == 8) && !no_xcd_map) {
-    const int per = 8 / n_chunks;
+  if ((gchunks == 1 || gchunks == 2 || gchunks == 4 || gchunks == 8) && !no_xcd_map) {
+    const int per = 8 / gchunks;
     grid = dim3((unsigned)(8 * ((strips + per - 1) / per)), 1);
-    xcd_map = n_chunks;
+    xcd_map = gchunks;
   }
   const size_t ldsb = ((size_t)(M + 1) * 2 * NK * 64 + 2 * 192) * 16 + (size_t)2 * M * 512 * sizeof(float);  // one tile (two padded slots) + the state
   static std::atomic<unsigned long long> optin{0};
@@ -1197,7 +1219,7 @@ static void launch_gmm_fxw_t(hipStream_t s, const FbGmmDev &g, const float *feat
                             160 * 1024) == hipSuccess)
       optin.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_gmm_fx2w<NK, M>), grid, dim3(256), ldsb, s, g, feats, n_rows_ptr, n_chunks, rows_cap, part_m, part_s,
+  hipLaunchKernelGGL((k_gmm_fx2w<NK, M>), grid, dim3(256), ldsb, s, gl, feats, n_rows_ptr, n_chunks, rows_cap, part_m, part_s,
                      xcd_map);
 }
 // k_gmm_fx2w is instantiated for the shapes the reference's systems have with the recipe's 72-dimensional features

@@ -2,7 +2,7 @@
 # round-6 profile set on the GPU box: rocprofv3 kernel-trace stats of the bench commands (GMM headline with 1 / 3
 # attacks in flight, three products / the F6 class forced, realistic enrolment, the reference-pipeline mode, GMM CSI, i-vector SV
 # spd=50 and OSI spd=200), the HBM-traffic PMC passes (separate runs, --kernel-trace only, one counter group per pass)
-# and the default bench lines.  traffic.json records the hash of the kernel sources it was taken on: bench.py reports
+# and the default bench lines.  The GMM PMC passes run the chain of a shared GPU (--chain unfused: the headline's launch shapes).  traffic.json records the hash of the kernel sources it was taken on: bench.py reports
 # roofline.traffic only while that hash is the build's (bench.kernel_source_hash()).
 # usage: gpurun -- 'bash tools/profile/prof_r06.sh r06_a [commit]'   ->  gpurun_out/<tag>/
 R=$GRAFT_REPO_ROOT; tag=$1; commit=${2:-unknown}; O=$R/gpurun_out/$tag; mkdir -p $O
@@ -15,6 +15,7 @@ prof() {  # name, bench args...
 }
 prof gmm_1attack --steps 100 --warmup 10 --streams 1
 prof gmm_3attacks --steps 100 --warmup 10
+prof gmm_1attack_shared_gpu_chain --steps 100 --warmup 10 --streams 1 --chain unfused   # the headline's launch shapes, alone on the chip
 FB_GMM_DELTA_P=3 prof gmm_p3_1attack --steps 100 --warmup 10 --streams 1
 FB_GMM_DELTA_P=6 prof gmm_f6_1attack --steps 100 --warmup 10 --streams 1
 prof gmm_realistic_1attack --steps 100 --warmup 10 --streams 1 --enrol realistic
@@ -24,7 +25,7 @@ prof iv_sv_1attack --arch iv --steps 50 --warmup 5 --streams 1
 prof iv_osi_b201_1attack --arch iv --task OSI --speakers 10 --spd 200 --steps 20 --warmup 3 --streams 1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$name -o p -- python $R/bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$name -o p -- python $R/bench.py --steps 20 --warmup 3 --streams 1 --chain unfused --no-cpu-baseline --no-secondary > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmciv_$name -o p -- python $R/bench.py --arch iv --steps 10 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
 done
 cd $R
