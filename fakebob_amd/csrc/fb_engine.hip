@@ -1275,6 +1275,10 @@ static int run_scoring(fb_engine *e, int B, int total_frames) {
   }
   FBCHK(e->raw.ensure(sizeof(double) * (size_t)B * e->n_out));
   hipStream_t s = e->stream;
+  {  // (a GPU shared by three or more attacks: k_mfcc_f32 on half of the compute units, like k_gmm_fx2w above; FB_MFCC_CUS=n forces)
+    const char *cv = getenv("FB_MFCC_CUS");
+    e->fe.mfcc_cus = cv ? atoi(cv) : (e->fuse_opt == 0 ? 128 : 0);
+  }
   if (!(fe.mfcc_f32 && fb_launch_mfcc_f32(s, fe, e->melw_n, e->wav.as<int16_t>(), e->frame_rec.as<int32_t>(), total_frames, e->mfcc.as<float>(), e->uni_T, e->uni_n, e->h_wav_off[0])))
     fb_launch_mfcc(s, fe, e->melw_n, e->wav.as<int16_t>(), e->wav_off.as<int64_t>(), e->frame_off.as<int>(),
                    e->frame_rec.as<int32_t>(), B, total_frames, e->mfcc.as<float>());

@@ -27,6 +27,7 @@ struct FbFrontendDev {
   const double *dscale;   // [(order+1)][2*order*dwin+1] delta kernels (float32 values widened)
   const float *f32_tab;   // k_mfcc_f32's tables as one float32 blob in its LDS layout (fb_mfcc_f32_table; null: not supported)
   const int *stop;        // nullable device flag: != 0 -> k_mfcc does nothing (attack already stopped)
+  int mfcc_cus;           // k_mfcc_f32: compute units the launch may take (0 = all); set per batch by the engine
 };
 
 // ---- NES ----------------------------------------------------------------

@@ -507,7 +507,10 @@ bool fb_launch_mfcc_f32(hipStream_t s, const FbFrontendDev &fe, int melw_n, cons
     optin.fetch_or(bit, std::memory_order_release);
   }
   const int n_groups = (total_frames + 3) / 4;
-  const int rounds = (n_groups + 256 * FB_F32_WAVES - 1) / (256 * FB_F32_WAVES);
+  // compute units the launch may take (fe.mfcc_cus, 0 = all 256): a workgroup fills its unit (16 waves at 122 registers), so on
+  // a GPU shared by several attacks the launch is held to half of them and walks its frames in two rounds (fb_engine.hip)
+  const int cus = fe.mfcc_cus > 0 && fe.mfcc_cus < 256 ? fe.mfcc_cus : 256;
+  const int rounds = (n_groups + cus * FB_F32_WAVES - 1) / (cus * FB_F32_WAVES);
   const int blocks = (n_groups + rounds * FB_F32_WAVES - 1) / (rounds * FB_F32_WAVES);
   const int4 *rec = reinterpret_cast<const int4 *>(frame_rec);
   const int words = getenv("FB_MFCC_HALFWORDS") == nullptr;  // (A/B and the parity test of the 16-bit load path)
