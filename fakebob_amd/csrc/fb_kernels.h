@@ -256,7 +256,7 @@ void fb_launch_gsel(hipStream_t s, const FbGmmDev &g, const float *feats, const 
 // the wide form (k_gsel_w / k_gsel_final_w): fb_gsel_wide_chunks() > 0 = it applies, with that many component chunks.  gval:
 // rows_cap x 32 n_tiles floats (the dump's buffer serves), gid: rows_cap x 2 n_tiles bytes, gcnt: rows_cap x n_chunks ints.
 // No overflow and no rescue: sel[] is final (flag is raised by NaN features only).
-int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap);
+int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap, int target_blocks = 256 /* workgroups the passes aim at */);
 void fb_launch_gsel_wide(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks,
                          int nsel, float *gmax, float *tau, float *gval, unsigned char *gid, int *gcnt, int *flag, int *sel,
                          int *cnt /* nullable: fb_iv_bucket_cnt() -- the bucket sort's per-block counts, made here */, int Cpad);

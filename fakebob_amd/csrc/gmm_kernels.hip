@@ -752,11 +752,13 @@ bool fb_gsel_w_applies(const FbGmmDev &g, int n_chunks);   // gmm_wide_kernel.hi
 void fb_launch_gsel_w(hipStream_t s, const FbGmmDev &g, const float *feats, const int *n_rows_ptr, int rows_cap, int n_chunks, int pick,
                       float *gmax, const float *tau, float *gval, unsigned char *gid, int *gcnt, int tiles_a);
 int fb_gsel_w_tiles_a(const FbGmmDev &g, int n_chunks, int nsel);
-int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap) {
+int fb_gsel_wide_chunks(const FbGmmDev &g, int nsel, int rows_cap, int target_blocks) {
   if (getenv("FB_IV_GSEL_DUMP") != nullptr) return 0;
   if (!(g.mode == FB_GMM_MODE_FX2 && g.M == 1 && g.n_items == 2 && 2 * g.n_tiles >= 4 * nsel && 2 * g.n_tiles <= 256 && nsel <= 32)) return 0;
   const int strips = (rows_cap + 255) / 256;
-  int want = 256 / (strips > 0 ? strips : 1);
+  if (const char *ev = getenv("FB_GSEL_TARGET_BLOCKS")) target_blocks = atoi(ev);
+  int want = (target_blocks > 0 ? target_blocks : 256) / (strips > 0 ? strips : 1);
+  if (want < 1) want = 1;
   int n = 8;
   while (n > 1 && (n > want || !fb_gsel_w_applies(g, n))) n >>= 1;
   return fb_gsel_w_applies(g, n) ? n : 0;
